@@ -1,0 +1,205 @@
+/*
+ * plhip.h — C ABI of libplhip.so: the MI355X (gfx950) hash group-by aggregation path.
+ *
+ * This header is the drop-in boundary for ONE hot path of Polars 0.33.2 (reference repo
+ * backend-devloper/polars): hash group-by aggregation over Arrow-backed columns.  Every entry point
+ * cites the reference interface it replaces as `path:line` relative to the reference root.  A Rust
+ * `polars-hip-sys` crate would bind these 1:1 (see INTEGRATION.md for the binding stubs).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types cross this boundary;
+ *   - every function returns a plhip_status_t (0 = OK) and never unwinds; a human readable message for
+ *     the calling thread's last failure is available from plhip_last_error();
+ *   - columns follow the Arrow primitive layout the reference uses
+ *     (crates/nano-arrow/src/array/primitive/mod.rs:48-52): a values buffer, an optional LSB-first
+ *     validity bitmap (crates/nano-arrow/src/bitmap/utils/mod.rs:19,77-79) and an element offset that
+ *     applies to both;
+ *   - `location` says where the buffers live: host memory (the library stages them through pinned
+ *     buffers) or device memory of the current HIP device (zero-copy; what bench.py uses);
+ *   - all entry points are thread safe; calls that run concurrently on one device serialise on that
+ *     device's stream pool;
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry point fails with
+ *     PLHIP_ERR_NO_DEVICE.
+ */
+#ifndef PLHIP_H
+#define PLHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PLHIP_ABI_VERSION 1
+
+/* Mirrors the PolarsError kinds this path can raise (crates/polars-error/src/lib.rs;
+ * crates/polars-core/src/frame/group_by/mod.rs:59-73: ComputeError for zero keys, ShapeMismatch for
+ * key/frame length mismatch). */
+typedef enum plhip_status {
+  PLHIP_OK = 0,
+  PLHIP_ERR_COMPUTE = 1,           /* PolarsError::ComputeError */
+  PLHIP_ERR_SHAPE_MISMATCH = 2,    /* PolarsError::ShapeMismatch */
+  PLHIP_ERR_OOM = 3,               /* allocation failure (host or HBM) */
+  PLHIP_ERR_UNSUPPORTED_DTYPE = 4, /* PolarsError::InvalidOperation for this path */
+  PLHIP_ERR_HIP = 5,               /* a HIP runtime call failed; message holds hipGetErrorString */
+  PLHIP_ERR_INVALID = 6,           /* NULL pointer / bad enum / bad index at the ABI */
+  PLHIP_ERR_NO_DEVICE = 7          /* no gfx950 device visible; the library has no CPU path */
+} plhip_status_t;
+
+/* Physical dtypes of the hot path (crates/polars-core/src/datatypes/dtype.rs; Categorical keys arrive
+ * as their u32 physical codes, crates/polars-core/src/frame/group_by/mod.rs:33-34). */
+typedef enum plhip_dtype {
+  PLHIP_I8 = 0,
+  PLHIP_I16 = 1,
+  PLHIP_I32 = 2,
+  PLHIP_I64 = 3,
+  PLHIP_U8 = 4,
+  PLHIP_U16 = 5,
+  PLHIP_U32 = 6,
+  PLHIP_U64 = 7,
+  PLHIP_F32 = 8,
+  PLHIP_F64 = 9
+} plhip_dtype_t;
+
+typedef enum plhip_location { PLHIP_HOST = 0, PLHIP_DEVICE = 1 } plhip_location_t;
+
+/* One single-chunk Arrow primitive array (the reference rechunks before this path:
+ * crates/polars-lazy/src/physical_plan/executors/group_by.rs:66,
+ * crates/polars-core/src/frame/group_by/aggregations/mod.rs:625). */
+typedef struct plhip_column {
+  const void *values;      /* buffer start (element 0 of the BUFFER, before `offset`) */
+  const uint8_t *validity; /* LSB-first bitmap over the buffer, or NULL = no nulls */
+  int64_t offset;          /* Arrow array offset in elements, applied to values and validity */
+  int64_t length;          /* number of elements */
+  int32_t dtype;           /* plhip_dtype_t */
+  int32_t location;        /* plhip_location_t */
+} plhip_column_t;
+
+/* GroupByMethod subset on the path (crates/polars-core/src/frame/group_by/mod.rs:844-861). */
+typedef enum plhip_agg_kind {
+  PLHIP_AGG_SUM = 0,   /* aggregations/mod.rs:622-688 */
+  PLHIP_AGG_MEAN = 1,  /* aggregations/mod.rs:701-779 (float), 941-1016 (int) */
+  PLHIP_AGG_MIN = 2,   /* aggregations/mod.rs:459-537 */
+  PLHIP_AGG_MAX = 3,   /* aggregations/mod.rs:539-620 */
+  PLHIP_AGG_COUNT = 4  /* proxy.rs:452-466: group length INCLUDING nulls, as IdxSize (u32) */
+} plhip_agg_kind_t;
+
+typedef struct plhip_agg {
+  int32_t column; /* index into the `values` array; ignored for COUNT */
+  int32_t kind;   /* plhip_agg_kind_t */
+} plhip_agg_t;
+
+/* flags for plhip_group_by_agg */
+#define PLHIP_FLAG_MAINTAIN_ORDER 1u /* group_by_stable: groups ordered by first row (hashing.rs:32-79) */
+#define PLHIP_FLAG_OUTPUT_DEVICE 2u  /* result buffers stay in HBM (device pointers) */
+#define PLHIP_FLAG_PARTIAL 4u        /* emit mergeable partial state instead of final values: MEAN becomes
+                                        two columns (sum, valid count) as in AggregationExpr::
+                                        evaluate_partitioned (crates/polars-lazy/src/physical_plan/
+                                        expressions/aggregation.rs:283-365) */
+#define PLHIP_FLAG_SORT_KEYS 8u      /* canonical output order: ascending by key tuple, nulls first
+                                        (test/bench convenience; no reference counterpart) */
+
+/* strategy override, PLHIP_STRATEGY env var or plhip_set_strategy(): mirrors the reference's
+ * POLARS_NO_PARTITION / POLARS_FORCE_PARTITION switches
+ * (crates/polars-lazy/src/physical_plan/executors/group_by_partitioned.rs:167-186). */
+typedef enum plhip_strategy {
+  PLHIP_STRATEGY_AUTO = 0,
+  PLHIP_STRATEGY_GLOBAL = 1,     /* every row updates the HBM-resident table */
+  PLHIP_STRATEGY_LDS = 2,        /* per-workgroup LDS tables, then one merge into the HBM table */
+  PLHIP_STRATEGY_PARTITIONED = 3 /* radix partition on hash bits, then one LDS table per partition */
+} plhip_strategy_t;
+
+typedef struct plhip_result plhip_result_t; /* opaque: a frame of output columns */
+typedef struct plhip_groups plhip_groups_t; /* opaque: GroupsProxy::Idx as CSR */
+
+/* ---- library ------------------------------------------------------------------------------------ */
+
+/* ABI version of the loaded library (== PLHIP_ABI_VERSION of the header it was built from). */
+int32_t plhip_abi_version(void);
+
+/* Selects the HIP device for the calling thread and creates its stream/workspace pool.
+ * Reference analogue: the global rayon POOL (crates/polars-core/src/lib.rs:49-62). */
+int32_t plhip_init(int32_t device_id);
+
+/* Message for the calling thread's last non-OK status ("" if none). Never NULL. */
+const char *plhip_last_error(void);
+
+int32_t plhip_set_strategy(int32_t strategy /* plhip_strategy_t */);
+
+/* Name of the strategy the last plhip_group_by_agg call on this thread ran
+ * ("global", "lds", "partitioned"); the POLARS_VERBOSE analogue
+ * (crates/polars-lazy/src/physical_plan/executors/group_by.rs:124-126). */
+const char *plhip_last_strategy(void);
+
+/* Milliseconds the device spent in the kernels of the last plhip_group_by_agg call on this thread
+ * (HIP events on the library's own stream around the launches; staging copies excluded), and the
+ * part of it spent in the dominant kernel.  Used by bench.py for `roofline.achieved`. */
+int32_t plhip_last_kernel_ms(float *total_ms, float *dominant_ms, const char **dominant_kernel);
+
+/* ---- hashing ------------------------------------------------------------------------------------ */
+
+/* VecHash::vec_hash on keys[0] then VecHash::vec_hash_combine for keys[1..]
+ * (crates/polars-core/src/hashing/vector_hasher.rs:78-139, series_to_hashes :467-483):
+ *   h = folded_multiply(as_u64(v), 6364136223846793005) ; combine: h = folded_multiply(as_u64(v) ^ h, M)
+ * Null rows hash to `null_hash` (get_null_hash_value :42-51 is seed dependent, so the caller supplies
+ * it).  Float columns hash their bit pattern (:304-326).  `out` has keys[0].length u64 elements and
+ * lives where `out_location` says. */
+int32_t plhip_vec_hash(const plhip_column_t *keys, int32_t n_keys, uint64_t null_hash, uint64_t *out,
+                       int32_t out_location);
+
+/* ---- fused group-by + aggregation ------------------------------------------------------------- */
+
+/* Replaces group_by_helper / GroupByExec::execute end to end
+ * (crates/polars-lazy/src/physical_plan/executors/group_by.rs:57-148) and the low-cardinality
+ * PartitionGroupByExec (group_by_partitioned.rs:273-361): groups `keys` (null key = its own group,
+ * float keys by bit pattern) and evaluates `aggs` over `values`.
+ * Output frame = key columns (input dtypes) followed by one column per agg, in order
+ * (group_by.rs:91-94).  Output dtypes follow the reference:
+ *   SUM   i8/i16/u8/u16 -> i64 (series/implementations/mod.rs:167-174); i32,u32,i64,u64 wrap in their
+ *         own type; f32 -> f32; f64 -> f64; empty/all-null group -> 0, never null
+ *   MEAN  f32 -> f32, everything else -> f64; all-null group -> null
+ *   MIN/MAX own dtype; floats ignore NaN; all-null group -> null
+ *   COUNT u32
+ * Errors: n_keys == 0 -> PLHIP_ERR_COMPUTE; length mismatch -> PLHIP_ERR_SHAPE_MISMATCH
+ * (group_by/mod.rs:59-73). */
+int32_t plhip_group_by_agg(const plhip_column_t *keys, int32_t n_keys, const plhip_column_t *values,
+                           int32_t n_values, const plhip_agg_t *aggs, int32_t n_aggs, uint32_t flags,
+                           plhip_result_t **out);
+
+/* ---- result frame accessors ------------------------------------------------------------------- */
+
+int64_t plhip_result_num_rows(const plhip_result_t *r);    /* number of groups */
+int32_t plhip_result_num_columns(const plhip_result_t *r); /* n_keys + n output columns */
+/* Fills `col` with the i-th output column (location = host unless PLHIP_FLAG_OUTPUT_DEVICE). The
+ * buffers belong to the result and die with plhip_result_free. */
+int32_t plhip_result_column(const plhip_result_t *r, int32_t i, plhip_column_t *col);
+void plhip_result_free(plhip_result_t *r);
+
+/* ---- two-step API: the seams a Rust host layer would rebind -------------------------------------- */
+
+/* IntoGroupsProxy::group_tuples (crates/polars-core/src/frame/group_by/into_groups.rs:12-19) for one
+ * key and group_by_threaded_multiple_keys_flat (hashing.rs:380-468) for several: builds
+ * GroupsProxy::Idx (proxy.rs:16-20) as CSR: first[G], offsets[G+1], indices[N]; indices ascending
+ * inside a group, first[g] == indices[offsets[g]].  `sorted` != 0 orders groups by first
+ * (hashing.rs:32-79); otherwise the order is unspecified, as in the reference. */
+int32_t plhip_group_tuples(const plhip_column_t *keys, int32_t n_keys, int32_t sorted, int32_t out_location,
+                           plhip_groups_t **out);
+int64_t plhip_groups_num_groups(const plhip_groups_t *g);
+int64_t plhip_groups_num_rows(const plhip_groups_t *g);
+/* Pointers (u32 = IdxSize, crates/polars-utils/src/lib.rs:19-22) owned by the handle. */
+int32_t plhip_groups_buffers(const plhip_groups_t *g, const uint32_t **first, const uint32_t **offsets,
+                             const uint32_t **indices, int32_t *location);
+void plhip_groups_free(plhip_groups_t *g);
+
+/* Series::agg_sum / agg_mean / agg_min / agg_max on GroupsProxy::Idx
+ * (crates/polars-core/src/series/series_trait.rs:129-154, aggregations/mod.rs:459-779,941-1016) and
+ * GroupsProxy::group_count (proxy.rs:452-466) for kind == COUNT (values may be NULL then).
+ * Returns a one-column result frame with G rows. */
+int32_t plhip_agg_groups(const plhip_column_t *values, int32_t kind, const plhip_groups_t *groups,
+                         uint32_t flags, plhip_result_t **out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLHIP_H */

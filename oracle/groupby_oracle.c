@@ -1,0 +1,649 @@
+/*
+ * groupby_oracle.c — CPU restatement (plain C11 + pthreads) of Polars 0.33.2's hash group-by path.
+ *
+ * TEST INFRASTRUCTURE ONLY: the checker for tests/, __graft_entry__.smoke() and the timed CPU baseline
+ * of bench.py.  Never linked into, imported by or called from the product (polars_amd/, libplhip.so).
+ *
+ * The reference is Rust and cannot be built or imported in this image (no rustc/cargo, no polars
+ * wheel), so this file restates its algorithm from source; every function cites the reference lines it
+ * follows (paths relative to the reference root).  It is pinned by the reference's own known-answer
+ * tests, transcribed to tests/golden/reference_known_answers.json (tests/test_oracle_golden.py).
+ *
+ * What is restated faithfully: hashing arithmetic, the partition predicate and P, group membership
+ * (key-bit equality, null = own group), first[]/ascending index lists, the `sorted` group order, the
+ * sequential left-fold order and every dtype/null/NaN rule of agg_sum/mean/min/max/count.
+ * What is NOT reproducible by construction: hashbrown/ahash table iteration order (per-process random
+ * seed in the reference) -> unsorted group order here is partition order, insertion order inside.
+ */
+#include "groupby_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---------------------------------------------------------------------------------------------- */
+/* hashing                                                                                        */
+/* ---------------------------------------------------------------------------------------------- */
+
+/* vector_hasher.rs:14 */
+#define ORC_MULTIPLE 6364136223846793005ULL
+
+/* vector_hasher.rs:37-40 */
+uint64_t orc_folded_multiply(uint64_t s, uint64_t by) {
+  unsigned __int128 r = (unsigned __int128)s * (unsigned __int128)by;
+  return (uint64_t)r ^ (uint64_t)(r >> 64);
+}
+
+static inline int col_width(int dtype) {
+  switch (dtype) {
+    case PLHIP_I8: case PLHIP_U8: return 1;
+    case PLHIP_I16: case PLHIP_U16: return 2;
+    case PLHIP_I32: case PLHIP_U32: case PLHIP_F32: return 4;
+    case PLHIP_I64: case PLHIP_U64: case PLHIP_F64: return 8;
+    default: return 0;
+  }
+}
+
+static inline int col_valid(const plhip_column_t *c, int64_t i) {
+  if (!c->validity) return 1;
+  int64_t b = c->offset + i;
+  return (c->validity[b >> 3] >> (b & 7)) & 1; /* nano-arrow bitmap/utils/mod.rs:77-79 (LSB first) */
+}
+
+/* AsU64 (hashing/partition.rs:5-65): i8/i16 `as u64` sign-extend, i32 is transmuted to u32 first,
+ * floats hash their bit pattern (vector_hasher.rs:304-326 -> bit_repr_small/large). */
+static inline uint64_t col_as_u64(const plhip_column_t *c, int64_t i) {
+  int64_t j = c->offset + i;
+  switch (c->dtype) {
+    case PLHIP_I8: return (uint64_t)(int64_t)((const int8_t *)c->values)[j];
+    case PLHIP_I16: return (uint64_t)(int64_t)((const int16_t *)c->values)[j];
+    case PLHIP_U8: return ((const uint8_t *)c->values)[j];
+    case PLHIP_U16: return ((const uint16_t *)c->values)[j];
+    case PLHIP_I32: case PLHIP_U32: case PLHIP_F32: return ((const uint32_t *)c->values)[j];
+    default: return ((const uint64_t *)c->values)[j];
+  }
+}
+
+/* Key bits used for group EQUALITY: the same-width unsigned bit pattern
+ * (group_by/mod.rs:29-50 prepare_dataframe_unsorted; into_groups.rs:152-211 reinterpret/bit_repr). */
+static inline uint64_t col_key_bits(const plhip_column_t *c, int64_t i) {
+  int64_t j = c->offset + i;
+  switch (col_width(c->dtype)) {
+    case 1: return ((const uint8_t *)c->values)[j];
+    case 2: return ((const uint16_t *)c->values)[j];
+    case 4: return ((const uint32_t *)c->values)[j];
+    default: return ((const uint64_t *)c->values)[j];
+  }
+}
+
+int orc_vec_hash(const plhip_column_t *keys, int n_keys, uint64_t null_h, uint64_t *out) {
+  if (n_keys < 1 || !keys || !out) return PLHIP_ERR_INVALID;
+  int64_t n = keys[0].length;
+  for (int k = 0; k < n_keys; k++) {
+    if (keys[k].length != n) return PLHIP_ERR_SHAPE_MISMATCH;
+    if (!col_width(keys[k].dtype)) return PLHIP_ERR_UNSUPPORTED_DTYPE;
+  }
+  /* integer_vec_hash (vector_hasher.rs:78-101) + insert_null_hash (:53-71) */
+  for (int64_t i = 0; i < n; i++)
+    out[i] = col_valid(&keys[0], i) ? orc_folded_multiply(col_as_u64(&keys[0], i), ORC_MULTIPLE) : null_h;
+  /* integer_vec_hash_combine (:103-139) */
+  for (int k = 1; k < n_keys; k++)
+    for (int64_t i = 0; i < n; i++) {
+      uint64_t to_hash = col_valid(&keys[k], i) ? col_as_u64(&keys[k], i) : null_h;
+      out[i] = orc_folded_multiply(to_hash ^ out[i], ORC_MULTIPLE);
+    }
+  return PLHIP_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* group tuples                                                                                   */
+/* ---------------------------------------------------------------------------------------------- */
+
+typedef struct {
+  /* normalised keys, shared read-only */
+  int n_keys;
+  int64_t n;
+  uint64_t **kb;      /* [n_keys][n] key bits (0 for null) */
+  uint64_t *nullmask; /* [n] bit k set = key k is null; NULL when no key is nullable */
+  uint64_t *part_x;   /* [n] partition value x (hashing.rs:215 single key: key bits; :430 multi: hash) */
+  uint64_t n_partitions;
+  uint32_t *row_lgid; /* [n] local group id inside the row's partition */
+} gt_shared_t;
+
+typedef struct {
+  gt_shared_t *sh;
+  uint64_t thread_no;
+  /* private open-addressing table: slot -> local gid + 1 (0 = empty) */
+  uint32_t *slots;
+  uint64_t cap;
+  uint32_t n_groups;
+  uint32_t *first; /* [n_groups] */
+  uint32_t *count; /* [n_groups] */
+  uint64_t gcap;
+  int err;
+} gt_part_t;
+
+static inline uint64_t tuple_hash(const gt_shared_t *sh, int64_t row) {
+  uint64_t h = orc_folded_multiply(sh->kb[0][row] ^ (sh->nullmask ? sh->nullmask[row] * 0x9e3779b97f4a7c15ULL : 0),
+                                   ORC_MULTIPLE);
+  for (int k = 1; k < sh->n_keys; k++) h = orc_folded_multiply(sh->kb[k][row] ^ h, ORC_MULTIPLE);
+  return h;
+}
+
+/* compare_keys (hashing.rs:319-330): column by column; null == null (null key is its own group). */
+static inline int tuple_eq(const gt_shared_t *sh, int64_t a, int64_t b) {
+  if (sh->nullmask && sh->nullmask[a] != sh->nullmask[b]) return 0;
+  for (int k = 0; k < sh->n_keys; k++)
+    if (sh->kb[k][a] != sh->kb[k][b]) return 0;
+  return 1;
+}
+
+static int part_grow_table(gt_part_t *p) {
+  uint64_t ncap = p->cap * 2;
+  uint32_t *ns = (uint32_t *)calloc(ncap, sizeof(uint32_t));
+  if (!ns) return -1;
+  for (uint32_t g = 0; g < p->n_groups; g++) {
+    uint64_t s = tuple_hash(p->sh, p->first[g]) & (ncap - 1);
+    while (ns[s]) s = (s + 1) & (ncap - 1);
+    ns[s] = g + 1;
+  }
+  free(p->slots);
+  p->slots = ns;
+  p->cap = ncap;
+  return 0;
+}
+
+/* One partition's scan: group_by_threaded_slice body (hashing.rs:200-239) /
+ * group_by_threaded_multiple_keys_flat body (:403-464): walk ALL rows in order, keep the rows of this
+ * partition, insert-or-push.  The per-group Vec<IdxSize> is replaced by (first, count) + a row->gid
+ * map that a counting sort turns into the same ascending index lists. */
+static void *part_scan(void *arg) {
+  gt_part_t *p = (gt_part_t *)arg;
+  gt_shared_t *sh = p->sh;
+  const uint64_t mask = sh->n_partitions - 1;
+  p->cap = 1024; /* _HASHMAP_INIT_SIZE = 512 entries (hashing/mod.rs:26) at load 0.5 */
+  p->slots = (uint32_t *)calloc(p->cap, sizeof(uint32_t));
+  p->gcap = 512;
+  p->first = (uint32_t *)malloc(p->gcap * sizeof(uint32_t));
+  p->count = (uint32_t *)malloc(p->gcap * sizeof(uint32_t));
+  if (!p->slots || !p->first || !p->count) { p->err = 1; return NULL; }
+  for (int64_t row = 0; row < sh->n; row++) {
+    /* this_partition (hashing/partition.rs:134-138) */
+    if ((sh->part_x[row] & mask) != p->thread_no) continue;
+    uint64_t s = tuple_hash(sh, row) & (p->cap - 1);
+    for (;;) {
+      uint32_t v = p->slots[s];
+      if (!v) { /* RawEntryMut::Vacant */
+        if (p->n_groups == p->gcap) {
+          p->gcap *= 2;
+          p->first = (uint32_t *)realloc(p->first, p->gcap * sizeof(uint32_t));
+          p->count = (uint32_t *)realloc(p->count, p->gcap * sizeof(uint32_t));
+          if (!p->first || !p->count) { p->err = 1; return NULL; }
+        }
+        uint32_t g = p->n_groups++;
+        p->first[g] = (uint32_t)row;
+        p->count[g] = 1;
+        p->slots[s] = g + 1;
+        sh->row_lgid[row] = g;
+        if ((uint64_t)p->n_groups * 2 > p->cap && part_grow_table(p)) { p->err = 1; return NULL; }
+        break;
+      }
+      if (tuple_eq(sh, p->first[v - 1], row)) { /* RawEntryMut::Occupied */
+        p->count[v - 1]++;
+        sh->row_lgid[row] = v - 1;
+        break;
+      }
+      s = (s + 1) & (p->cap - 1);
+    }
+  }
+  return NULL;
+}
+
+typedef struct { uint32_t first; uint32_t part; uint32_t lgid; } gt_item_t;
+static int item_cmp(const void *a, const void *b) {
+  uint32_t x = ((const gt_item_t *)a)->first, y = ((const gt_item_t *)b)->first;
+  return (x > y) - (x < y);
+}
+
+/* _set_partition_size (crates/polars-core/src/utils/mod.rs:32-46): largest power of two <= threads */
+static uint64_t set_partition_size(int n_threads) {
+  uint64_t p = 1;
+  while (p * 2 <= (uint64_t)(n_threads < 1 ? 1 : n_threads)) p *= 2;
+  return p;
+}
+
+void orc_groups_free(orc_groups_t *g) {
+  if (!g) return;
+  free(g->first); free(g->offsets); free(g->indices);
+  memset(g, 0, sizeof(*g));
+}
+
+int orc_group_tuples(const plhip_column_t *keys, int n_keys, int sorted, int n_threads, orc_groups_t *out) {
+  if (!out) return PLHIP_ERR_INVALID;
+  memset(out, 0, sizeof(*out));
+  /* group_by/mod.rs:59-62 */
+  if (n_keys < 1 || !keys) return PLHIP_ERR_COMPUTE;
+  if (n_keys > 64) return PLHIP_ERR_INVALID;
+  int64_t n = keys[0].length;
+  for (int k = 0; k < n_keys; k++) {
+    if (keys[k].length != n) return PLHIP_ERR_SHAPE_MISMATCH; /* group_by/mod.rs:67-71 */
+    if (!col_width(keys[k].dtype)) return PLHIP_ERR_UNSUPPORTED_DTYPE;
+  }
+  if (n > 0xFFFFFFFFLL) return PLHIP_ERR_COMPUTE; /* IdxSize = u32 (polars-utils/src/lib.rs:19-22) */
+
+  gt_shared_t sh;
+  memset(&sh, 0, sizeof(sh));
+  sh.n_keys = n_keys;
+  sh.n = n;
+  int rc = PLHIP_OK;
+  int any_nullable = 0;
+  for (int k = 0; k < n_keys; k++) any_nullable |= keys[k].validity != NULL;
+  sh.kb = (uint64_t **)calloc((size_t)n_keys, sizeof(uint64_t *));
+  sh.part_x = (uint64_t *)malloc((size_t)(n ? n : 1) * sizeof(uint64_t));
+  sh.row_lgid = (uint32_t *)malloc((size_t)(n ? n : 1) * sizeof(uint32_t));
+  if (any_nullable) sh.nullmask = (uint64_t *)calloc((size_t)(n ? n : 1), sizeof(uint64_t));
+  gt_part_t *parts = NULL;
+  pthread_t *tids = NULL;
+  gt_item_t *items = NULL;
+  uint32_t **remap = NULL;
+  uint32_t *cursor = NULL;
+  if (!sh.kb || !sh.part_x || !sh.row_lgid || (any_nullable && !sh.nullmask)) { rc = PLHIP_ERR_OOM; goto done; }
+  for (int k = 0; k < n_keys; k++) {
+    sh.kb[k] = (uint64_t *)malloc((size_t)(n ? n : 1) * sizeof(uint64_t));
+    if (!sh.kb[k]) { rc = PLHIP_ERR_OOM; goto done; }
+    for (int64_t i = 0; i < n; i++) {
+      if (col_valid(&keys[k], i)) sh.kb[k][i] = col_key_bits(&keys[k], i);
+      else { sh.kb[k][i] = 0; sh.nullmask[i] |= 1ULL << k; }
+    }
+  }
+  /* into_groups.rs:26-51: multithreaded only when len > 1000 (group_multithreaded :21-24) */
+  sh.n_partitions = (n_threads > 1 && n > 1000) ? set_partition_size(n_threads) : 1;
+  if (n_keys == 1) {
+    /* hashing.rs:215 / :279: this_partition(k.as_u64()); None -> u64::MAX >> 2 (partition.rs:67-76) */
+    for (int64_t i = 0; i < n; i++)
+      sh.part_x[i] = (sh.nullmask && sh.nullmask[i]) ? (UINT64_MAX >> 2) : sh.kb[0][i];
+  } else {
+    /* hashing.rs:385-386,430: partition on the combined row hash */
+    rc = orc_vec_hash(keys, n_keys, 0x5bd1e9955bd1e995ULL, sh.part_x);
+    if (rc) goto done;
+  }
+
+  uint64_t P = sh.n_partitions;
+  parts = (gt_part_t *)calloc(P, sizeof(gt_part_t));
+  tids = (pthread_t *)calloc(P, sizeof(pthread_t));
+  if (!parts || !tids) { rc = PLHIP_ERR_OOM; goto done; }
+  for (uint64_t t = 0; t < P; t++) { parts[t].sh = &sh; parts[t].thread_no = t; }
+  if (P == 1) part_scan(&parts[0]);
+  else {
+    for (uint64_t t = 0; t < P; t++) pthread_create(&tids[t], NULL, part_scan, &parts[t]);
+    for (uint64_t t = 0; t < P; t++) pthread_join(tids[t], NULL);
+  }
+  uint64_t G = 0;
+  for (uint64_t t = 0; t < P; t++) { if (parts[t].err) { rc = PLHIP_ERR_OOM; goto done; } G += parts[t].n_groups; }
+
+  /* finish_group_order / finish_group_order_vecs (hashing.rs:32-141): flatten partitions; if sorted,
+   * sort groups by first. */
+  items = (gt_item_t *)malloc((size_t)(G ? G : 1) * sizeof(gt_item_t));
+  remap = (uint32_t **)calloc(P, sizeof(uint32_t *));
+  if (!items || !remap) { rc = PLHIP_ERR_OOM; goto done; }
+  {
+    uint64_t o = 0;
+    for (uint64_t t = 0; t < P; t++) {
+      remap[t] = (uint32_t *)malloc((size_t)(parts[t].n_groups ? parts[t].n_groups : 1) * sizeof(uint32_t));
+      if (!remap[t]) { rc = PLHIP_ERR_OOM; goto done; }
+      for (uint32_t g = 0; g < parts[t].n_groups; g++) {
+        items[o].first = parts[t].first[g]; items[o].part = (uint32_t)t; items[o].lgid = g; o++;
+      }
+    }
+  }
+  if (sorted) qsort(items, G, sizeof(gt_item_t), item_cmp);
+  out->n_groups = (uint32_t)G;
+  out->n_rows = (uint32_t)n;
+  out->first = (uint32_t *)malloc((size_t)(G ? G : 1) * sizeof(uint32_t));
+  out->offsets = (uint32_t *)malloc((size_t)(G + 1) * sizeof(uint32_t));
+  out->indices = (uint32_t *)malloc((size_t)(n ? n : 1) * sizeof(uint32_t));
+  cursor = (uint32_t *)malloc((size_t)(G ? G : 1) * sizeof(uint32_t));
+  if (!out->first || !out->offsets || !out->indices || !cursor) { rc = PLHIP_ERR_OOM; goto done; }
+  {
+    uint32_t off = 0;
+    for (uint64_t g = 0; g < G; g++) {
+      out->first[g] = items[g].first;
+      out->offsets[g] = off;
+      cursor[g] = off;
+      off += parts[items[g].part].count[items[g].lgid];
+      remap[items[g].part][items[g].lgid] = (uint32_t)g;
+    }
+    out->offsets[G] = off;
+  }
+  /* rows are walked in ascending order, so every group's list is ascending (hashing.rs:211-229) */
+  for (int64_t row = 0; row < n; row++) {
+    uint64_t t = sh.part_x[row] & (P - 1);
+    uint32_t g = remap[t][sh.row_lgid[row]];
+    out->indices[cursor[g]++] = (uint32_t)row;
+  }
+
+done:
+  if (parts) for (uint64_t t = 0; t < sh.n_partitions; t++) { free(parts[t].slots); free(parts[t].first); free(parts[t].count); }
+  if (remap) for (uint64_t t = 0; t < sh.n_partitions; t++) free(remap[t]);
+  free(remap); free(items); free(cursor); free(parts); free(tids);
+  if (sh.kb) for (int k = 0; k < n_keys; k++) free(sh.kb[k]);
+  free(sh.kb); free(sh.part_x); free(sh.row_lgid); free(sh.nullmask);
+  if (rc) orc_groups_free(out);
+  return rc;
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* aggregation                                                                                    */
+/* ---------------------------------------------------------------------------------------------- */
+
+int orc_agg_out_dtype(int dtype, int kind) {
+  switch (kind) {
+    case PLHIP_AGG_COUNT: return PLHIP_U32; /* IdxSize, proxy.rs:452-466 */
+    case PLHIP_AGG_SUM:
+      /* series/implementations/mod.rs:167-174: i8/u8/i16/u16 are cast to Int64 before agg_sum */
+      if (dtype == PLHIP_I8 || dtype == PLHIP_I16 || dtype == PLHIP_U8 || dtype == PLHIP_U16) return PLHIP_I64;
+      return dtype;
+    case PLHIP_AGG_MEAN: return dtype == PLHIP_F32 ? PLHIP_F32 : PLHIP_F64; /* aggregations/mod.rs:741, dispatch.rs:160-179 */
+    case PLHIP_AGG_MIN: case PLHIP_AGG_MAX: return dtype;
+    default: return -1;
+  }
+}
+
+/* compare_fn_nan_max / compare_fn_nan_min (polars-arrow/src/kernels/rolling/mod.rs:29-69) through
+ * TakeExtremum (aggregations/mod.rs:240-259). */
+#define DEF_FLOAT_EXTREMUM(T, SFX)                                                   \
+  static inline T take_min_##SFX(T acc, T v) {                                       \
+    int an = isnan(acc), vn = isnan(v);                                              \
+    int less = (!an && !vn) ? (acc < v) : (!an && vn); /* NaN compares as largest */ \
+    return less ? acc : v;                                                           \
+  }                                                                                  \
+  static inline T take_max_##SFX(T acc, T v) {                                       \
+    int an = isnan(acc), vn = isnan(v);                                              \
+    int greater = (!an && !vn) ? (acc > v) : (!an && vn); /* NaN as smallest */      \
+    return greater ? acc : v;                                                        \
+  }
+DEF_FLOAT_EXTREMUM(float, f32)
+DEF_FLOAT_EXTREMUM(double, f64)
+
+/* Integer TakeExtremum (aggregations/mod.rs:217-238) and wrapping add in the column's own type. */
+#define DEF_INT_OPS(T, UT, SFX)                                                    \
+  static inline T take_min_##SFX(T a, T b) { return a < b ? a : b; }               \
+  static inline T take_max_##SFX(T a, T b) { return a > b ? a : b; }               \
+  static inline T wadd_##SFX(T a, T b) { return (T)((UT)a + (UT)b); }
+DEF_INT_OPS(int8_t, uint8_t, i8)
+DEF_INT_OPS(int16_t, uint16_t, i16)
+DEF_INT_OPS(int32_t, uint32_t, i32)
+DEF_INT_OPS(int64_t, uint64_t, i64)
+DEF_INT_OPS(uint8_t, uint8_t, u8)
+DEF_INT_OPS(uint16_t, uint16_t, u16)
+DEF_INT_OPS(uint32_t, uint32_t, u32)
+DEF_INT_OPS(uint64_t, uint64_t, u64)
+static inline float wadd_f32(float a, float b) { return a + b; }
+static inline double wadd_f64(double a, double b) { return a + b; }
+
+/*
+ * One group, one column, one kind.  T = column type, S = sum type (T, or int64 for the small ints),
+ * MINV/MAXV = T::min_value()/max_value().  Structure follows aggregations/mod.rs:
+ *   agg_sum  :622-651   agg_min :459-497   agg_max :539-580
+ *   float agg_mean :701-742   int agg_mean :941-991
+ * with the take kernels of polars-arrow/src/kernels/take_agg/mod.rs:17-109.
+ */
+#define DEF_AGG_GROUP(T, S, SFX, SSFX, MINV, MAXV, IS_FLOAT)                                               \
+  static void agg_group_##SFX(const plhip_column_t *c, int kind, const uint32_t *idx, uint32_t len,        \
+                              uint32_t first, void *outv, uint8_t *valid, uint64_t g) {                    \
+    const T *v = (const T *)c->values + c->offset;                                                         \
+    const int no_nulls = c->validity == NULL;                                                              \
+    switch (kind) {                                                                                        \
+      case PLHIP_AGG_SUM: {                                                                                \
+        S acc = 0;                                                                                         \
+        if (len == 0) acc = 0;                                                                             \
+        else if (len == 1) acc = col_valid(c, first) ? (S)v[first] : 0;                                    \
+        else if (no_nulls) for (uint32_t i = 0; i < len; i++) acc = wadd_##SSFX(acc, (S)v[idx[i]]);        \
+        else for (uint32_t i = 0; i < len; i++) if (col_valid(c, idx[i])) acc = wadd_##SSFX(acc, (S)v[idx[i]]); \
+        ((S *)outv)[g] = acc; valid[g] = 1; /* never null: unwrap_or(zero) */                              \
+        break;                                                                                             \
+      }                                                                                                    \
+      case PLHIP_AGG_MIN: case PLHIP_AGG_MAX: {                                                            \
+        const int is_min = kind == PLHIP_AGG_MIN;                                                          \
+        T acc = is_min ? (T)(MAXV) : (T)(MINV);                                                            \
+        uint32_t nulls = 0;                                                                                \
+        if (len == 0) { valid[g] = 0; ((T *)outv)[g] = 0; break; }                                         \
+        if (len == 1) { /* arr.get(first) */                                                               \
+          valid[g] = (uint8_t)col_valid(c, first); ((T *)outv)[g] = valid[g] ? v[first] : 0; break;        \
+        }                                                                                                  \
+        for (uint32_t i = 0; i < len; i++) {                                                               \
+          if (!no_nulls && !col_valid(c, idx[i])) { nulls++; continue; }                                   \
+          acc = is_min ? take_min_##SFX(acc, v[idx[i]]) : take_max_##SFX(acc, v[idx[i]]);                  \
+        }                                                                                                  \
+        valid[g] = nulls != len; ((T *)outv)[g] = valid[g] ? acc : 0;                                      \
+        break;                                                                                             \
+      }                                                                                                    \
+      case PLHIP_AGG_MEAN: {                                                                               \
+        if (len == 0) { valid[g] = 0; break; }                                                             \
+        if (IS_FLOAT) {                                                                                    \
+          /* float: fold in T, then to_f64, divide, cast back to T */                                      \
+          T *o = (T *)outv;                                                                                \
+          if (len == 1) { valid[g] = (uint8_t)col_valid(c, first); o[g] = valid[g] ? (T)(double)v[first] : 0; break; } \
+          T acc = 0; uint32_t nulls = 0;                                                                   \
+          for (uint32_t i = 0; i < len; i++) {                                                             \
+            if (!no_nulls && !col_valid(c, idx[i])) { nulls++; continue; }                                 \
+            acc = acc + v[idx[i]];                                                                         \
+          }                                                                                                \
+          valid[g] = nulls != len;                                                                         \
+          o[g] = valid[g] ? (T)((double)acc / ((double)len - (double)nulls)) : 0;                          \
+        } else {                                                                                           \
+          /* int: every element cast to f64, summed in f64 from 0.0 */                                     \
+          double *o = (double *)outv;                                                                      \
+          if (len == 1) { valid[g] = (uint8_t)col_valid(c, first); o[g] = valid[g] ? (double)v[first] : 0; break; } \
+          double acc = 0.0; uint32_t nulls = 0;                                                            \
+          for (uint32_t i = 0; i < len; i++) {                                                             \
+            if (!no_nulls && !col_valid(c, idx[i])) { nulls++; continue; }                                 \
+            acc = acc + (double)v[idx[i]];                                                                 \
+          }                                                                                                \
+          valid[g] = nulls != len;                                                                         \
+          o[g] = valid[g] ? acc / ((double)len - (double)nulls) : 0;                                       \
+        }                                                                                                  \
+        break;                                                                                             \
+      }                                                                                                    \
+      default: break;                                                                                      \
+    }                                                                                                      \
+  }
+
+DEF_AGG_GROUP(int8_t, int64_t, i8, i64, INT8_MIN, INT8_MAX, 0)
+DEF_AGG_GROUP(int16_t, int64_t, i16, i64, INT16_MIN, INT16_MAX, 0)
+DEF_AGG_GROUP(int32_t, int32_t, i32, i32, INT32_MIN, INT32_MAX, 0)
+DEF_AGG_GROUP(int64_t, int64_t, i64, i64, INT64_MIN, INT64_MAX, 0)
+DEF_AGG_GROUP(uint8_t, int64_t, u8, i64, 0, UINT8_MAX, 0)
+DEF_AGG_GROUP(uint16_t, int64_t, u16, i64, 0, UINT16_MAX, 0)
+DEF_AGG_GROUP(uint32_t, uint32_t, u32, u32, 0, UINT32_MAX, 0)
+DEF_AGG_GROUP(uint64_t, uint64_t, u64, u64, 0, UINT64_MAX, 0)
+DEF_AGG_GROUP(float, float, f32, f32, -FLT_MAX, FLT_MAX, 1)   /* T::min_value() = f32::MIN = -MAX */
+DEF_AGG_GROUP(double, double, f64, f64, -DBL_MAX, DBL_MAX, 1)
+
+typedef void (*agg_group_fn)(const plhip_column_t *, int, const uint32_t *, uint32_t, uint32_t, void *, uint8_t *, uint64_t);
+static agg_group_fn agg_fn_for(int dtype) {
+  switch (dtype) {
+    case PLHIP_I8: return agg_group_i8; case PLHIP_I16: return agg_group_i16;
+    case PLHIP_I32: return agg_group_i32; case PLHIP_I64: return agg_group_i64;
+    case PLHIP_U8: return agg_group_u8; case PLHIP_U16: return agg_group_u16;
+    case PLHIP_U32: return agg_group_u32; case PLHIP_U64: return agg_group_u64;
+    case PLHIP_F32: return agg_group_f32; case PLHIP_F64: return agg_group_f64;
+    default: return NULL;
+  }
+}
+
+typedef struct {
+  const plhip_column_t *c; int kind; const orc_groups_t *g; void *outv; uint8_t *valid;
+  uint64_t g0, g1; agg_group_fn fn;
+} agg_job_t;
+
+static void *agg_job(void *arg) {
+  agg_job_t *j = (agg_job_t *)arg;
+  for (uint64_t g = j->g0; g < j->g1; g++) {
+    uint32_t off = j->g->offsets[g], len = j->g->offsets[g + 1] - off;
+    if (j->kind == PLHIP_AGG_COUNT) { ((uint32_t *)j->outv)[g] = len; j->valid[g] = 1; continue; }
+    j->fn(j->c, j->kind, j->g->indices + off, len, j->g->first[g], j->outv, j->valid, g);
+  }
+  return NULL;
+}
+
+/* _agg_helper_idx (aggregations/mod.rs:158-177): rayon par_iter over groups -> here a static split of
+ * the group range over n_threads pthreads. */
+int orc_agg(const plhip_column_t *values, int kind, const orc_groups_t *g, void *out_values,
+            uint8_t *out_valid, int n_threads) {
+  if (!g || !out_values || !out_valid) return PLHIP_ERR_INVALID;
+  agg_group_fn fn = NULL;
+  if (kind != PLHIP_AGG_COUNT) {
+    if (!values) return PLHIP_ERR_INVALID;
+    if (values->length != g->n_rows) return PLHIP_ERR_SHAPE_MISMATCH;
+    fn = agg_fn_for(values->dtype);
+    if (!fn) return PLHIP_ERR_UNSUPPORTED_DTYPE;
+  }
+  if (kind < 0 || kind > PLHIP_AGG_COUNT) return PLHIP_ERR_INVALID;
+  int T = n_threads < 1 ? 1 : n_threads;
+  if ((uint64_t)T > g->n_groups) T = g->n_groups ? (int)g->n_groups : 1;
+  agg_job_t *jobs = (agg_job_t *)calloc((size_t)T, sizeof(agg_job_t));
+  pthread_t *tids = (pthread_t *)calloc((size_t)T, sizeof(pthread_t));
+  if (!jobs || !tids) { free(jobs); free(tids); return PLHIP_ERR_OOM; }
+  uint64_t G = g->n_groups;
+  for (int t = 0; t < T; t++) {
+    jobs[t] = (agg_job_t){values, kind, g, out_values, out_valid, G * t / T, G * (t + 1) / T, fn};
+    if (T > 1) pthread_create(&tids[t], NULL, agg_job, &jobs[t]);
+  }
+  if (T == 1) agg_job(&jobs[0]);
+  else for (int t = 0; t < T; t++) pthread_join(tids[t], NULL);
+  free(jobs); free(tids);
+  return PLHIP_OK;
+}
+
+/* ---- partitioned order ------------------------------------------------------------------------ */
+
+/* Reads element g of a partial column as double / u64 bits for the final fold. */
+static int out_width(int dtype) { return col_width(dtype); }
+
+int orc_agg_partitioned(const plhip_column_t *values, int kind, const orc_groups_t *g, int n_parts,
+                        void *out_values, uint8_t *out_valid) {
+  if (!g || !out_values || !out_valid || n_parts < 1) return PLHIP_ERR_INVALID;
+  if (kind == PLHIP_AGG_COUNT) return orc_agg(values, kind, g, out_values, out_valid, 1); /* u32 partial sums: exact */
+  if (!values) return PLHIP_ERR_INVALID;
+  agg_group_fn fn = agg_fn_for(values->dtype);
+  if (!fn) return PLHIP_ERR_UNSUPPORTED_DTYPE;
+  const uint32_t n = g->n_rows;
+  /* split_df -> _split_offsets (crates/polars-core/src/utils/mod.rs:122-140): n_parts contiguous
+   * chunks of len/n_parts rows, the last one takes the remainder. */
+  uint32_t chunk = n / (uint32_t)n_parts;
+  const int odt = orc_agg_out_dtype(values->dtype, kind);
+  const int ow = out_width(odt);
+  uint32_t *buf = (uint32_t *)malloc(((size_t)n + 1) * sizeof(uint32_t));
+  if (!buf) return PLHIP_ERR_OOM;
+  for (uint64_t gi = 0; gi < g->n_groups; gi++) {
+    const uint32_t off = g->offsets[gi], len = g->offsets[gi + 1] - off;
+    const uint32_t *idx = g->indices + off;
+    /* running state of the FINAL fold over partials (finalize, aggregation.rs:367-398,471-480) */
+    double fsum = 0.0; float fsum32 = 0.f; uint64_t isum = 0; uint64_t cnt = 0;
+    int any_valid = 0; int n_partials = 0;
+    union { int64_t i; uint64_t u; double d; float f; uint8_t b[8]; } ext, one; /* min/max running value */
+    memset(&ext, 0, sizeof(ext));
+    uint32_t i = 0;
+    for (int p = 0; p < n_parts && i < len; p++) {
+      uint32_t hi = (p == n_parts - 1) ? n : (uint32_t)(p + 1) * chunk;
+      uint32_t m = 0;
+      while (i < len && idx[i] < hi) buf[m++] = idx[i++];
+      if (!m) continue; /* the key does not occur in this part: no partial row */
+      n_partials++;
+      uint8_t v1 = 0; memset(&one, 0, sizeof(one));
+      if (kind == PLHIP_AGG_SUM) {
+        fn(values, PLHIP_AGG_SUM, buf, m, buf[0], &one, &v1, 0);
+        /* final agg_sum of the partial sums, in the partial column's dtype */
+        if (odt == PLHIP_F64) fsum = n_partials == 1 ? (m ? one.d : 0) : fsum + one.d;
+        else if (odt == PLHIP_F32) fsum32 = n_partials == 1 ? one.f : fsum32 + one.f;
+        else if (ow == 4) isum = (uint32_t)((uint32_t)isum + (uint32_t)one.u);
+        else isum += one.u;
+      } else if (kind == PLHIP_AGG_MEAN) {
+        /* partial = struct{ sum (i32/u32 cast to i64 first; then cast to f64 unless f32), valid count }
+         * (aggregation.rs:297-322) */
+        uint32_t vc = 0;
+        for (uint32_t k = 0; k < m; k++) vc += (uint32_t)col_valid(values, buf[k]);
+        cnt += vc;
+        if (values->dtype == PLHIP_F32) {
+          fn(values, PLHIP_AGG_SUM, buf, m, buf[0], &one, &v1, 0);
+          fsum32 = n_partials == 1 ? one.f : fsum32 + one.f;
+        } else if (values->dtype == PLHIP_F64) {
+          fn(values, PLHIP_AGG_SUM, buf, m, buf[0], &one, &v1, 0);
+          fsum = n_partials == 1 ? one.d : fsum + one.d;
+        } else {
+          /* integer: exact i64 partial (small ints via agg_sum -> i64, i32/u32 via cast i64), then f64 */
+          int64_t s = 0;
+          for (uint32_t k = 0; k < m; k++) {
+            if (!col_valid(values, buf[k])) continue;
+            int64_t j = values->offset + buf[k];
+            switch (values->dtype) {
+              case PLHIP_I8: s += ((const int8_t *)values->values)[j]; break;
+              case PLHIP_I16: s += ((const int16_t *)values->values)[j]; break;
+              case PLHIP_I32: s += ((const int32_t *)values->values)[j]; break;
+              case PLHIP_U8: s += ((const uint8_t *)values->values)[j]; break;
+              case PLHIP_U16: s += ((const uint16_t *)values->values)[j]; break;
+              case PLHIP_U32: s += ((const uint32_t *)values->values)[j]; break;
+              case PLHIP_I64: s = (int64_t)((uint64_t)s + ((const uint64_t *)values->values)[j]); break;
+              default: s = (int64_t)((uint64_t)s + ((const uint64_t *)values->values)[j]); break;
+            }
+          }
+          double ps = values->dtype == PLHIP_U64 ? (double)(uint64_t)s : (double)s;
+          fsum = n_partials == 1 ? ps : fsum + ps;
+        }
+      } else { /* MIN / MAX: partial extremum per part, then extremum of the valid partials */
+        fn(values, kind, buf, m, buf[0], &one, &v1, 0);
+        if (v1) {
+          if (!any_valid) { ext = one; any_valid = 1; }
+          else {
+            uint32_t two[2] = {0, 1};
+            /* fold the two partials with the same TakeExtremum through a 2-element column */
+            uint8_t tmp[16]; memcpy(tmp, &ext, (size_t)ow); memcpy(tmp + ow, &one, (size_t)ow);
+            plhip_column_t pc = {tmp, NULL, 0, 2, values->dtype, 0};
+            uint8_t v2 = 0; memset(&one, 0, sizeof(one));
+            fn(&pc, kind, two, 2, 0, &one, &v2, 0);
+            ext = one;
+          }
+        }
+      }
+    }
+    switch (kind) {
+      case PLHIP_AGG_SUM:
+        out_valid[gi] = 1;
+        if (odt == PLHIP_F64) ((double *)out_values)[gi] = fsum;
+        else if (odt == PLHIP_F32) ((float *)out_values)[gi] = fsum32;
+        else if (ow == 4) ((uint32_t *)out_values)[gi] = (uint32_t)isum;
+        else ((uint64_t *)out_values)[gi] = isum;
+        break;
+      case PLHIP_AGG_MEAN:
+        /* `&agg_s / &agg_count` (aggregation.rs:389): plain division, 0/0 -> NaN (not null!) */
+        out_valid[gi] = len != 0;
+        if (values->dtype == PLHIP_F32) ((float *)out_values)[gi] = len ? fsum32 / (float)cnt : 0;
+        else ((double *)out_values)[gi] = len ? fsum / (double)cnt : 0;
+        break;
+      default:
+        out_valid[gi] = (uint8_t)any_valid;
+        memset((uint8_t *)out_values + (size_t)gi * ow, 0, (size_t)ow);
+        if (any_valid) memcpy((uint8_t *)out_values + (size_t)gi * ow, &ext, (size_t)ow);
+        break;
+    }
+  }
+  free(buf);
+  return PLHIP_OK;
+}
+
+/* GroupBy::keys_sliced (group_by/mod.rs:262-296): key_col.take(first[]) */
+int orc_take_keys(const plhip_column_t *key, const orc_groups_t *g, void *out_values, uint8_t *out_valid) {
+  if (!key || !g || !out_values || !out_valid) return PLHIP_ERR_INVALID;
+  int w = col_width(key->dtype);
+  if (!w) return PLHIP_ERR_UNSUPPORTED_DTYPE;
+  for (uint64_t i = 0; i < g->n_groups; i++) {
+    uint32_t r = g->first[i];
+    out_valid[i] = (uint8_t)col_valid(key, r);
+    if (out_valid[i]) memcpy((uint8_t *)out_values + i * w, (const uint8_t *)key->values + (key->offset + r) * w, (size_t)w);
+    else memset((uint8_t *)out_values + i * w, 0, (size_t)w);
+  }
+  return PLHIP_OK;
+}

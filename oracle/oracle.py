@@ -1,0 +1,141 @@
+"""ctypes wrapper of the CPU oracle (oracle/groupby_oracle.c).
+
+TEST INFRASTRUCTURE ONLY — imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+The product (polars_amd/) never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+from polars_amd import _ffi
+from polars_amd.column import Column
+
+HERE = Path(__file__).resolve().parent
+LIB = HERE / "_build" / "libgroupby_oracle.so"
+
+
+class _Groups(C.Structure):
+    _fields_ = [("n_groups", C.c_uint32), ("n_rows", C.c_uint32), ("first", C.POINTER(C.c_uint32)),
+                ("offsets", C.POINTER(C.c_uint32)), ("indices", C.POINTER(C.c_uint32))]
+
+
+_lib = None
+
+
+def build() -> Path:
+    subprocess.run(["make", "-C", str(HERE)], check=True, capture_output=True)
+    return LIB
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not LIB.exists():
+            build()
+        L = C.CDLL(str(LIB))
+        P = C.POINTER
+        L.orc_folded_multiply.argtypes = [C.c_uint64, C.c_uint64]
+        L.orc_folded_multiply.restype = C.c_uint64
+        L.orc_vec_hash.argtypes = [P(_ffi.ColumnStruct), C.c_int, C.c_uint64, C.c_void_p]
+        L.orc_group_tuples.argtypes = [P(_ffi.ColumnStruct), C.c_int, C.c_int, C.c_int, P(_Groups)]
+        L.orc_groups_free.argtypes = [P(_Groups)]
+        L.orc_groups_free.restype = None
+        L.orc_agg_out_dtype.argtypes = [C.c_int, C.c_int]
+        L.orc_agg.argtypes = [P(_ffi.ColumnStruct), C.c_int, P(_Groups), C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_agg_partitioned.argtypes = [P(_ffi.ColumnStruct), C.c_int, P(_Groups), C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_take_keys.argtypes = [P(_ffi.ColumnStruct), P(_Groups), C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _structs(cols):
+    arr = (_ffi.ColumnStruct * max(1, len(cols)))()
+    for i, c in enumerate(cols):
+        if c.location != _ffi.HOST:
+            raise ValueError("the oracle reads host columns only")
+        arr[i] = c.struct()
+    return arr
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise _ffi._ERR_CLASS.get(rc, _ffi.PlHipError)(rc, "oracle")
+
+
+def folded_multiply(s: int, by: int) -> int:
+    return lib().orc_folded_multiply(s, by)
+
+
+def vec_hash(keys: list[Column], null_h: int) -> np.ndarray:
+    out = np.empty(len(keys[0]), dtype=np.uint64)
+    _check(lib().orc_vec_hash(_structs(keys), len(keys), null_h, out.ctypes.data))
+    return out
+
+
+class Groups:
+    """GroupsProxy::Idx as CSR numpy arrays (copies; the C buffers are freed)."""
+
+    def __init__(self, keys: list[Column], sorted_: bool = False, n_threads: int = 1):
+        g = _Groups()
+        _check(lib().orc_group_tuples(_structs(keys), len(keys), int(sorted_), n_threads, C.byref(g)))
+        G, n = g.n_groups, g.n_rows
+        self.first = np.ctypeslib.as_array(g.first, shape=(max(G, 1),))[:G].copy()
+        self.offsets = np.ctypeslib.as_array(g.offsets, shape=(G + 1,)).copy()
+        self.indices = np.ctypeslib.as_array(g.indices, shape=(max(n, 1),))[:n].copy()
+        lib().orc_groups_free(C.byref(g))
+        self.n_groups, self.n_rows = G, n
+
+    def _c(self) -> _Groups:
+        g = _Groups()
+        g.n_groups, g.n_rows = self.n_groups, self.n_rows
+        g.first = self.first.ctypes.data_as(C.POINTER(C.c_uint32))
+        g.offsets = self.offsets.ctypes.data_as(C.POINTER(C.c_uint32))
+        g.indices = self.indices.ctypes.data_as(C.POINTER(C.c_uint32))
+        return g
+
+    def lists(self) -> list[list[int]]:
+        return [self.indices[self.offsets[i]:self.offsets[i + 1]].tolist() for i in range(self.n_groups)]
+
+
+def agg(values: Column | None, kind: str | int, groups: Groups, n_threads: int = 1, partitioned: int = 0):
+    """Returns (values ndarray, valid bool ndarray) for one aggregation over `groups`."""
+    k = _ffi.AGG_NAMES[kind] if isinstance(kind, str) else kind
+    src_dt = _ffi.U32 if values is None else values.dtype
+    out_dt = _ffi.code_np_dtype(lib().orc_agg_out_dtype(src_dt, k))
+    out = np.zeros(groups.n_groups, dtype=out_dt)
+    valid = np.zeros(groups.n_groups, dtype=np.uint8)
+    g = groups._c()
+    vs = _structs([values]) if values is not None else None
+    if partitioned:
+        _check(lib().orc_agg_partitioned(vs, k, C.byref(g), partitioned, out.ctypes.data, valid.ctypes.data))
+    else:
+        _check(lib().orc_agg(vs, k, C.byref(g), out.ctypes.data, valid.ctypes.data, n_threads))
+    return out, valid.astype(bool)
+
+
+def take_keys(key: Column, groups: Groups):
+    out = np.zeros(groups.n_groups, dtype=_ffi.code_np_dtype(key.dtype))
+    valid = np.zeros(groups.n_groups, dtype=np.uint8)
+    g = groups._c()
+    _check(lib().orc_take_keys(_structs([key]), C.byref(g), out.ctypes.data, valid.ctypes.data))
+    return out, valid.astype(bool)
+
+
+def group_by_agg(keys: list[Column], values: list[Column], aggs: list[tuple[int, str]], *,
+                 maintain_order: bool = False, n_threads: int = 1, partitioned: int = 0):
+    """group_by_helper (crates/polars-lazy/src/physical_plan/executors/group_by.rs:57-95) on the oracle:
+    returns a list of (name, values, valid) = key columns then one column per agg, in group order."""
+    groups = Groups(keys, maintain_order, n_threads)
+    out = []
+    for kc in keys:
+        v, m = take_keys(kc, groups)
+        out.append((kc.name, v, m))
+    for ci, kind in aggs:
+        col = None if kind == "count" else values[ci]
+        v, m = agg(col, kind, groups, n_threads, partitioned)
+        out.append((f"{values[ci].name if col is not None else 'count'}_{kind}", v, m))
+    return out, groups

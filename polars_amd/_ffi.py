@@ -1,0 +1,162 @@
+"""ctypes binding of libplhip.so (include/plhip.h).
+
+The library is the product: there is no Python or CPU fallback.  If the shared object is missing or
+no MI355X is visible, calls fail loudly (PlHipError / OSError).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+# plhip_dtype_t
+I8, I16, I32, I64, U8, U16, U32, U64, F32, F64 = range(10)
+_NP_TO_CODE = {
+    np.dtype(np.int8): I8, np.dtype(np.int16): I16, np.dtype(np.int32): I32, np.dtype(np.int64): I64,
+    np.dtype(np.uint8): U8, np.dtype(np.uint16): U16, np.dtype(np.uint32): U32, np.dtype(np.uint64): U64,
+    np.dtype(np.float32): F32, np.dtype(np.float64): F64,
+}
+_CODE_TO_NP = {v: k for k, v in _NP_TO_CODE.items()}
+DTYPE_NAMES = {I8: "i8", I16: "i16", I32: "i32", I64: "i64", U8: "u8", U16: "u16", U32: "u32", U64: "u64",
+               F32: "f32", F64: "f64"}
+
+HOST, DEVICE = 0, 1
+
+# plhip_agg_kind_t
+AGG_SUM, AGG_MEAN, AGG_MIN, AGG_MAX, AGG_COUNT = range(5)
+AGG_NAMES = {"sum": AGG_SUM, "mean": AGG_MEAN, "min": AGG_MIN, "max": AGG_MAX, "count": AGG_COUNT}
+
+FLAG_MAINTAIN_ORDER = 1
+FLAG_OUTPUT_DEVICE = 2
+FLAG_PARTIAL = 4
+FLAG_SORT_KEYS = 8
+
+STRATEGIES = {"auto": 0, "global": 1, "lds": 2, "partitioned": 3}
+
+STATUS_NAMES = {
+    0: "OK", 1: "ComputeError", 2: "ShapeMismatch", 3: "OutOfMemory", 4: "UnsupportedDtype", 5: "HipError",
+    6: "InvalidArgument", 7: "NoDevice",
+}
+
+
+class PlHipError(RuntimeError):
+    """A non-OK plhip_status_t; `.status` holds the code, the message comes from plhip_last_error()."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(f"{STATUS_NAMES.get(status, status)}: {message}")
+        self.status = status
+
+
+class ComputeError(PlHipError):
+    pass
+
+
+class ShapeMismatch(PlHipError):
+    pass
+
+
+_ERR_CLASS = {1: ComputeError, 2: ShapeMismatch}
+
+
+class ColumnStruct(C.Structure):
+    """plhip_column_t"""
+
+    _fields_ = [
+        ("values", C.c_void_p),
+        ("validity", C.c_void_p),
+        ("offset", C.c_int64),
+        ("length", C.c_int64),
+        ("dtype", C.c_int32),
+        ("location", C.c_int32),
+    ]
+
+
+class AggStruct(C.Structure):
+    """plhip_agg_t"""
+
+    _fields_ = [("column", C.c_int32), ("kind", C.c_int32)]
+
+
+def np_dtype_code(dt) -> int:
+    dt = np.dtype(dt)
+    if dt not in _NP_TO_CODE:
+        raise PlHipError(4, f"dtype {dt} is not supported on the group-by path")
+    return _NP_TO_CODE[dt]
+
+
+def code_np_dtype(code: int):
+    return _CODE_TO_NP[code]
+
+
+LIB_PATH = Path(__file__).resolve().parent / "_lib" / "libplhip.so"
+_lib = None
+
+
+def lib():
+    """Loads libplhip.so once.  Raises OSError with a build hint when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = Path(os.environ.get("PLHIP_LIBRARY", LIB_PATH))
+    if not path.exists():
+        raise OSError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950); polars_amd has no CPU fallback"
+        )
+    L = C.CDLL(str(path))
+    vp, i32, i64, u32, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64
+    P = C.POINTER
+    L.plhip_abi_version.restype = i32
+    L.plhip_init.argtypes = [i32]
+    L.plhip_init.restype = i32
+    L.plhip_last_error.restype = C.c_char_p
+    L.plhip_set_strategy.argtypes = [i32]
+    L.plhip_set_strategy.restype = i32
+    L.plhip_last_strategy.restype = C.c_char_p
+    L.plhip_last_kernel_ms.argtypes = [P(C.c_float), P(C.c_float), P(C.c_char_p)]
+    L.plhip_last_kernel_ms.restype = i32
+    L.plhip_vec_hash.argtypes = [P(ColumnStruct), i32, u64, vp, i32]
+    L.plhip_vec_hash.restype = i32
+    L.plhip_group_by_agg.argtypes = [P(ColumnStruct), i32, P(ColumnStruct), i32, P(AggStruct), i32, u32, P(vp)]
+    L.plhip_group_by_agg.restype = i32
+    L.plhip_result_num_rows.argtypes = [vp]
+    L.plhip_result_num_rows.restype = i64
+    L.plhip_result_num_columns.argtypes = [vp]
+    L.plhip_result_num_columns.restype = i32
+    L.plhip_result_column.argtypes = [vp, i32, P(ColumnStruct)]
+    L.plhip_result_column.restype = i32
+    L.plhip_result_free.argtypes = [vp]
+    L.plhip_result_free.restype = None
+    L.plhip_group_tuples.argtypes = [P(ColumnStruct), i32, i32, i32, P(vp)]
+    L.plhip_group_tuples.restype = i32
+    L.plhip_groups_num_groups.argtypes = [vp]
+    L.plhip_groups_num_groups.restype = i64
+    L.plhip_groups_num_rows.argtypes = [vp]
+    L.plhip_groups_num_rows.restype = i64
+    L.plhip_groups_buffers.argtypes = [vp, P(vp), P(vp), P(vp), P(i32)]
+    L.plhip_groups_buffers.restype = i32
+    L.plhip_groups_free.argtypes = [vp]
+    L.plhip_groups_free.restype = None
+    L.plhip_agg_groups.argtypes = [P(ColumnStruct), i32, vp, u32, P(vp)]
+    L.plhip_agg_groups.restype = i32
+    if L.plhip_abi_version() != 1:
+        raise OSError("libplhip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(status: int) -> None:
+    if status != 0:
+        msg = lib().plhip_last_error().decode("utf-8", "replace")
+        raise _ERR_CLASS.get(status, PlHipError)(status, msg)
+
+
+EXPORTED_SYMBOLS = [
+    "plhip_abi_version", "plhip_init", "plhip_last_error", "plhip_set_strategy", "plhip_last_strategy",
+    "plhip_last_kernel_ms", "plhip_vec_hash", "plhip_group_by_agg", "plhip_result_num_rows",
+    "plhip_result_num_columns", "plhip_result_column", "plhip_result_free", "plhip_group_tuples",
+    "plhip_groups_num_groups", "plhip_groups_num_rows", "plhip_groups_buffers", "plhip_groups_free",
+    "plhip_agg_groups",
+]
