@@ -94,6 +94,24 @@ LIB_PATH = Path(__file__).resolve().parent / "_lib" / "libplhip.so"
 _lib = None
 
 
+def _preload_hip_runtime() -> None:
+    """One process must hold ONE HIP runtime.  PyTorch-ROCm wheels bundle their own libamdhip64.so (same
+    soname, libamdhip64.so.7, as /opt/rocm's): if libplhip.so pulled in the system copy first, a later
+    `import torch` would load a second runtime and find no GPU.  Loading torch's copy first (by path, without
+    importing torch) makes the dynamic linker hand that same instance to libplhip.so.  Without torch
+    installed, libplhip.so resolves the system ROCm runtime through its RUNPATH."""
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is not None and spec.origin:
+        cand = Path(spec.origin).parent / "lib" / "libamdhip64.so"
+        if cand.exists():
+            C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """Loads libplhip.so once.  Raises OSError with a build hint when it is missing."""
     global _lib
@@ -105,6 +123,7 @@ def lib():
             f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950); polars_amd has no CPU fallback"
         )
+    _preload_hip_runtime()
     L = C.CDLL(str(path))
     vp, i32, i64, u32, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64
     P = C.POINTER

@@ -1,0 +1,758 @@
+// api.hip — the C ABI of libplhip.so (include/plhip.h): argument checking, staging of host columns,
+// lowering of a query to a Plan, strategy choice, kernel launches, result frames.
+//
+// This is the host layer that replaces polars-lazy's GroupByExec / PartitionGroupByExec for the path
+// (crates/polars-lazy/src/physical_plan/executors/group_by.rs:57-148, group_by_partitioned.rs:161-361).
+// There is no CPU compute path in this file: without a HIP device every entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/plhip.h"
+#include "kernels.hpp"
+
+size_t lds_table_bytes(const Plan &p, uint32_t lcap); // kernels.hip
+
+// ---------------------------------------------------------------------------------------------------------
+// per-thread context
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+struct Scratch { // grow-only device buffer reused across calls (hipMalloc/hipFree are slow and synchronising)
+  void *p = nullptr;
+  size_t bytes = 0;
+  hipError_t reserve(size_t n) {
+    if (n <= bytes) return hipSuccess;
+    if (p) hipFree(p);
+    p = nullptr; bytes = 0;
+    size_t want = n + n / 4;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) { e = hipMalloc(&p, n); want = n; }
+    if (e == hipSuccess) bytes = want;
+    return e;
+  }
+};
+
+struct Ctx {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  std::string err;
+  std::string strategy = "";
+  float total_ms = 0.f, dom_ms = 0.f;
+  std::string dom_kernel = "";
+  int forced_strategy = -1; // -1: not set by the API (env / auto)
+  Scratch table, slots, sortkeys, flags, misc, rank, plans;
+  uint32_t *host_flags = nullptr; // pinned
+};
+
+thread_local Ctx g_ctx;
+
+int fail(int status, const std::string &msg) {
+  g_ctx.err = msg;
+  return status;
+}
+int fail_hip(hipError_t e, const char *what) {
+  return fail(e == hipErrorOutOfMemory ? PLHIP_ERR_OOM : PLHIP_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(expr)                                  \
+  do {                                                 \
+    hipError_t _e = (expr);                            \
+    if (_e != hipSuccess) return fail_hip(_e, #expr);  \
+  } while (0)
+
+int ensure_ctx() {
+  Ctx &c = g_ctx;
+  if (c.device >= 0) {
+    HIP_TRY(hipSetDevice(c.device));
+    return PLHIP_OK;
+  }
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(PLHIP_ERR_NO_DEVICE, "no HIP device visible; libplhip.so has no CPU path (gfx950 required)");
+  int dev = 0;
+  e = hipGetDevice(&dev);
+  if (e != hipSuccess) dev = 0;
+  HIP_TRY(hipSetDevice(dev));
+  HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+  for (auto &ev : c.ev) HIP_TRY(hipEventCreate(&ev));
+  HIP_TRY(hipHostMalloc((void **)&c.host_flags, 64, hipHostMallocDefault));
+  c.device = dev;
+  return PLHIP_OK;
+}
+
+int dtype_width(int dt) {
+  switch (dt) {
+    case PLHIP_I8: case PLHIP_U8: return 1;
+    case PLHIP_I16: case PLHIP_U16: return 2;
+    case PLHIP_I32: case PLHIP_U32: case PLHIP_F32: return 4;
+    case PLHIP_I64: case PLHIP_U64: case PLHIP_F64: return 8;
+    default: return 0;
+  }
+}
+bool dt_is_float(int dt) { return dt == PLHIP_F32 || dt == PLHIP_F64; }
+bool dt_is_signed(int dt) { return dt == PLHIP_I8 || dt == PLHIP_I16 || dt == PLHIP_I32 || dt == PLHIP_I64; }
+
+// A column as the kernels see it: pointers to element 0 of the logical slice, validity bit offset.
+struct DevCol {
+  const uint8_t *values = nullptr;
+  const uint8_t *validity = nullptr;
+  int64_t boff = 0;
+  int64_t length = 0;
+  int dtype = 0;
+};
+
+struct Staging { // owns device copies of host columns for the duration of one call
+  std::vector<void *> owned;
+  ~Staging() { for (void *p : owned) hipFree(p); }
+};
+
+int stage_column(const plhip_column_t &c, DevCol &d, Staging &st, hipStream_t s) {
+  const int w = dtype_width(c.dtype);
+  if (!w) return fail(PLHIP_ERR_UNSUPPORTED_DTYPE, "unsupported dtype code " + std::to_string(c.dtype));
+  if (c.length < 0 || c.offset < 0) return fail(PLHIP_ERR_INVALID, "negative column offset/length");
+  if (c.length > 0 && !c.values) return fail(PLHIP_ERR_INVALID, "column values pointer is NULL");
+  d.length = c.length;
+  d.dtype = c.dtype;
+  if (c.location == PLHIP_DEVICE) {
+    d.values = (const uint8_t *)c.values + c.offset * w;
+    d.validity = c.validity;
+    d.boff = c.offset;
+    return PLHIP_OK;
+  }
+  if (c.location != PLHIP_HOST) return fail(PLHIP_ERR_INVALID, "bad column location");
+  void *dv = nullptr;
+  const size_t vbytes = (size_t)c.length * w;
+  HIP_TRY(hipMalloc(&dv, vbytes ? vbytes : 8));
+  st.owned.push_back(dv);
+  if (vbytes) HIP_TRY(hipMemcpyAsync(dv, (const uint8_t *)c.values + c.offset * w, vbytes, hipMemcpyHostToDevice, s));
+  d.values = (const uint8_t *)dv;
+  if (c.validity) {
+    const int64_t b0 = c.offset >> 3, b1 = (c.offset + c.length + 7) >> 3;
+    void *db = nullptr;
+    HIP_TRY(hipMalloc(&db, (size_t)(b1 - b0) + 8));
+    st.owned.push_back(db);
+    if (b1 > b0) HIP_TRY(hipMemcpyAsync(db, c.validity + b0, (size_t)(b1 - b0), hipMemcpyHostToDevice, s));
+    d.validity = (const uint8_t *)db;
+    d.boff = c.offset & 7;
+  }
+  return PLHIP_OK;
+}
+
+uint64_t next_pow2(uint64_t x) {
+  uint64_t p = 1;
+  while (p < x) p <<= 1;
+  return p;
+}
+int bit_length(uint64_t x) {
+  int b = 0;
+  while (x) { b++; x >>= 1; }
+  return b;
+}
+
+int add_acc(Plan &p, uint32_t op, uint32_t conv, int src, uint32_t width, uint64_t init) {
+  for (int i = 0; i < p.n_accs; i++)
+    if (p.accs[i].op == op && p.accs[i].conv == conv && p.accs[i].src == src) return i;
+  if (p.n_accs >= PLHIP_MAX_ACCS) return -1;
+  AccSpec &a = p.accs[p.n_accs];
+  a.op = op; a.conv = conv; a.src = src; a.width = width; a.init = init; a.offset = 0;
+  return p.n_accs++;
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------------------------
+// result frames
+// ---------------------------------------------------------------------------------------------------------
+struct ResultCol {
+  int dtype = 0;
+  void *values = nullptr;   // device or host (malloc)
+  uint8_t *validity = nullptr;
+};
+struct plhip_result {
+  std::vector<ResultCol> cols;
+  int64_t n_rows = 0;
+  bool on_device = false;
+  int device = 0;
+  ~plhip_result() {
+    for (auto &c : cols) {
+      if (on_device) { if (c.values) hipFree(c.values); if (c.validity) hipFree(c.validity); }
+      else { free(c.values); free(c.validity); }
+    }
+  }
+};
+
+struct plhip_groups {
+  uint32_t *first = nullptr, *offsets = nullptr, *indices = nullptr;
+  int64_t n_groups = 0, n_rows = 0;
+  bool on_device = false;
+  ~plhip_groups() {
+    if (on_device) { hipFree(first); hipFree(offsets); hipFree(indices); }
+    else { free(first); free(offsets); free(indices); }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// lowering
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+struct KeyCol { // a key column on its way into the packed key
+  DevCol col;
+  uint64_t lo = 0, hi = 0; // range of the normalised bits over valid rows
+  uint32_t bits = 64;
+  bool nullable = false;
+};
+
+void set_keyspec(KeySpec &k, const KeyCol &kc) {
+  k.values = kc.col.values; k.validity = kc.col.validity; k.boff = kc.col.boff; k.dtype = (uint32_t)kc.col.dtype;
+  k.minv = kc.lo; k.shift = 0; k.bits = kc.bits; k.nullable = kc.nullable ? 1 : 0;
+}
+
+int read_flags(TableRef t, uint32_t *out8);
+
+// min/max pass over `cols` (k_key_minmax), then bits = bit_length(hi - lo + nullable)
+int measure_key_columns(std::vector<KeyCol> &cols, int64_t n) {
+  Ctx &c = g_ctx;
+  Plan M{};
+  M.n_rows = n; M.n_keys = (int)cols.size();
+  for (size_t i = 0; i < cols.size(); i++) { cols[i].lo = 0; cols[i].bits = 64; set_keyspec(M.keys[i], cols[i]); }
+  const size_t mm_bytes = cols.size() * 2 * sizeof(uint64_t);
+  HIP_TRY(c.misc.reserve(mm_bytes));
+  std::vector<uint64_t> mm(cols.size() * 2);
+  for (size_t i = 0; i < cols.size(); i++) { mm[2 * i] = ~0ull; mm[2 * i + 1] = 0; }
+  HIP_TRY(hipMemcpyAsync(c.misc.p, mm.data(), mm_bytes, hipMemcpyHostToDevice, c.stream));
+  if (n > 0) launch_key_minmax(M, (uint64_t *)c.misc.p, c.stream);
+  HIP_TRY(hipMemcpyAsync(mm.data(), c.misc.p, mm_bytes, hipMemcpyDeviceToHost, c.stream));
+  HIP_TRY(hipStreamSynchronize(c.stream));
+  for (size_t i = 0; i < cols.size(); i++) {
+    KeyCol &k = cols[i];
+    const uint64_t lo = mm[2 * i], hi = mm[2 * i + 1];
+    const uint64_t span = hi >= lo ? hi - lo : 0; // no valid row: only the null code
+    k.lo = hi >= lo ? lo : 0;
+    k.hi = hi >= lo ? hi : 0;
+    k.bits = (k.nullable && span == ~0ull) ? 65u : (uint32_t)bit_length(span + (k.nullable ? 1 : 0));
+  }
+  return PLHIP_OK;
+}
+
+// Fills P.keys from packable columns (sum of bits <= 64): key 0 in the most significant bits.
+void pack_keys(Plan &P, const std::vector<KeyCol> &cols) {
+  P.n_keys = (int)cols.size();
+  int shift = 0;
+  for (auto &k : cols) shift += (int)k.bits;
+  for (size_t i = 0; i < cols.size(); i++) {
+    set_keyspec(P.keys[i], cols[i]);
+    shift -= (int)cols[i].bits;
+    P.keys[i].shift = (uint32_t)shift;
+  }
+}
+
+// Dense ids of the distinct tuples of `sub` (whose bits fit one word): ids[row] in [0, n_distinct).
+// The wide-tuple analogue of the reference hashing rows first (vector_hasher.rs:467-483) and comparing
+// keys on equal hashes (hashing.rs:334-378) - here the tuple is made narrow instead, so equality is exact.
+int dense_ids(const std::vector<KeyCol> &sub, int64_t n, Staging &st, KeyCol &out) {
+  Ctx &c = g_ctx;
+  Plan K{};
+  K.n_rows = n;
+  K.single_key = 0; // nulls are codes: a null tuple member must get an id like any other value
+  pack_keys(K, sub);
+  const uint64_t cap = next_pow2(std::max<uint64_t>(2 * (uint64_t)n, 1024));
+  plan_layout(K, cap);
+  HIP_TRY(c.table.reserve(table_bytes(K, cap)));
+  HIP_TRY(c.flags.reserve(64));
+  HIP_TRY(c.slots.reserve((cap + 2) * 8));
+  HIP_TRY(c.rank.reserve((cap + 2) * 4));
+  void *ids = nullptr;
+  HIP_TRY(hipMalloc(&ids, (size_t)std::max<int64_t>(n, 1) * 4));
+  st.owned.push_back(ids);
+  TableRef t{(uint8_t *)c.table.p, cap, (uint32_t *)c.flags.p};
+  launch_table_init(K, t, c.stream);
+  launch_sample_keys(K, t, n, 1, c.stream);
+  launch_compact(K, t, (uint64_t *)c.slots.p, c.stream);
+  uint32_t f[8];
+  int rc = read_flags(t, f);
+  if (rc) return rc;
+  if (f[FLAG_OVERFLOW]) return fail(PLHIP_ERR_COMPUTE, "hash table overflow while encoding wide keys");
+  const uint64_t g = f[FLAG_NGROUPS];
+  launch_rank_scatter((const uint64_t *)c.slots.p, g, (uint32_t *)c.rank.p, c.stream);
+  launch_encode_rows(K, t, (const uint32_t *)c.rank.p, (uint32_t *)ids, c.stream);
+  HIP_TRY(hipGetLastError());
+  out = KeyCol{};
+  out.col.values = (const uint8_t *)ids; out.col.validity = nullptr; out.col.boff = 0; out.col.length = n;
+  out.col.dtype = PLHIP_U32;
+  out.lo = 0; out.hi = g ? g - 1 : 0; out.bits = (uint32_t)bit_length(out.hi); out.nullable = false;
+  return PLHIP_OK;
+}
+
+// Lowers the key columns to the packed-key plan.  `KG.enabled` is set when the tuple had to be reduced
+// to dense ids (then output keys are gathered at the first row).
+int build_keys(Plan &P, const std::vector<DevCol> &keys, Staging &st, KeyGather &KG) {
+  KG.enabled = 0; KG.first_acc = -1;
+  P.single_key = keys.size() == 1;
+  std::vector<KeyCol> cols(keys.size());
+  for (size_t i = 0; i < keys.size(); i++) {
+    cols[i].col = keys[i];
+    cols[i].nullable = keys[i].validity != nullptr;
+    KeySpec tmp{};
+    set_keyspec(tmp, cols[i]);
+    tmp.minv = 0;
+    KG.okeys[i] = tmp;
+  }
+  if (P.single_key) { // normalised bits as they are; null -> reserved slot
+    cols[0].lo = 0; cols[0].bits = 64; cols[0].nullable = false;
+    pack_keys(P, cols);
+    return PLHIP_OK;
+  }
+  int rc = measure_key_columns(cols, P.n_rows);
+  if (rc) return rc;
+  auto total_bits = [&]() { int t = 0; for (auto &k : cols) t += (int)k.bits; return t; };
+  while (total_bits() > 64) {
+    KG.enabled = 1;
+    std::stable_sort(cols.begin(), cols.end(), [](const KeyCol &a, const KeyCol &b) { return a.bits > b.bits; });
+    std::vector<KeyCol> sub;
+    size_t take = 0;
+    if (cols[0].bits > 64) { // 64-bit span plus nulls: split off the null flag by encoding the column alone
+      // a single nullable full-range column: encode it through the single-key path semantics
+      return fail(PLHIP_ERR_UNSUPPORTED_DTYPE, "a nullable key column spans the full 64-bit range inside a wide key tuple");
+    }
+    if (cols[0].bits > 32) take = 1;
+    else { int t = 0; while (take < cols.size() && t + (int)cols[take].bits <= 64) { t += (int)cols[take].bits; take++; } }
+    sub.assign(cols.begin(), cols.begin() + take);
+    KeyCol enc;
+    if ((rc = dense_ids(sub, P.n_rows, st, enc))) return rc;
+    cols.erase(cols.begin(), cols.begin() + take);
+    cols.push_back(enc);
+  }
+  pack_keys(P, cols);
+  return PLHIP_OK;
+}
+
+struct Lowered {
+  Plan P;
+  KeyGather KG;
+  int n_out_keys = 0;
+  std::vector<OutSpec> outs;
+  int first_acc = -1;
+};
+
+int build_aggs(Lowered &L, const std::vector<DevCol> &vals, const plhip_agg_t *aggs, int n_aggs, uint32_t flags) {
+  Plan &P = L.P;
+  P.n_vals = (int)vals.size();
+  for (size_t i = 0; i < vals.size(); i++) {
+    ValSpec &v = P.vals[i];
+    v.values = vals[i].values; v.validity = vals[i].validity; v.boff = vals[i].boff; v.dtype = (uint32_t)vals[i].dtype; v.pad = 0;
+  }
+  for (int k = 0; k < L.n_out_keys; k++) { // output keys are the ORIGINAL key columns, in order
+    OutSpec o{};
+    o.kind = OUT_KEY; o.dtype = L.KG.okeys[k].dtype; o.acc = k; o.cnt_valid = -1; o.cnt_all = -1;
+    o.validity = L.KG.okeys[k].validity ? (uint8_t *)1 : nullptr; // placeholder: "needs a bitmap"
+    L.outs.push_back(o);
+  }
+  const bool partial = flags & PLHIP_FLAG_PARTIAL;
+  for (int i = 0; i < n_aggs; i++) {
+    const int kind = aggs[i].kind;
+    OutSpec o{};
+    o.cnt_valid = -1; o.cnt_all = -1; o.acc = -1;
+    if (kind == PLHIP_AGG_COUNT) {
+      o.kind = partial ? OUT_RAW_U32_AS_U64 : OUT_COUNT;
+      o.dtype = partial ? PLHIP_U64 : PLHIP_U32;
+      o.acc = add_acc(P, ACC_CNT_ALL, CONV_NONE, -1, 4, 0);
+      if (o.acc < 0) return fail(PLHIP_ERR_INVALID, "too many accumulators");
+      L.outs.push_back(o);
+      continue;
+    }
+    if (kind < 0 || kind > PLHIP_AGG_COUNT) return fail(PLHIP_ERR_INVALID, "bad aggregation kind");
+    const int ci = aggs[i].column;
+    if (ci < 0 || ci >= (int)vals.size()) return fail(PLHIP_ERR_INVALID, "aggregation column index out of range");
+    const int dt = vals[ci].dtype;
+    const bool nullable = vals[ci].validity != nullptr;
+    const bool is_f = dt_is_float(dt), is_s = dt_is_signed(dt);
+    const int w = dtype_width(dt);
+    const int cnt_valid = nullable ? add_acc(P, ACC_CNT_VALID, CONV_NONE, ci, 4, 0) : -1;
+    if (kind == PLHIP_AGG_SUM) {
+      if (is_f) { o.kind = OUT_SUM_F64; o.dtype = dt; o.acc = add_acc(P, ACC_ADD_F64, CONV_F64, ci, 8, 0); }
+      else {
+        o.kind = OUT_SUM_INT; o.dtype = w < 4 ? PLHIP_I64 : dt; // series/implementations/mod.rs:167-174
+        o.acc = add_acc(P, ACC_ADD_U64, CONV_INT, ci, 8, 0);
+      }
+      if (partial && is_f) { o.kind = OUT_RAW_U64; o.dtype = PLHIP_F64; }
+      if (partial && !is_f) { o.kind = OUT_RAW_U64; o.dtype = (is_s || w < 4) ? PLHIP_I64 : PLHIP_U64; }
+      o.validity = nullptr;
+    } else if (kind == PLHIP_AGG_MEAN) {
+      o.cnt_valid = cnt_valid;
+      o.cnt_all = add_acc(P, ACC_CNT_ALL, CONV_NONE, -1, 4, 0);
+      if (!is_f && w <= 4) {
+        o.kind = is_s ? OUT_MEAN_INT : OUT_MEAN_UINT; o.dtype = PLHIP_F64;
+        o.acc = add_acc(P, ACC_ADD_U64, CONV_INT, ci, 8, 0);
+      } else {
+        o.kind = OUT_MEAN_F64; o.dtype = dt == PLHIP_F32 ? PLHIP_F32 : PLHIP_F64;
+        o.acc = add_acc(P, ACC_ADD_F64, CONV_F64, ci, 8, 0);
+      }
+      o.validity = nullable ? (uint8_t *)1 : nullptr;
+      if (partial) { // (sum, valid count) as in evaluate_partitioned (aggregation.rs:297-322)
+        OutSpec s = o;
+        s.kind = OUT_RAW_U64; s.validity = nullptr;
+        s.dtype = (o.kind == OUT_MEAN_F64) ? PLHIP_F64 : (is_s ? PLHIP_I64 : PLHIP_U64);
+        L.outs.push_back(s);
+        o.kind = OUT_RAW_U32_AS_U64; o.dtype = PLHIP_U64; o.acc = nullable ? cnt_valid : o.cnt_all; o.validity = nullptr;
+      }
+    } else { // MIN / MAX
+      const bool is_min = kind == PLHIP_AGG_MIN;
+      o.dtype = dt;
+      o.cnt_valid = cnt_valid;
+      if (is_f) {
+        o.kind = is_min ? OUT_FMIN : OUT_FMAX;
+        o.cnt_all = add_acc(P, ACC_CNT_ALL, CONV_NONE, -1, 4, 0);
+        o.acc = is_min ? add_acc(P, ACC_MIN_U64, CONV_FMIN, ci, 8, ~0ull) : add_acc(P, ACC_MAX_U64, CONV_FMAX, ci, 8, 0);
+      } else {
+        o.kind = OUT_MIN_INT;
+        if (is_s) o.acc = is_min ? add_acc(P, ACC_MIN_I64, CONV_INT, ci, 8, (uint64_t)INT64_MAX)
+                                 : add_acc(P, ACC_MAX_I64, CONV_INT, ci, 8, (uint64_t)INT64_MIN);
+        else o.acc = is_min ? add_acc(P, ACC_MIN_U64, CONV_INT, ci, 8, ~0ull) : add_acc(P, ACC_MAX_U64, CONV_INT, ci, 8, 0);
+      }
+      o.validity = nullable ? (uint8_t *)1 : nullptr;
+    }
+    if (o.acc < 0 || (kind == PLHIP_AGG_MEAN && o.cnt_all < 0)) return fail(PLHIP_ERR_INVALID, "too many accumulators");
+    L.outs.push_back(o);
+  }
+  if ((flags & PLHIP_FLAG_MAINTAIN_ORDER) || L.KG.enabled) {
+    L.first_acc = add_acc(P, ACC_FIRST_ROW, CONV_NONE, -1, 4, 0xFFFFFFFFull);
+    if (L.first_acc < 0) return fail(PLHIP_ERR_INVALID, "too many accumulators");
+    L.KG.first_acc = L.first_acc;
+  }
+  if ((int)L.outs.size() > PLHIP_MAX_OUTS) return fail(PLHIP_ERR_INVALID, "too many output columns");
+  return PLHIP_OK;
+}
+
+int env_strategy() {
+  const char *e = getenv("PLHIP_STRATEGY");
+  if (!e) return PLHIP_STRATEGY_AUTO;
+  if (!strcmp(e, "global")) return PLHIP_STRATEGY_GLOBAL;
+  if (!strcmp(e, "lds")) return PLHIP_STRATEGY_LDS;
+  if (!strcmp(e, "partitioned")) return PLHIP_STRATEGY_PARTITIONED;
+  return PLHIP_STRATEGY_AUTO;
+}
+
+// Largest power-of-two LDS table (slots) that fits `budget` bytes.
+uint32_t lds_cap_for(const Plan &P, size_t budget) {
+  uint32_t cap = 1u << 15;
+  while (cap > 64 && lds_table_bytes(P, cap) > budget) cap >>= 1;
+  return cap;
+}
+
+// Sampled cardinality estimate, the analogue of estimate_unique_count
+// (crates/polars-lazy/src/physical_plan/executors/group_by_partitioned.rs:115-157): insert every
+// (n/s)-th row's key into a scratch HBM table and count the distinct keys d, then invert
+// E[d] = G (1 - exp(-s/G)).
+int estimate_groups(const Plan &P, uint64_t &g_est);
+
+} // namespace
+
+// kernels.hip: a keys-only pass over a strided sample (declared here to keep kernels.hpp minimal)
+void launch_sample_keys(const Plan &p, TableRef t, int64_t n_sample, int64_t stride, hipStream_t s);
+
+namespace {
+
+int read_flags(TableRef t, uint32_t *out8) {
+  Ctx &c = g_ctx;
+  HIP_TRY(hipMemcpyAsync(c.host_flags, t.flags, 32, hipMemcpyDeviceToHost, c.stream));
+  HIP_TRY(hipStreamSynchronize(c.stream));
+  memcpy(out8, c.host_flags, 32);
+  return PLHIP_OK;
+}
+
+int estimate_groups(const Plan &P, uint64_t &g_est) {
+  Ctx &c = g_ctx;
+  const int64_t n = P.n_rows;
+  const int64_t s = std::min<int64_t>(n, 1 << 16);
+  if (s <= 0) { g_est = 0; return PLHIP_OK; }
+  Plan K = P;
+  K.n_accs = 0;
+  const uint64_t cap = 1u << 18;
+  HIP_TRY(c.table.reserve(table_bytes(K, cap)));
+  HIP_TRY(c.flags.reserve(64));
+  HIP_TRY(c.slots.reserve((cap + 2) * 8));
+  TableRef t{(uint8_t *)c.table.p, cap, (uint32_t *)c.flags.p};
+  plan_layout(K, cap);
+  launch_table_init(K, t, c.stream);
+  launch_sample_keys(K, t, s, n / s, c.stream);
+  launch_compact(K, t, (uint64_t *)c.slots.p, c.stream);
+  uint32_t f[8];
+  int rc = read_flags(t, f);
+  if (rc) return rc;
+  const double d = f[FLAG_NGROUPS];
+  if (d >= 0.9 * (double)s) { g_est = (uint64_t)n; return PLHIP_OK; }
+  // solve d = G (1 - exp(-s/G)) by bisection on G in [d, n]
+  double lo = d, hi = (double)n;
+  for (int it = 0; it < 60; it++) {
+    const double g = 0.5 * (lo + hi);
+    const double e = g * (1.0 - std::exp(-(double)s / g));
+    if (e < d) lo = g; else hi = g;
+  }
+  g_est = (uint64_t)std::min<double>((double)n, std::ceil(hi));
+  return PLHIP_OK;
+}
+
+int copy_out(const void *dev, size_t bytes, void **host) {
+  *host = malloc(bytes ? bytes : 8);
+  if (!*host) return fail(PLHIP_ERR_OOM, "host allocation failed");
+  if (bytes) HIP_TRY(hipMemcpy(*host, dev, bytes, hipMemcpyDeviceToHost));
+  return PLHIP_OK;
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------------------------
+// library entry points
+// ---------------------------------------------------------------------------------------------------------
+extern "C" {
+
+int32_t plhip_abi_version(void) { return PLHIP_ABI_VERSION; }
+
+int32_t plhip_init(int32_t device_id) {
+  Ctx &c = g_ctx;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(PLHIP_ERR_NO_DEVICE, "no HIP device visible; libplhip.so has no CPU path (gfx950 required)");
+  if (device_id < 0 || device_id >= n) return fail(PLHIP_ERR_INVALID, "device id out of range");
+  if (c.device >= 0 && c.device != device_id) return fail(PLHIP_ERR_INVALID, "this thread is already bound to another device");
+  HIP_TRY(hipSetDevice(device_id));
+  return ensure_ctx();
+}
+
+const char *plhip_last_error(void) { return g_ctx.err.c_str(); }
+
+int32_t plhip_set_strategy(int32_t strategy) {
+  if (strategy < 0 || strategy > PLHIP_STRATEGY_PARTITIONED) return fail(PLHIP_ERR_INVALID, "bad strategy");
+  g_ctx.forced_strategy = strategy;
+  return PLHIP_OK;
+}
+
+const char *plhip_last_strategy(void) { return g_ctx.strategy.c_str(); }
+
+int32_t plhip_last_kernel_ms(float *total_ms, float *dominant_ms, const char **dominant_kernel) {
+  if (total_ms) *total_ms = g_ctx.total_ms;
+  if (dominant_ms) *dominant_ms = g_ctx.dom_ms;
+  if (dominant_kernel) *dominant_kernel = g_ctx.dom_kernel.c_str();
+  return PLHIP_OK;
+}
+
+int32_t plhip_vec_hash(const plhip_column_t *keys, int32_t n_keys, uint64_t null_hash, uint64_t *out,
+                       int32_t out_location) {
+  if (!keys || n_keys < 1 || n_keys > PLHIP_MAX_KEYS) return fail(PLHIP_ERR_INVALID, "bad key columns");
+  int rc = ensure_ctx();
+  if (rc) return rc;
+  Ctx &c = g_ctx;
+  const int64_t n = keys[0].length;
+  for (int i = 0; i < n_keys; i++)
+    if (keys[i].length != n) return fail(PLHIP_ERR_SHAPE_MISMATCH, "key columns differ in length");
+  if (n > 0 && !out) return fail(PLHIP_ERR_INVALID, "output pointer is NULL");
+  Staging st;
+  std::vector<DevCol> dk(n_keys);
+  for (int i = 0; i < n_keys; i++) if ((rc = stage_column(keys[i], dk[i], st, c.stream))) return rc;
+  Plan P{};
+  P.n_rows = n; P.n_keys = n_keys;
+  for (int i = 0; i < n_keys; i++) {
+    P.keys[i].values = dk[i].values; P.keys[i].validity = dk[i].validity; P.keys[i].boff = dk[i].boff;
+    P.keys[i].dtype = dk[i].dtype;
+  }
+  if (n == 0) return PLHIP_OK;
+  uint64_t *dout = out;
+  if (out_location == PLHIP_HOST) {
+    HIP_TRY(c.misc.reserve((size_t)n * 8));
+    dout = (uint64_t *)c.misc.p;
+  }
+  launch_vec_hash(P, null_hash, dout, c.stream);
+  HIP_TRY(hipGetLastError());
+  if (out_location == PLHIP_HOST) HIP_TRY(hipMemcpyAsync(out, dout, (size_t)n * 8, hipMemcpyDeviceToHost, c.stream));
+  HIP_TRY(hipStreamSynchronize(c.stream));
+  return PLHIP_OK;
+}
+
+int32_t plhip_group_by_agg(const plhip_column_t *keys, int32_t n_keys, const plhip_column_t *values,
+                           int32_t n_values, const plhip_agg_t *aggs, int32_t n_aggs, uint32_t flags,
+                           plhip_result_t **out) {
+  if (!out) return fail(PLHIP_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  // group_by/mod.rs:59-62
+  if (n_keys < 1 || !keys) return fail(PLHIP_ERR_COMPUTE, "at least one key is required in a group_by operation");
+  if (n_keys > PLHIP_MAX_KEYS) return fail(PLHIP_ERR_INVALID, "too many key columns (max 16)");
+  if (n_values < 0 || n_values > PLHIP_MAX_VALS || (n_values > 0 && !values)) return fail(PLHIP_ERR_INVALID, "bad value columns");
+  if (n_aggs < 0 || (n_aggs > 0 && !aggs)) return fail(PLHIP_ERR_INVALID, "bad aggregation list");
+  const int64_t n = keys[0].length;
+  // group_by/mod.rs:67-71
+  for (int i = 0; i < n_keys; i++)
+    if (keys[i].length != n) return fail(PLHIP_ERR_SHAPE_MISMATCH, "series used as keys should have the same length as the dataframe");
+  for (int i = 0; i < n_values; i++)
+    if (values[i].length != n) return fail(PLHIP_ERR_SHAPE_MISMATCH, "series used as keys should have the same length as the dataframe");
+  if (n > 0xFFFFFFFFll) return fail(PLHIP_ERR_COMPUTE, "more than u32::MAX rows (IdxSize is u32)");
+  int rc = ensure_ctx();
+  if (rc) return rc;
+  Ctx &c = g_ctx;
+
+  Staging st;
+  std::vector<DevCol> dk(n_keys), dv(n_values);
+  for (int i = 0; i < n_keys; i++) if ((rc = stage_column(keys[i], dk[i], st, c.stream))) return rc;
+  for (int i = 0; i < n_values; i++) if ((rc = stage_column(values[i], dv[i], st, c.stream))) return rc;
+
+  Lowered L{};
+  L.P.n_rows = n;
+  HIP_TRY(hipEventRecord(c.ev[0], c.stream));
+  L.n_out_keys = n_keys;
+  if ((rc = build_keys(L.P, dk, st, L.KG))) return rc;
+  if ((rc = build_aggs(L, dv, aggs, n_aggs, flags))) return rc;
+  Plan &P = L.P;
+
+  // ---- strategy ------------------------------------------------------------------------------------
+  int strategy = c.forced_strategy > 0 ? c.forced_strategy : env_strategy();
+  uint64_t g_est = (uint64_t)n;
+  const size_t lds_budget = 150 * 1024;
+  const uint32_t lds_cap_max = lds_cap_for(P, lds_budget);
+  if (n >= (1 << 14) && (rc = estimate_groups(P, g_est))) return rc;
+  if (strategy == PLHIP_STRATEGY_AUTO) {
+    if (n < (1 << 14)) strategy = PLHIP_STRATEGY_GLOBAL;
+    else strategy = (g_est <= lds_cap_max / 2) ? PLHIP_STRATEGY_LDS : PLHIP_STRATEGY_GLOBAL;
+  }
+  if (strategy == PLHIP_STRATEGY_PARTITIONED) strategy = PLHIP_STRATEGY_GLOBAL; // TODO(partitioned)
+
+  uint32_t fl[8] = {0};
+  uint64_t cap = 0;
+  TableRef T{};
+  for (int attempt = 0;; attempt++) {
+    uint64_t want = attempt == 0 ? std::min<uint64_t>((uint64_t)n, g_est * 2 + 1024) : (uint64_t)n;
+    cap = next_pow2(std::max<uint64_t>(2 * want, 1024));
+    plan_layout(P, cap);
+    HIP_TRY(c.table.reserve(table_bytes(P, cap)));
+    HIP_TRY(c.flags.reserve(64));
+    HIP_TRY(c.slots.reserve((cap + 2) * 8));
+    T = TableRef{(uint8_t *)c.table.p, cap, (uint32_t *)c.flags.p};
+    launch_table_init(P, T, c.stream);
+    HIP_TRY(hipEventRecord(c.ev[1], c.stream));
+    if (strategy == PLHIP_STRATEGY_LDS) {
+      uint32_t lcap = lds_cap_max;
+      if (g_est < (uint64_t)n) { // size the LDS table to the estimate (4x head-room), not to the budget
+        uint32_t fit = (uint32_t)next_pow2(std::max<uint64_t>(4 * g_est, 256));
+        if (fit < lcap) lcap = fit;
+      }
+      launch_agg_lds(P, T, lcap, c.stream);
+      c.strategy = "lds"; c.dom_kernel = "k_agg_lds";
+    } else {
+      launch_agg_global(P, T, c.stream);
+      c.strategy = "global"; c.dom_kernel = "k_agg_global";
+    }
+    HIP_TRY(hipEventRecord(c.ev[2], c.stream));
+    launch_compact(P, T, (uint64_t *)c.slots.p, c.stream);
+    HIP_TRY(hipGetLastError());
+    if ((rc = read_flags(T, fl))) return rc;
+    if (!fl[FLAG_OVERFLOW]) break;
+    if (attempt >= 1) return fail(PLHIP_ERR_COMPUTE, "hash table overflow at load factor <= 0.5");
+  }
+  const uint64_t G = fl[FLAG_NGROUPS];
+  uint64_t *slots = (uint64_t *)c.slots.p;
+
+  // ---- ordering --------------------------------------------------------------------------------------
+  if ((flags & (PLHIP_FLAG_MAINTAIN_ORDER | PLHIP_FLAG_SORT_KEYS)) && G > 1) {
+    const bool by_first = (flags & PLHIP_FLAG_MAINTAIN_ORDER) || L.KG.enabled; // dense ids have no canonical order
+    // null group: slot list position 0 already (keys order: nulls first); by-first sorts everything
+    const uint64_t skip = (!by_first && fl[FLAG_NULL]) ? 1 : 0;
+    HIP_TRY(c.sortkeys.reserve(G * 8));
+    launch_gather_sort_keys(P, T, slots + skip, G - skip, by_first ? L.first_acc : -1, (uint64_t *)c.sortkeys.p, c.stream);
+    HIP_TRY(sort_pairs_u64((uint64_t *)c.sortkeys.p, slots + skip, G - skip, by_first ? 32 : 64, c.stream));
+  }
+
+  // ---- outputs ---------------------------------------------------------------------------------------
+  plhip_result *R = new (std::nothrow) plhip_result();
+  if (!R) return fail(PLHIP_ERR_OOM, "host allocation failed");
+  R->n_rows = (int64_t)G;
+  R->on_device = true; // until copied
+  R->device = c.device;
+  OutPlan O{};
+  O.n_outs = (int)L.outs.size();
+  for (size_t i = 0; i < L.outs.size(); i++) {
+    OutSpec o = L.outs[i];
+    ResultCol rcnew;
+    rcnew.dtype = (int)o.dtype;
+    const size_t vb = (size_t)std::max<uint64_t>(G, 1) * dtype_width((int)o.dtype);
+    hipError_t e = hipMalloc(&rcnew.values, vb);
+    if (e == hipSuccess && o.validity) e = hipMalloc((void **)&rcnew.validity, (G / 64 + 1) * 8);
+    R->cols.push_back(rcnew);
+    if (e != hipSuccess) { delete R; return fail_hip(e, "hipMalloc(output)"); }
+    o.values = (uint8_t *)rcnew.values;
+    o.validity = rcnew.validity;
+    O.outs[i] = o;
+  }
+  HIP_TRY(c.plans.reserve(sizeof(OutPlan) + sizeof(KeyGather)));
+  HIP_TRY(hipMemcpyAsync(c.plans.p, &O, sizeof(OutPlan), hipMemcpyHostToDevice, c.stream));
+  HIP_TRY(hipMemcpyAsync((uint8_t *)c.plans.p + sizeof(OutPlan), &L.KG, sizeof(KeyGather), hipMemcpyHostToDevice, c.stream));
+  launch_finalize(P, T, (const OutPlan *)c.plans.p, (const KeyGather *)((uint8_t *)c.plans.p + sizeof(OutPlan)), slots, G, c.stream);
+  HIP_TRY(hipEventRecord(c.ev[3], c.stream));
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
+  if (e != hipSuccess) { delete R; return fail_hip(e, "group-by kernels"); }
+  hipEventElapsedTime(&c.total_ms, c.ev[0], c.ev[3]);
+  hipEventElapsedTime(&c.dom_ms, c.ev[1], c.ev[2]);
+
+  if (!(flags & PLHIP_FLAG_OUTPUT_DEVICE)) {
+    plhip_result *H = new (std::nothrow) plhip_result();
+    if (!H) { delete R; return fail(PLHIP_ERR_OOM, "host allocation failed"); }
+    H->n_rows = R->n_rows; H->on_device = false; H->device = c.device;
+    for (auto &col : R->cols) {
+      ResultCol h;
+      h.dtype = col.dtype;
+      rc = copy_out(col.values, (size_t)G * dtype_width(col.dtype), &h.values);
+      if (!rc && col.validity) rc = copy_out(col.validity, (G / 64 + 1) * 8, (void **)&h.validity);
+      H->cols.push_back(h);
+      if (rc) { delete R; delete H; return rc; }
+    }
+    delete R;
+    R = H;
+  }
+  *out = R;
+  return PLHIP_OK;
+}
+
+int64_t plhip_result_num_rows(const plhip_result_t *r) { return r ? r->n_rows : -1; }
+int32_t plhip_result_num_columns(const plhip_result_t *r) { return r ? (int32_t)r->cols.size() : -1; }
+int32_t plhip_result_column(const plhip_result_t *r, int32_t i, plhip_column_t *col) {
+  if (!r || !col || i < 0 || i >= (int32_t)r->cols.size()) return fail(PLHIP_ERR_INVALID, "bad result column index");
+  col->values = r->cols[i].values;
+  col->validity = r->cols[i].validity;
+  col->offset = 0;
+  col->length = r->n_rows;
+  col->dtype = r->cols[i].dtype;
+  col->location = r->on_device ? PLHIP_DEVICE : PLHIP_HOST;
+  return PLHIP_OK;
+}
+void plhip_result_free(plhip_result_t *r) { delete r; }
+
+// ---- two-step API (filled in by groups.hip) --------------------------------------------------------
+int64_t plhip_groups_num_groups(const plhip_groups_t *g) { return g ? g->n_groups : -1; }
+int64_t plhip_groups_num_rows(const plhip_groups_t *g) { return g ? g->n_rows : -1; }
+int32_t plhip_groups_buffers(const plhip_groups_t *g, const uint32_t **first, const uint32_t **offsets,
+                             const uint32_t **indices, int32_t *location) {
+  if (!g) return fail(PLHIP_ERR_INVALID, "groups handle is NULL");
+  if (first) *first = g->first;
+  if (offsets) *offsets = g->offsets;
+  if (indices) *indices = g->indices;
+  if (location) *location = g->on_device ? PLHIP_DEVICE : PLHIP_HOST;
+  return PLHIP_OK;
+}
+void plhip_groups_free(plhip_groups_t *g) { delete g; }
+
+int32_t plhip_group_tuples(const plhip_column_t *, int32_t, int32_t, int32_t, plhip_groups_t **) {
+  return fail(PLHIP_ERR_COMPUTE, "plhip_group_tuples: not built yet");
+}
+int32_t plhip_agg_groups(const plhip_column_t *, int32_t, const plhip_groups_t *, uint32_t, plhip_result_t **) {
+  return fail(PLHIP_ERR_COMPUTE, "plhip_agg_groups: not built yet");
+}
+
+} // extern "C"

@@ -1,0 +1,506 @@
+// kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the hash group-by aggregation path.
+//
+// The path is HBM-bound integer/byte work: no MFMA.  What matters is coalesced column reads, keeping the
+// per-group accumulators in LDS (ds_* atomics) whenever the groups a workgroup sees fit there, and
+// touching HBM-resident tables with as few (scattered, memory-side) atomics as possible.
+//
+//   k_table_init   fill an HBM table with EMPTY keys / accumulator identities
+//   k_agg_global   every row -> find-or-insert in the HBM table + global atomics  (any cardinality; the
+//                  fallback and the correctness anchor)
+//   k_agg_lds      persistent workgroups, one LDS open-addressing table each (ds_cmpst_b64 claim, ds_add /
+//                  ds_min / ds_max folds), rows that do not fit spill to the HBM table, then ONE merge of
+//                  every LDS slot into the HBM table
+//   k_compact      occupied slots -> dense slot list + group count
+//   k_finalize     accumulators -> the reference's output columns (dtype / null / NaN rules)
+//   k_key_minmax   per key column min/max of the normalised bits (range compression of multi-key tuples)
+//   k_vec_hash     VecHash::vec_hash / vec_hash_combine
+#include "kernels.hpp"
+
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+#include "device.hpp"
+
+// ---------------------------------------------------------------------------------------------------------
+// layout
+// ---------------------------------------------------------------------------------------------------------
+static inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+
+void plan_layout(Plan &p, uint64_t cap) {
+  uint64_t off = align_up((cap + 2) * 8, 256);
+  for (int i = 0; i < p.n_accs; i++) {
+    p.accs[i].offset = off;
+    off += align_up((cap + 2) * p.accs[i].width, 256);
+  }
+}
+
+size_t table_bytes(const Plan &p, uint64_t cap) {
+  uint64_t off = align_up((cap + 2) * 8, 256);
+  for (int i = 0; i < p.n_accs; i++) off += align_up((cap + 2) * p.accs[i].width, 256);
+  return off;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// HBM table init
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_table_init(Plan P, TableRef T) {
+  const uint64_t n = T.cap + 2;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    ((uint64_t *)T.base)[i] = PLHIP_EMPTY_KEY;
+    for (int a = 0; a < P.n_accs; a++) {
+      const AccSpec &A = P.accs[a];
+      if (A.width == 8) ((uint64_t *)(T.base + A.offset))[i] = A.init;
+      else ((uint32_t *)(T.base + A.offset))[i] = (uint32_t)A.init;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 8) T.flags[threadIdx.x] = 0;
+}
+
+void launch_table_init(const Plan &p, TableRef t, hipStream_t s) {
+  uint64_t n = t.cap + 2;
+  int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(k_table_init, dim3(grid), dim3(256), 0, s, p, t);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// strategy "global": every row updates the HBM table
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_agg_global(Plan P, TableRef T) {
+  uint64_t *keys = (uint64_t *)T.base;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < P.n_rows; row += stride) {
+    bool isnull;
+    const uint64_t key = row_packed_key(P, row, isnull);
+    const uint64_t slot = gtable_slot(keys, T.cap, T.flags, key, isnull);
+    if (slot == ~0ull) continue; // overflow flag raised; the host retries with a larger table
+    for (int a = 0; a < P.n_accs; a++) {
+      const AccSpec &A = P.accs[a];
+      uint64_t operand;
+      if (acc_operand(P, A, row, operand)) acc_apply(T.base, A, slot, operand);
+    }
+  }
+}
+
+// keys-only pass over every `stride`-th row: the sampled cardinality estimate
+__global__ void __launch_bounds__(256) k_sample_keys(Plan P, TableRef T, int64_t n_sample, int64_t stride) {
+  uint64_t *keys = (uint64_t *)T.base;
+  const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_sample; i += gs) {
+    bool isnull;
+    const uint64_t key = row_packed_key(P, i * stride, isnull);
+    gtable_slot(keys, T.cap, T.flags, key, isnull);
+  }
+}
+
+void launch_sample_keys(const Plan &p, TableRef t, int64_t n_sample, int64_t stride, hipStream_t s) {
+  if (n_sample <= 0) return;
+  hipLaunchKernelGGL(k_sample_keys, dim3((unsigned)((n_sample + 255) / 256)), dim3(256), 0, s, p, t, n_sample, stride);
+}
+
+void launch_agg_global(const Plan &p, TableRef t, hipStream_t s) {
+  int64_t blocks = (p.n_rows + 255) / 256;
+  int grid = (int)(blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks));
+  hipLaunchKernelGGL(k_agg_global, dim3(grid), dim3(256), 0, s, p, t);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// strategy "lds": per-workgroup LDS tables
+// ---------------------------------------------------------------------------------------------------------
+#define LDS_PROBE_LIMIT 64
+#define LDS_BLOCK 1024
+
+extern __shared__ __align__(16) uint8_t smem[];
+
+// LDS find-or-insert: ds_cmpst_rtn_b64 claim on the key word; same protocol as the HBM table.
+DEVINL uint32_t lds_slot(uint64_t *lkeys, uint32_t lcap, uint32_t *lused, uint64_t key, bool isnull) {
+  if (isnull) { if (!lused[1]) lused[1] = 1; return lcap + 1; }
+  if (key == PLHIP_EMPTY_KEY) { if (!lused[0]) lused[0] = 1; return lcap; }
+  const uint32_t mask = lcap - 1;
+  const uint64_t h = hash_key(key);
+  uint32_t s = (uint32_t)(h >> 40) & mask; // high bits: independent of the HBM table's slot bits
+  for (int i = 0; i < LDS_PROBE_LIMIT; i++) {
+    uint64_t k = lkeys[s];
+    if (k == key) return s;
+    if (k == PLHIP_EMPTY_KEY) {
+      k = atomicCAS((unsigned long long *)&lkeys[s], (unsigned long long)PLHIP_EMPTY_KEY, (unsigned long long)key);
+      if (k == PLHIP_EMPTY_KEY || k == key) return s;
+    }
+    s = (s + 1) & mask;
+  }
+  return ~0u;
+}
+
+__global__ void __launch_bounds__(LDS_BLOCK) k_agg_lds(Plan P, TableRef T, uint32_t lcap, int64_t rows_per_wg) {
+  __shared__ uint32_t lused[2];
+  __shared__ uint32_t loff[PLHIP_MAX_ACCS];
+  uint64_t *lkeys = (uint64_t *)smem;
+  const uint32_t lslots = lcap + 2;
+  if (threadIdx.x == 0) {
+    uint32_t off = lslots * 8;
+    for (int a = 0; a < P.n_accs; a++) { loff[a] = off; off += lslots * 8; } // 8-byte cells keep ds_*_b64 aligned
+    lused[0] = lused[1] = 0;
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < lslots; i += blockDim.x) {
+    lkeys[i] = PLHIP_EMPTY_KEY;
+    for (int a = 0; a < P.n_accs; a++) {
+      if (P.accs[a].width == 8) ((uint64_t *)(smem + loff[a]))[i] = P.accs[a].init;
+      else ((uint32_t *)(smem + loff[a]))[i] = (uint32_t)P.accs[a].init;
+    }
+  }
+  __syncthreads();
+
+  uint64_t *gkeys = (uint64_t *)T.base;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
+  const int64_t r1 = (r0 + rows_per_wg < P.n_rows) ? r0 + rows_per_wg : P.n_rows;
+  uint32_t spilled = 0;
+  for (int64_t row = r0 + threadIdx.x; row < r1; row += blockDim.x) {
+    bool isnull;
+    const uint64_t key = row_packed_key(P, row, isnull);
+    const uint32_t ls = lds_slot(lkeys, lcap, lused, key, isnull);
+    if (ls != ~0u) {
+      for (int a = 0; a < P.n_accs; a++) {
+        AccSpec A = P.accs[a];
+        uint64_t operand;
+        if (acc_operand(P, A, row, operand)) { A.offset = loff[a]; acc_apply(smem, A, ls, operand); }
+      }
+    } else { // LDS table full along this probe sequence: fold the row straight into the HBM table
+      spilled++;
+      const uint64_t gs = gtable_slot(gkeys, T.cap, T.flags, key, false);
+      if (gs == ~0ull) continue;
+      for (int a = 0; a < P.n_accs; a++) {
+        const AccSpec &A = P.accs[a];
+        uint64_t operand;
+        if (acc_operand(P, A, row, operand)) acc_apply(T.base, A, gs, operand);
+      }
+    }
+  }
+  if (spilled) atomicAdd(&T.flags[FLAG_LDS_SPILL], spilled);
+  __syncthreads();
+
+  // merge: one HBM find-or-insert per occupied LDS slot, one global atomic per touched accumulator
+  for (uint32_t i = threadIdx.x; i < lslots; i += blockDim.x) {
+    const uint64_t key = lkeys[i];
+    bool occupied, isnull = false;
+    if (i < lcap) occupied = key != PLHIP_EMPTY_KEY;
+    else if (i == lcap) occupied = lused[0] != 0;
+    else { occupied = lused[1] != 0; isnull = true; }
+    if (!occupied) continue;
+    const uint64_t gs = gtable_slot(gkeys, T.cap, T.flags, i == lcap ? PLHIP_EMPTY_KEY : key, isnull);
+    if (gs == ~0ull) continue;
+    for (int a = 0; a < P.n_accs; a++) {
+      const AccSpec &A = P.accs[a];
+      const uint64_t part = (A.width == 8) ? ((uint64_t *)(smem + loff[a]))[i] : (uint64_t)((uint32_t *)(smem + loff[a]))[i];
+      if (part == A.init) continue; // identity: nothing to fold
+      acc_apply(T.base, A, gs, part);
+    }
+  }
+}
+
+static int g_num_cus = 0;
+static int num_cus() {
+  if (!g_num_cus) {
+    int dev = 0;
+    hipGetDevice(&dev);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cus = prop.multiProcessorCount;
+    if (g_num_cus <= 0) g_num_cus = 256;
+  }
+  return g_num_cus;
+}
+
+size_t lds_table_bytes(const Plan &p, uint32_t lcap) { return (size_t)(lcap + 2) * 8 * (1 + p.n_accs); }
+
+void launch_agg_lds(const Plan &p, TableRef t, uint32_t lcap, hipStream_t s) {
+  const size_t bytes = lds_table_bytes(p, lcap);
+  const int wg_per_cu = bytes <= 76 * 1024 ? 2 : 1;
+  int64_t max_wgs = (int64_t)num_cus() * wg_per_cu;
+  int64_t wgs = (p.n_rows + LDS_BLOCK * 4 - 1) / (LDS_BLOCK * 4); // at least 4 rows per thread
+  if (wgs < 1) wgs = 1;
+  if (wgs > max_wgs) wgs = max_wgs;
+  int64_t rows_per_wg = (p.n_rows + wgs - 1) / wgs;
+  rows_per_wg = (rows_per_wg + 63) / 64 * 64;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void *)k_agg_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_agg_lds, dim3((unsigned)wgs), dim3(LDS_BLOCK), bytes, s, p, t, lcap, rows_per_wg);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// compaction: occupied slots -> slot list (+ group count in flags[FLAG_NGROUPS])
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_compact(TableRef T, uint64_t *slots) {
+  const uint64_t *keys = (const uint64_t *)T.base;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint32_t has_null = T.flags[FLAG_NULL] ? 1u : 0u;
+  const int lane = threadIdx.x & 63;
+  for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < T.cap + 1; base += stride) {
+    const uint64_t i = base + threadIdx.x;
+    bool occ = false;
+    if (i < T.cap) occ = keys[i] != PLHIP_EMPTY_KEY;
+    else if (i == T.cap) occ = T.flags[FLAG_SENTINEL] != 0;
+    // one counter atomic per wave: ballot + popcount prefix
+    const unsigned long long m = __ballot(occ);
+    uint32_t wbase = 0;
+    if (m) {
+      if (lane == 0) wbase = atomicAdd(&T.flags[FLAG_NGROUPS], (uint32_t)__popcll(m));
+      wbase = __shfl(wbase, 0);
+      if (occ) slots[has_null + wbase + __popcll(m & ((1ull << lane) - 1))] = i;
+    }
+  }
+}
+
+__global__ void k_compact_finish(TableRef T, uint64_t *slots) {
+  if (T.flags[FLAG_NULL]) { slots[0] = T.cap + 1; T.flags[FLAG_NGROUPS] += 1; }
+}
+
+void launch_compact(const Plan &p, TableRef t, uint64_t *slots, hipStream_t s) {
+  (void)p;
+  uint64_t n = t.cap + 1;
+  int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(k_compact, dim3(grid), dim3(256), 0, s, t, slots);
+  hipLaunchKernelGGL(k_compact_finish, dim3(1), dim3(1), 0, s, t, slots);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// ordering support
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_gather_sort_keys(Plan P, TableRef T, const uint64_t *slots, uint64_t n,
+                                                          int first_acc, uint64_t *out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t s = slots[i];
+  if (first_acc >= 0) out[i] = ((const uint32_t *)(T.base + P.accs[first_acc].offset))[s];
+  else out[i] = ((const uint64_t *)T.base)[s];
+}
+
+void launch_gather_sort_keys(const Plan &p, TableRef t, const uint64_t *slots, uint64_t n, int by_first_acc,
+                             uint64_t *out_keys, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_gather_sort_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, t, slots, n,
+                     by_first_acc, out_keys);
+}
+
+// Output ordering only (maintain_order / sort_keys): a library radix sort of (u64 key, u64 slot) pairs.
+hipError_t sort_pairs_u64(uint64_t *keys, uint64_t *vals, uint64_t n, int end_bit, hipStream_t s) {
+  if (n < 2) return hipSuccess;
+  uint64_t *kout = nullptr, *vout = nullptr;
+  void *tmp = nullptr;
+  size_t tmp_bytes = 0;
+  hipError_t e = hipMalloc(&kout, n * 8);
+  if (e != hipSuccess) return e;
+  e = hipMalloc(&vout, n * 8);
+  if (e != hipSuccess) { hipFree(kout); return e; }
+  e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, kout, vals, vout, n, 0, end_bit, s);
+  if (e == hipSuccess) e = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8);
+  if (e == hipSuccess) e = rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, kout, vals, vout, n, 0, end_bit, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(keys, kout, n * 8, hipMemcpyDeviceToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(vals, vout, n * 8, hipMemcpyDeviceToDevice, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  hipFree(kout); hipFree(vout); hipFree(tmp);
+  return e;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// finalize: accumulators -> output columns
+// ---------------------------------------------------------------------------------------------------------
+DEVINL void store_by_dtype_int(uint8_t *out, uint32_t dtype, uint64_t i, uint64_t v) {
+  switch (dtype) {
+    case PLHIP_I8: case PLHIP_U8: out[i] = (uint8_t)v; break;
+    case PLHIP_I16: case PLHIP_U16: ((uint16_t *)out)[i] = (uint16_t)v; break;
+    case PLHIP_I32: case PLHIP_U32: case PLHIP_F32: ((uint32_t *)out)[i] = (uint32_t)v; break;
+    default: ((uint64_t *)out)[i] = v; break;
+  }
+}
+DEVINL void store_float(uint8_t *out, uint32_t dtype, uint64_t i, double v) {
+  if (dtype == PLHIP_F32) ((float *)out)[i] = (float)v;
+  else ((double *)out)[i] = v;
+}
+
+__global__ void __launch_bounds__(256) k_finalize(Plan P, TableRef T, const OutPlan *__restrict__ Op,
+                                                  const KeyGather *__restrict__ KG, const uint64_t *slots, uint64_t G) {
+  const OutPlan &O = *Op;
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; // a wave covers an aligned 64-group span
+  const bool live = i < G;
+  const uint64_t s = live ? slots[i] : 0;
+  const uint64_t packed = live ? ((const uint64_t *)T.base)[s] : 0;
+  for (int o = 0; o < O.n_outs; o++) {
+    const OutSpec &S = O.outs[o];
+    bool valid = live;
+    if (live) {
+      uint64_t acc = 0;
+      if (S.kind != OUT_KEY && S.acc >= 0) {
+        const AccSpec &A = P.accs[S.acc];
+        acc = A.width == 8 ? ((const uint64_t *)(T.base + A.offset))[s] : ((const uint32_t *)(T.base + A.offset))[s];
+      }
+      const uint32_t cnt_all = S.cnt_all >= 0 ? ((const uint32_t *)(T.base + P.accs[S.cnt_all].offset))[s] : 0;
+      const uint32_t cnt_valid = S.cnt_valid >= 0 ? ((const uint32_t *)(T.base + P.accs[S.cnt_valid].offset))[s] : cnt_all;
+      switch (S.kind) {
+        case OUT_KEY: {
+          if (KG->enabled) { // keys_sliced: take the original key column at the group's first row
+            const KeySpec &K = KG->okeys[S.acc];
+            const int64_t row = ((const uint32_t *)(T.base + P.accs[KG->first_acc].offset))[s];
+            valid = bit_valid(K.validity, K.boff, row);
+            store_by_dtype_int(S.values, K.dtype, i, valid ? key_denorm(load_key_norm(K.values, K.dtype, row), K.dtype) : 0);
+            break;
+          }
+          const KeySpec &K = P.keys[S.acc];
+          uint64_t norm;
+          if (P.single_key) {
+            valid = s != T.cap + 1;
+            norm = (s == T.cap) ? PLHIP_EMPTY_KEY : packed;
+          } else {
+            uint64_t code = K.bits >= 64 ? packed : ((packed >> K.shift) & ((1ull << K.bits) - 1));
+            if (K.nullable) { valid = code != 0; code -= 1; }
+            norm = code + K.minv;
+          }
+          store_by_dtype_int(S.values, K.dtype, i, valid ? key_denorm(norm, K.dtype) : 0);
+          break;
+        }
+        case OUT_SUM_INT: // wrapping sum in the output width (aggregations/mod.rs:622-651); never null
+          store_by_dtype_int(S.values, S.dtype, i, acc);
+          break;
+        case OUT_SUM_F64:
+          store_float(S.values, S.dtype, i, __longlong_as_double((long long)acc));
+          break;
+        case OUT_MEAN_INT: case OUT_MEAN_UINT: { // aggregations/mod.rs:941-991
+          valid = cnt_valid != 0;
+          const double sum = S.kind == OUT_MEAN_INT ? (double)(long long)acc : (double)acc;
+          store_float(S.values, S.dtype, i, valid ? sum / (double)cnt_valid : 0.0);
+          break;
+        }
+        case OUT_MEAN_F64: { // aggregations/mod.rs:701-742: f32 sums are f32 before the division
+          valid = cnt_valid != 0;
+          double sum = __longlong_as_double((long long)acc);
+          if (S.dtype == PLHIP_F32) sum = (double)(float)sum;
+          store_float(S.values, S.dtype, i, valid ? sum / (double)cnt_valid : 0.0);
+          break;
+        }
+        case OUT_MIN_INT:
+          valid = S.cnt_valid >= 0 ? cnt_valid != 0 : true;
+          store_by_dtype_int(S.values, S.dtype, i, valid ? acc : 0);
+          break;
+        case OUT_FMIN: case OUT_FMAX: {
+          // aggregations/mod.rs:459-620 with TakeExtremum :240-259: fold from T::MAX (min) / T::MIN (max)
+          // ignoring NaN, so +-inf and all-NaN groups clamp to the init; a 1-row group returns its value.
+          valid = cnt_valid != 0;
+          const bool is_min = S.kind == OUT_FMIN;
+          const double big = S.dtype == PLHIP_F32 ? 3.4028234663852886e38 : 1.7976931348623157e308;
+          double r = 0.0;
+          if (valid) {
+            const bool only_nan = is_min ? acc == ~0ull : acc == 0ull;
+            if (cnt_all == 1) r = only_nan ? __longlong_as_double(0x7ff8000000000000ll) : f64_from_ordered(acc);
+            else if (only_nan) r = is_min ? big : -big;
+            else {
+              r = f64_from_ordered(acc);
+              if (is_min && r > big) r = big;
+              if (!is_min && r < -big) r = -big;
+            }
+          }
+          store_float(S.values, S.dtype, i, r);
+          break;
+        }
+        case OUT_COUNT: ((uint32_t *)S.values)[i] = (uint32_t)acc; break;
+        case OUT_RAW_U64: ((uint64_t *)S.values)[i] = acc; break;
+        case OUT_RAW_U32_AS_U64: ((uint64_t *)S.values)[i] = acc; break;
+      }
+    }
+    if (S.validity) {
+      const unsigned long long m = __ballot(valid);
+      if ((threadIdx.x & 63) == 0 && (i & ~63ull) < G) ((uint64_t *)S.validity)[i >> 6] = m;
+    }
+  }
+}
+
+void launch_finalize(const Plan &p, TableRef t, const OutPlan *o, const KeyGather *kg, const uint64_t *slots,
+                     uint64_t n_groups, hipStream_t s) {
+  if (!n_groups) return;
+  hipLaunchKernelGGL(k_finalize, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, s, p, t, o, kg, slots, n_groups);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// dense ids for wide key tuples
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_rank_scatter(const uint64_t *slots, uint64_t n, uint32_t *rank) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) rank[slots[i]] = (uint32_t)i;
+}
+void launch_rank_scatter(const uint64_t *slots, uint64_t n, uint32_t *rank, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_rank_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, slots, n, rank);
+}
+
+__global__ void __launch_bounds__(256) k_encode_rows(Plan P, TableRef T, const uint32_t *rank, uint32_t *ids) {
+  uint64_t *keys = (uint64_t *)T.base;
+  const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < P.n_rows; row += gs) {
+    bool isnull;
+    const uint64_t key = row_packed_key(P, row, isnull);
+    const uint64_t slot = gtable_slot(keys, T.cap, T.flags, key, isnull); // every key is present: lookup only
+    ids[row] = slot == ~0ull ? 0u : rank[slot];
+  }
+}
+void launch_encode_rows(const Plan &p, TableRef t, const uint32_t *rank, uint32_t *ids, hipStream_t s) {
+  int64_t blocks = (p.n_rows + 255) / 256;
+  int grid = (int)(blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks));
+  hipLaunchKernelGGL(k_encode_rows, dim3(grid), dim3(256), 0, s, p, t, rank, ids);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// key range pre-pass (multi-key tuples)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_key_minmax(Plan P, uint64_t *minmax) {
+  const int k = blockIdx.y;
+  const KeySpec &K = P.keys[k];
+  uint64_t lo = ~0ull, hi = 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < P.n_rows; row += stride) {
+    if (!bit_valid(K.validity, K.boff, row)) continue;
+    const uint64_t v = load_key_norm(K.values, K.dtype, row);
+    lo = v < lo ? v : lo;
+    hi = v > hi ? v : hi;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const uint64_t l2 = __shfl_xor(lo, off), h2 = __shfl_xor(hi, off);
+    lo = l2 < lo ? l2 : lo;
+    hi = h2 > hi ? h2 : hi;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin((unsigned long long *)&minmax[2 * k], (unsigned long long)lo);
+    atomicMax((unsigned long long *)&minmax[2 * k + 1], (unsigned long long)hi);
+  }
+}
+
+void launch_key_minmax(const Plan &p, uint64_t *minmax, hipStream_t s) {
+  int64_t blocks = (p.n_rows + 1023) / 1024;
+  int grid = (int)(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks));
+  hipLaunchKernelGGL(k_key_minmax, dim3(grid, p.n_keys), dim3(256), 0, s, p, minmax);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// VecHash (crates/polars-core/src/hashing/vector_hasher.rs:78-139, 467-483)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_vec_hash(Plan P, uint64_t null_h, uint64_t *out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < P.n_rows; row += stride) {
+    const KeySpec &K0 = P.keys[0];
+    uint64_t h = bit_valid(K0.validity, K0.boff, row)
+                     ? folded_multiply(load_as_u64(K0.values, K0.dtype, row), PLHIP_MULTIPLE)
+                     : null_h;
+    for (int k = 1; k < P.n_keys; k++) {
+      const KeySpec &K = P.keys[k];
+      const uint64_t v = bit_valid(K.validity, K.boff, row) ? load_as_u64(K.values, K.dtype, row) : null_h;
+      h = folded_multiply(v ^ h, PLHIP_MULTIPLE);
+    }
+    out[row] = h;
+  }
+}
+
+void launch_vec_hash(const Plan &p, uint64_t null_hash, uint64_t *out, hipStream_t s) {
+  int64_t blocks = (p.n_rows + 255) / 256;
+  int grid = (int)(blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks));
+  hipLaunchKernelGGL(k_vec_hash, dim3(grid), dim3(256), 0, s, p, null_hash, out);
+}

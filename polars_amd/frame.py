@@ -1,0 +1,324 @@
+"""Host-side mirror of the reference's group-by API for the accelerated path.
+
+    df.group_by("id3", maintain_order=False).agg([col("v1").sum(), col("v3").mean()])
+    df.lazy().group_by("id3").agg(...).collect()
+
+mirrors py-polars `DataFrame.group_by(...).agg(...)` (py-polars/polars/dataframe/group_by.py:241-244, which
+itself is `self.df.lazy().group_by(by, maintain_order).agg(aggs).collect(no_optimization=True)`), and the
+eager Rust `GroupBy::{sum,mean,min,max,count}` helpers with their `{name}_{agg}` output names
+(crates/polars-core/src/frame/group_by/mod.rs:348-699, 889-909).  Only what the hash group-by hot path
+needs exists here: plain-column keys, and sum/mean/min/max/count of plain columns.  All compute happens in
+libplhip.so (HIP); nothing in this file computes an aggregate.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterable, Sequence
+
+import numpy as np
+
+from . import _ffi
+from .column import Column
+
+
+# ---------------------------------------------------------------------------------------------------
+# expressions: col("x").sum().alias("y"), count()
+# ---------------------------------------------------------------------------------------------------
+class Expr:
+    """A plain column, optionally with one aggregation and an alias (AggregationExpr,
+    crates/polars-lazy/src/physical_plan/expressions/aggregation.rs:19-33)."""
+
+    def __init__(self, column: str | None, agg: str | None = None, alias: str | None = None):
+        self.column, self.agg, self._alias = column, agg, alias
+
+    def _with(self, agg: str) -> "Expr":
+        if self.agg is not None:
+            raise _ffi.ComputeError(1, "nested aggregations are outside the accelerated path")
+        return Expr(self.column, agg, self._alias)
+
+    def sum(self) -> "Expr":
+        return self._with("sum")
+
+    def mean(self) -> "Expr":
+        return self._with("mean")
+
+    def min(self) -> "Expr":
+        return self._with("min")
+
+    def max(self) -> "Expr":
+        return self._with("max")
+
+    def count(self) -> "Expr":
+        return self._with("count")
+
+    def alias(self, name: str) -> "Expr":
+        return Expr(self.column, self.agg, name)
+
+    @property
+    def output_name(self) -> str:
+        # lazy aggregations keep the input column name unless aliased (aggregation.rs:51-52)
+        return self._alias or (self.column if self.column is not None else "count")
+
+
+def col(name: str) -> Expr:
+    return Expr(name)
+
+
+def count() -> Expr:
+    """pl.count(): group length including nulls (CountExpr, expressions/count.rs:28-37)."""
+    return Expr(None, "count", "count")
+
+
+def sum_(name: str) -> Expr:  # exported as polars_amd.sum (mirrors pl.sum)
+    return col(name).sum()
+
+
+def mean_(name: str) -> Expr:
+    return col(name).mean()
+
+
+def min_(name: str) -> Expr:
+    return col(name).min()
+
+
+def max_(name: str) -> Expr:
+    return col(name).max()
+
+
+# ---------------------------------------------------------------------------------------------------
+# frames
+# ---------------------------------------------------------------------------------------------------
+class DataFrame:
+    def __init__(self, data=None):
+        self._cols: dict[str, Column] = {}
+        if data is None:
+            data = {}
+        if isinstance(data, dict):
+            for name, v in data.items():
+                self._add(v if isinstance(v, Column) else self._make(name, v), name)
+        else:
+            for c in data:
+                self._add(c, c.name)
+
+    @staticmethod
+    def _make(name, v) -> Column:
+        if isinstance(v, tuple):  # (values, valid_mask)
+            return Column(name, v[0], v[1])
+        if isinstance(v, list):
+            if any(x is None for x in v):
+                mask = np.array([x is not None for x in v])
+                vals = np.array([0 if x is None else x for x in v])
+                return Column(name, vals, mask)
+            v = np.array(v)
+        return Column(name, v)
+
+    def _add(self, c: Column, name: str):
+        if name in self._cols:
+            raise _ffi.PlHipError(6, f"duplicate column {name!r}")
+        if self._cols and len(c) != self.height:
+            raise _ffi.ShapeMismatch(2, f"column {name!r} has {len(c)} rows, frame has {self.height}")
+        c.name = name
+        self._cols[name] = c
+
+    @property
+    def columns(self) -> list[str]:
+        return list(self._cols)
+
+    @property
+    def height(self) -> int:
+        return len(next(iter(self._cols.values()))) if self._cols else 0
+
+    @property
+    def shape(self) -> tuple[int, int]:
+        return (self.height, len(self._cols))
+
+    def __getitem__(self, name: str) -> Column:
+        return self._cols[name]
+
+    def get_column(self, name: str) -> Column:
+        if name not in self._cols:
+            raise _ffi.PlHipError(6, f"column {name!r} not found")
+        return self._cols[name]
+
+    def to_dict(self) -> dict[str, list]:
+        return {n: c.to_list() for n, c in self._cols.items()}
+
+    def rows(self) -> list[tuple]:
+        cols = [c.to_list() for c in self._cols.values()]
+        return list(zip(*cols))
+
+    def lazy(self) -> "LazyFrame":
+        return LazyFrame(self)
+
+    def group_by(self, *by, maintain_order: bool = False) -> "GroupBy":
+        return GroupBy(self, _flatten(by), maintain_order)
+
+    def group_by_stable(self, *by) -> "GroupBy":
+        """DataFrame::group_by_stable (group_by/mod.rs:122-129)."""
+        return GroupBy(self, _flatten(by), True)
+
+    def __repr__(self) -> str:
+        return f"DataFrame(shape={self.shape}, columns={self.columns})"
+
+
+def _flatten(by) -> list[str]:
+    out: list[str] = []
+    for b in by:
+        if isinstance(b, (list, tuple)):
+            out.extend(_flatten(b))
+        elif isinstance(b, Expr):
+            if b.agg is not None:
+                raise _ffi.ComputeError(1, "aggregations are not valid group-by keys")
+            out.append(b.column)
+        else:
+            out.append(b)
+    return out
+
+
+class GroupBy:
+    """Mirrors py-polars GroupBy / Rust GroupBy{df, selected_keys, groups, selected_agg}
+    (group_by/mod.rs:182-189)."""
+
+    def __init__(self, df: DataFrame, by: list[str], maintain_order: bool, selection: list[str] | None = None):
+        self.df, self.by, self.maintain_order, self.selection = df, by, maintain_order, selection
+
+    def select(self, names: Iterable[str]) -> "GroupBy":
+        return GroupBy(self.df, self.by, self.maintain_order, list(names))
+
+    def agg(self, *aggs) -> DataFrame:
+        exprs: list[Expr] = []
+        for a in aggs:
+            exprs.extend(a if isinstance(a, (list, tuple)) else [a])
+        return _execute(self.df, self.by, exprs, self.maintain_order)
+
+    def _eager(self, kind: str) -> DataFrame:
+        # GroupBy::sum()/mean()/... aggregate every non-key column (or the selection) and name the
+        # outputs `{name}_{agg}` (fmt_group_by_column, group_by/mod.rs:889-909)
+        names = self.selection if self.selection is not None else [c for c in self.df.columns if c not in self.by]
+        return _execute(self.df, self.by, [Expr(n, kind, f"{n}_{kind}") for n in names], self.maintain_order)
+
+    def sum(self) -> DataFrame:
+        return self._eager("sum")
+
+    def mean(self) -> DataFrame:
+        return self._eager("mean")
+
+    def min(self) -> DataFrame:
+        return self._eager("min")
+
+    def max(self) -> DataFrame:
+        return self._eager("max")
+
+    def count(self) -> DataFrame:
+        return self._eager("count")
+
+
+class LazyFrame:
+    def __init__(self, df: DataFrame):
+        self._df = df
+
+    def group_by(self, *by, maintain_order: bool = False) -> "LazyGroupBy":
+        return LazyGroupBy(self._df, _flatten(by), maintain_order)
+
+    def collect(self) -> DataFrame:
+        return self._df
+
+
+class LazyGroupBy:
+    def __init__(self, df, by, maintain_order):
+        self._df, self._by, self._mo = df, by, maintain_order
+
+    def agg(self, *aggs) -> "_LazyAgg":
+        exprs: list[Expr] = []
+        for a in aggs:
+            exprs.extend(a if isinstance(a, (list, tuple)) else [a])
+        return _LazyAgg(self._df, self._by, exprs, self._mo)
+
+
+class _LazyAgg:
+    def __init__(self, df, by, exprs, mo):
+        self._args = (df, by, exprs, mo)
+
+    def collect(self) -> DataFrame:
+        return _execute(*self._args)
+
+
+# ---------------------------------------------------------------------------------------------------
+# the one place that calls the C ABI
+# ---------------------------------------------------------------------------------------------------
+def set_strategy(name: str) -> None:
+    """'auto' | 'global' | 'lds' | 'partitioned' (POLARS_FORCE_PARTITION / POLARS_NO_PARTITION analogue)."""
+    _ffi.check(_ffi.lib().plhip_set_strategy(_ffi.STRATEGIES[name]))
+
+
+def last_strategy() -> str:
+    return _ffi.lib().plhip_last_strategy().decode()
+
+
+def last_kernel_ms() -> tuple[float, float, str]:
+    t, d, k = C.c_float(), C.c_float(), C.c_char_p()
+    _ffi.check(_ffi.lib().plhip_last_kernel_ms(C.byref(t), C.byref(d), C.byref(k)))
+    return t.value, d.value, (k.value or b"").decode()
+
+
+def group_by_agg_raw(keys: Sequence[Column], values: Sequence[Column], aggs: Sequence[tuple[int, int]],
+                     flags: int = 0):
+    """Thin call of plhip_group_by_agg.  Returns (handle, [ColumnStruct...]); the caller must
+    plhip_result_free(handle).  Used by bench.py (device-resident outputs) and by _execute."""
+    L = _ffi.lib()
+    karr = (_ffi.ColumnStruct * max(1, len(keys)))(*[k.struct() for k in keys])
+    varr = (_ffi.ColumnStruct * max(1, len(values)))(*[v.struct() for v in values])
+    aarr = (_ffi.AggStruct * max(1, len(aggs)))(*[_ffi.AggStruct(c, k) for c, k in aggs])
+    handle = C.c_void_p()
+    _ffi.check(L.plhip_group_by_agg(karr, len(keys), varr, len(values), aarr, len(aggs), flags, C.byref(handle)))
+    cols = []
+    for i in range(L.plhip_result_num_columns(handle)):
+        cs = _ffi.ColumnStruct()
+        _ffi.check(L.plhip_result_column(handle, i, C.byref(cs)))
+        cols.append(cs)
+    return handle, cols
+
+
+def _host_column(name: str, cs: _ffi.ColumnStruct) -> Column:
+    n = cs.length
+    dt = _ffi.code_np_dtype(cs.dtype)
+    if n == 0:
+        return Column(name, np.empty(0, dtype=dt))
+    vals = np.ctypeslib.as_array(C.cast(cs.values, C.POINTER(C.c_uint8)), shape=(n * dt.itemsize,)).view(dt).copy()
+    validity = None
+    if cs.validity:
+        nb = (n + 7) // 8
+        validity = np.ctypeslib.as_array(C.cast(cs.validity, C.POINTER(C.c_uint8)), shape=(nb,)).copy()
+    return Column(name, vals, validity, packed=True)
+
+
+def _execute(df: DataFrame, by: list[str], exprs: list[Expr], maintain_order: bool, extra_flags: int = 0) -> DataFrame:
+    """group_by_helper (crates/polars-lazy/src/physical_plan/executors/group_by.rs:57-95): keys then aggs."""
+    if not by:
+        raise _ffi.ComputeError(1, "at least one key is required in a group_by operation")
+    keys = [df.get_column(n) for n in by]
+    vals: list[Column] = []
+    index: dict[str, int] = {}
+    aggs: list[tuple[int, int]] = []
+    names = list(by)
+    for e in exprs:
+        if e.agg is None:
+            raise _ffi.ComputeError(1, "only col(x).sum/mean/min/max/count and count() run on the accelerated path")
+        if e.column is None:
+            aggs.append((-1, _ffi.AGG_COUNT))
+        else:
+            c = df.get_column(e.column)
+            if e.column not in index:
+                index[e.column] = len(vals)
+                vals.append(c)
+            aggs.append((index[e.column], _ffi.AGG_NAMES[e.agg]))
+        if e.output_name in names:
+            raise _ffi.PlHipError(6, f"column with name {e.output_name!r} has more than one occurrence")  # DuplicateError
+        names.append(e.output_name)
+    flags = (_ffi.FLAG_MAINTAIN_ORDER if maintain_order else 0) | extra_flags
+    handle, cols = group_by_agg_raw(keys, vals, aggs, flags)
+    try:
+        out = DataFrame([_host_column(nm, cs) for nm, cs in zip(names, cols)])
+    finally:
+        _ffi.lib().plhip_result_free(handle)
+    return out

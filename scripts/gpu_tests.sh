@@ -1,0 +1,7 @@
+#!/bin/bash
+# Runs the GPU parity tests on the box; output goes to gpurun_out/.
+mkdir -p gpurun_out
+timeout -k 10 ${1:-600} python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread ${@:2} > gpurun_out/pytest_gpu.log 2>&1
+rc=$?
+tail -40 gpurun_out/pytest_gpu.log
+exit $rc

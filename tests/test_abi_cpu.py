@@ -1,0 +1,63 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/plhip.h declares, and
+refuses to compute without a GPU (there is no CPU fallback)."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from polars_amd import _ffi
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _declared_symbols():
+    text = (ROOT / "include" / "plhip.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(plhip_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_is_built():
+    assert _ffi.LIB_PATH.exists(), "build with __graft_entry__.build()"
+
+
+def test_exports_every_declared_symbol():
+    lib = _ffi.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 18
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in plhip.h but not exported"
+    assert sorted(_ffi.EXPORTED_SYMBOLS) == declared
+
+
+def test_abi_version():
+    assert _ffi.lib().plhip_abi_version() == 1
+
+
+def test_fails_loudly_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from polars_amd import DataFrame, col
+
+    df = DataFrame({"k": np.arange(10, dtype=np.int32), "v": np.ones(10)})
+    with pytest.raises(_ffi.PlHipError) as ei:
+        df.group_by("k").agg(col("v").sum())
+    assert ei.value.status == 7  # PLHIP_ERR_NO_DEVICE
+
+
+def test_argument_errors_match_reference_kinds():
+    # group_by/mod.rs:59-62: zero keys -> ComputeError, raised before any device work
+    L = _ffi.lib()
+    out = C.c_void_p()
+    rc = L.plhip_group_by_agg(None, 0, None, 0, None, 0, 0, C.byref(out))
+    assert rc == 1 and b"at least one key" in L.plhip_last_error()
+    # group_by/mod.rs:67-71: key length mismatch -> ShapeMismatch
+    a = np.zeros(4, dtype=np.int32)
+    b = np.zeros(5, dtype=np.int32)
+    keys = (_ffi.ColumnStruct * 2)(
+        _ffi.ColumnStruct(a.ctypes.data, None, 0, 4, _ffi.I32, 0), _ffi.ColumnStruct(b.ctypes.data, None, 0, 5, _ffi.I32, 0))
+    rc = L.plhip_group_by_agg(keys, 2, None, 0, None, 0, 0, C.byref(out))
+    assert rc == 2

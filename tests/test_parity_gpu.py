@@ -1,0 +1,283 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the reference's own
+known answers.  Integers, keys, counts and validity bit-exact after a canonical key sort; f64 sum/mean
+within 1e-12 relative (the north star's tolerance); f32 within 1e-5 (the reference folds f32 in f32)."""
+import numpy as np
+import pytest
+
+import polars_amd as pa
+from polars_amd import _ffi
+from polars_amd.column import Column
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+KA = util.load_known_answers()
+STRATEGIES = ["auto", "global", "lds", "partitioned"]
+
+
+@pytest.fixture(autouse=True)
+def _reset_strategy():
+    yield
+    pa.set_strategy("auto")
+
+
+def run_product(keys, values, aggs, maintain_order=False, strategy="auto"):
+    pa.set_strategy(strategy)
+    # value columns may share a name with a key column (reference tests do that): build a frame that keeps both
+    cols = {f"k{j}": k for j, k in enumerate(keys)}
+    cols.update({f"v{j}": v for j, v in enumerate(values)})
+    df = pa.DataFrame({n: Column(n, c.values, c.valid_mask()) for n, c in cols.items()})
+    exprs = []
+    for i, (ci, kind) in enumerate(aggs):
+        e = pa.count() if kind == "count" else getattr(pa.col(f"v{ci}"), kind)()
+        exprs.append(e.alias(f"agg{i}"))
+    return df.group_by([f"k{j}" for j in range(len(keys))], maintain_order=maintain_order).agg(exprs)
+
+
+@pytest.mark.parametrize("strategy", STRATEGIES)
+@pytest.mark.parametrize("case", KA["group_by"], ids=lambda c: c["name"])
+def test_reference_known_answers(case, strategy):
+    keys = [util.make_column(k) for k in case["keys"]]
+    values = [util.make_column(v) for v in case["values"]]
+    out = run_product(keys, values, [tuple(a) for a in case["aggs"]], case["maintain_order"], strategy)
+    cols = [out[c].to_list() for c in out.columns]
+    dts = [_ffi.DTYPE_NAMES[out[c].dtype] for c in out.columns]
+    util.check_known_answer(case, cols, dts)
+
+
+@pytest.mark.parametrize("case", KA["hash"], ids=lambda c: c["name"])
+def test_hash_known_answers(case):
+    import ctypes as C
+
+    keys = [util.make_column(k) for k in case["keys"]]
+    out = np.empty(len(keys[0]), dtype=np.uint64)
+    arr = (_ffi.ColumnStruct * len(keys))(*[k.struct() for k in keys])
+    _ffi.check(_ffi.lib().plhip_vec_hash(arr, len(keys), case["null_hash"], out.ctypes.data, _ffi.HOST))
+    assert out.tolist() == case["expected"]
+
+
+# ---------------------------------------------------------------------------------------------------
+# randomised parity against the oracle
+# ---------------------------------------------------------------------------------------------------
+INT_DT = [np.int8, np.int16, np.int32, np.int64, np.uint8, np.uint16, np.uint32, np.uint64]
+ALL_DT = INT_DT + [np.float32, np.float64]
+
+
+def rand_col(rng, name, dt, n, card=None, null_frac=0.0, nan_frac=0.0, lo=None, hi=None):
+    dt = np.dtype(dt)
+    if dt.kind == "f":
+        if card:
+            pool = np.round(rng.uniform(-100, 100, card), 3).astype(dt)
+            v = pool[rng.integers(0, card, n)]
+        else:
+            v = np.round(rng.uniform(0, 100, n), 6).astype(dt)
+        if nan_frac:
+            v[rng.random(n) < nan_frac] = np.nan
+    else:
+        info = np.iinfo(dt)
+        a = info.min if lo is None else lo
+        b = info.max if hi is None else hi
+        if card:
+            pool = rng.integers(a, b, card, dtype=dt, endpoint=True)
+            v = pool[rng.integers(0, card, n)]
+        else:
+            v = rng.integers(a, b, n, dtype=dt, endpoint=True)
+    mask = None
+    if null_frac:
+        mask = rng.random(n) >= null_frac
+    return Column(name, v, mask)
+
+
+def check_parity(oracle, keys, values, aggs, strategy="auto", maintain_order=False, what=""):
+    want, _ = oracle.group_by_agg(keys, values, aggs, maintain_order=maintain_order)
+    got = run_product(keys, values, aggs, maintain_order, strategy)
+    g, w = util.frame_to_np(got), util.oracle_to_np(want)
+    if maintain_order:  # row order itself is part of the contract
+        for (gv, _), (wv, _) in zip(g[:len(keys)], w[:len(keys)]):
+            assert np.array_equal(util._bits(gv), util._bits(wv)), f"{what}: stable group order differs"
+    util.assert_frames_match(g, w, len(keys), what=what)
+    return got
+
+
+ALL_AGGS = ["sum", "mean", "min", "max", "count"]
+
+
+@pytest.mark.parametrize("strategy", STRATEGIES)
+@pytest.mark.parametrize("kdt", ALL_DT, ids=lambda d: np.dtype(d).name)
+def test_single_key_dtypes(oracle, kdt, strategy):
+    rng = np.random.default_rng(hash(np.dtype(kdt).name) % 1000)
+    n = 20000
+    keys = [rand_col(rng, "k", kdt, n, card=300, null_frac=0.05)]
+    values = [rand_col(rng, "a", np.int32, n, lo=-1000, hi=1000), rand_col(rng, "b", np.float64, n, null_frac=0.1)]
+    aggs = [(0, a) for a in ALL_AGGS] + [(1, a) for a in ALL_AGGS]
+    check_parity(oracle, keys, values, aggs, strategy, what=f"key {np.dtype(kdt).name}")
+
+
+@pytest.mark.parametrize("strategy", STRATEGIES)
+@pytest.mark.parametrize("vdt", ALL_DT, ids=lambda d: np.dtype(d).name)
+@pytest.mark.parametrize("nulls", [0.0, 0.3])
+def test_value_dtypes(oracle, vdt, nulls, strategy):
+    rng = np.random.default_rng(7)
+    n = 30000
+    keys = [rand_col(rng, "k", np.int32, n, card=50)]
+    dt = np.dtype(vdt)
+    if dt.kind == "f":
+        v = rand_col(rng, "v", vdt, n, null_frac=nulls, nan_frac=0.02)
+    elif dt.itemsize == 8:  # keep |sum| < 2^53 so that the f64 fold of the reference is order independent
+        v = rand_col(rng, "v", vdt, n, null_frac=nulls, lo=0 if dt.kind == "u" else -(1 << 40), hi=1 << 40)
+    else:
+        v = rand_col(rng, "v", vdt, n, null_frac=nulls)
+    check_parity(oracle, keys, [v], [(0, a) for a in ALL_AGGS], strategy, what=f"value {dt.name} nulls={nulls}")
+
+
+@pytest.mark.parametrize("strategy", STRATEGIES)
+def test_wrapping_sums(oracle, strategy):
+    # i32/u32/i64/u64 sums wrap in their own type (aggregations/mod.rs:622-651, release build)
+    rng = np.random.default_rng(3)
+    n = 5000
+    keys = [rand_col(rng, "k", np.uint32, n, card=7)]
+    values = [rand_col(rng, f"v{i}", dt, n) for i, dt in enumerate([np.int32, np.uint32, np.int64, np.uint64])]
+    check_parity(oracle, keys, values, [(i, "sum") for i in range(4)], strategy, what="wrapping")
+
+
+@pytest.mark.parametrize("strategy", STRATEGIES)
+def test_multi_key(oracle, strategy):
+    rng = np.random.default_rng(11)
+    n = 50000
+    keys = [rand_col(rng, "id1", np.uint32, n, lo=1, hi=100), rand_col(rng, "id2", np.int64, n, lo=-50, hi=50, null_frac=0.05),
+            rand_col(rng, "id3", np.int16, n, card=20), rand_col(rng, "f", np.float64, n, card=5, null_frac=0.1)]
+    values = [rand_col(rng, "v1", np.int64, n, lo=-1000, hi=1000), rand_col(rng, "v3", np.float64, n)]
+    aggs = [(0, "sum"), (0, "min"), (0, "max"), (1, "sum"), (1, "mean"), (0, "count")]
+    check_parity(oracle, keys, values, aggs, strategy, what="multi-key")
+
+
+@pytest.mark.parametrize("strategy", STRATEGIES)
+@pytest.mark.parametrize("mo", [False, True])
+def test_maintain_order(oracle, strategy, mo):
+    rng = np.random.default_rng(5)
+    n = 40000
+    keys = [rand_col(rng, "k", np.int64, n, card=1000, null_frac=0.01)]
+    values = [rand_col(rng, "v", np.int32, n, lo=0, hi=100)]
+    check_parity(oracle, keys, values, [(0, "sum"), (0, "count")], strategy, maintain_order=mo, what="stable")
+
+
+@pytest.mark.parametrize("strategy", STRATEGIES)
+def test_edge_keys(oracle, strategy):
+    # the table's empty sentinel as a real key, 0, extremes, -0.0 vs +0.0 (distinct groups: bit pattern)
+    k = np.array([0xFFFFFFFFFFFFFFFF, 0, 1, 0xFFFFFFFFFFFFFFFF, 0x7FFFFFFFFFFFFFFF, 0, 0x8000000000000000] * 30, dtype=np.uint64)
+    v = np.arange(len(k), dtype=np.int64)
+    check_parity(oracle, [Column("k", k)], [Column("v", v)], [(0, "sum"), (0, "count"), (0, "min")], strategy, what="sentinel")
+    f = np.array([0.0, -0.0, np.nan, 1.5, -0.0, np.nan, np.inf, -np.inf] * 10, dtype=np.float64)
+    v = np.arange(len(f), dtype=np.int32)
+    check_parity(oracle, [Column("f", f)], [Column("v", v)], [(0, "sum"), (0, "count")], strategy, what="float keys")
+    ki = np.array([-(2 ** 63), 2 ** 63 - 1, -1, 0] * 25, dtype=np.int64)
+    check_parity(oracle, [Column("k", ki, np.arange(100) % 7 != 0)], [Column("v", np.ones(100, np.float32))],
+                 [(0, "sum"), (0, "mean")], strategy, what="i64 extremes + nulls")
+
+
+@pytest.mark.parametrize("strategy", STRATEGIES)
+def test_float_extremum_rules(oracle, strategy):
+    # NaN ignored; +-inf and all-NaN groups clamp to the fold's init; 1-row groups return their value;
+    # all-null -> null (aggregations/mod.rs:459-620)
+    inf, nan = np.inf, np.nan
+    k = np.array([0, 0, 1, 1, 2, 3, 4, 4, 5, 5, 6, 7, 7, 8, 8, 8], dtype=np.int32)
+    v = np.array([nan, nan, inf, inf, nan, inf, -inf, -inf, 1.0, nan, -inf, 2.0, 3.0, nan, 5.0, nan])
+    m = np.ones(len(k), bool)
+    m[[11, 12]] = False  # group 7 all null
+    for vdt in (np.float64, np.float32):
+        cols = [Column("v", v.astype(vdt)), Column("vn", v.astype(vdt), m)]
+        check_parity(oracle, [Column("k", k)], cols, [(0, "min"), (0, "max"), (1, "min"), (1, "max"), (1, "mean"), (1, "sum")],
+                     strategy, what=f"extremum {np.dtype(vdt).name}")
+
+
+@pytest.mark.parametrize("strategy", STRATEGIES)
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 1000, 1025])
+def test_tiny_and_ragged_sizes(oracle, strategy, n):
+    rng = np.random.default_rng(n)
+    keys = [rand_col(rng, "k", np.int32, n, lo=0, hi=9)]
+    values = [rand_col(rng, "v", np.float64, n, null_frac=0.2 if n else 0.0)]
+    check_parity(oracle, keys, values, [(0, a) for a in ALL_AGGS], strategy, what=f"n={n}")
+
+
+@pytest.mark.parametrize("strategy", STRATEGIES)
+def test_arrow_offsets(oracle, strategy):
+    # a sliced Arrow array: values/validity offset that is not byte aligned
+    rng = np.random.default_rng(9)
+    n, off = 5000, 13
+    kbuf = rng.integers(0, 40, n + off + 5).astype(np.int32)
+    vbuf = rng.integers(-100, 100, n + off + 5).astype(np.int64)
+    vmask = rng.random(n + off + 5) > 0.25
+    kmask = rng.random(n + off + 5) > 0.1
+    keys = [Column("k", kbuf, kmask, offset=off, length=n)]
+    values = [Column("v", vbuf, vmask, offset=off, length=n)]
+    want, _ = oracle.group_by_agg(keys, values, [(0, a) for a in ALL_AGGS])
+    pa.set_strategy(strategy)
+    handle, cols = pa.group_by_agg_raw(keys, values, [(0, _ffi.AGG_NAMES[a]) for a in ALL_AGGS], 0)
+    try:
+        from polars_amd.frame import _host_column
+        got = [_host_column(str(i), cs) for i, cs in enumerate(cols)]
+        g = [(c.to_numpy(), c.valid_mask()) for c in got]
+    finally:
+        _ffi.lib().plhip_result_free(handle)
+    util.assert_frames_match(g, util.oracle_to_np(want), 1, what="offsets")
+
+
+@pytest.mark.parametrize("strategy", STRATEGIES)
+@pytest.mark.parametrize("card", [3, 2000, 100000, None])
+def test_cardinalities(oracle, strategy, card):
+    # from a handful of hot groups to all-unique keys
+    rng = np.random.default_rng(17)
+    n = 300000
+    if card is None:
+        k = rng.permutation(n).astype(np.int64) * 7919
+        keys = [Column("k", k)]
+    else:
+        keys = [rand_col(rng, "k", np.int64, n, card=card)]
+    values = [rand_col(rng, "v1", np.int32, n, lo=1, hi=5), rand_col(rng, "v3", np.float64, n)]
+    check_parity(oracle, keys, values, [(0, "sum"), (1, "mean"), (1, "sum"), (0, "count"), (1, "max")], strategy, what=f"card={card}")
+
+
+@pytest.mark.parametrize("strategy", STRATEGIES)
+def test_skewed_keys(oracle, strategy):
+    rng = np.random.default_rng(23)
+    n = 400000
+    z = rng.zipf(1.3, n).astype(np.int64)  # heavy hitters + a long tail
+    keys = [Column("k", z)]
+    values = [rand_col(rng, "v", np.float64, n), rand_col(rng, "w", np.int64, n, lo=-5, hi=5)]
+    check_parity(oracle, keys, values, [(0, "sum"), (0, "mean"), (1, "sum"), (1, "min"), (1, "max"), (0, "count")], strategy, what="zipf")
+
+
+def test_device_resident_inputs(oracle):
+    import torch
+
+    rng = np.random.default_rng(29)
+    n = 100000
+    k = rng.integers(0, 500, n).astype(np.int32)
+    v = rng.uniform(0, 100, n)
+    m = rng.random(n) > 0.05
+    keys_h, vals_h = [Column("k", k)], [Column("v", v, m)]
+    want, _ = oracle.group_by_agg(keys_h, vals_h, [(0, "sum"), (0, "mean"), (0, "count")])
+    dk = torch.from_numpy(k).cuda()
+    dv = torch.from_numpy(v).cuda()
+    dm = torch.from_numpy(pa.column.pack_validity(m)).cuda()
+    df = pa.DataFrame([Column("k", dk), Column("v", dv, dm, packed=True)])
+    got = df.group_by("k").agg(pa.col("v").sum().alias("s"), pa.col("v").mean().alias("m"), pa.count())
+    util.assert_frames_match(util.frame_to_np(got), util.oracle_to_np(want), 1, what="device inputs")
+
+
+def test_vec_hash_parity(oracle):
+    rng = np.random.default_rng(31)
+    n = 10000
+    keys = [rand_col(rng, "a", np.int32, n, null_frac=0.1), rand_col(rng, "b", np.float64, n),
+            rand_col(rng, "c", np.int8, n, null_frac=0.2), rand_col(rng, "d", np.uint64, n)]
+    null_h = 988796329533502010
+    want = oracle.vec_hash(keys, null_h)
+    out = np.empty(n, dtype=np.uint64)
+    arr = (_ffi.ColumnStruct * len(keys))(*[k.struct() for k in keys])
+    _ffi.check(_ffi.lib().plhip_vec_hash(arr, len(keys), null_h, out.ctypes.data, _ffi.HOST))
+    assert np.array_equal(out, want)
+
+
+def test_error_kinds():
+    with pytest.raises(pa.ComputeError):
+        pa.DataFrame({"a": np.zeros(3, np.int32)}).group_by().agg(pa.count())

@@ -94,3 +94,63 @@ def check_known_answer(case, columns: list[list], dtypes: list[str] | None = Non
         assert_rows_equal([(x,) for x in got], [(x,) for x in exp[0]], rel, case["name"])
     else:
         raise AssertionError(mode)
+
+
+# ---------------------------------------------------------------------------------------------------
+# numpy-level comparison for large frames
+# ---------------------------------------------------------------------------------------------------
+def _bits(v: np.ndarray) -> np.ndarray:
+    if v.dtype.kind == "f":
+        return v.view(np.uint32 if v.dtype.itemsize == 4 else np.uint64)
+    return v
+
+
+def canonical_order(key_cols) -> np.ndarray:
+    """Permutation that sorts rows by the key tuple (nulls first, floats by bit pattern)."""
+    ks = []
+    for v, m in reversed(list(key_cols)):
+        b = _bits(v)
+        if m is not None:
+            b = np.where(m, b, 0)
+            ks.append(b)
+            ks.append(m.astype(np.uint8))
+        else:
+            ks.append(b)
+    return np.lexsort(ks)
+
+
+def assert_frames_match(got, want, n_keys: int, rtol_f64=1e-12, rtol_f32=1e-5, what=""):
+    """got / want: lists of (values ndarray, valid mask or None).  Rows are compared after the canonical
+    sort on the keys.  Integers, counts, keys and validity must be bit-exact; floats within rtol."""
+    assert len(got) == len(want), f"{what}: {len(got)} columns vs {len(want)}"
+    ng, nw = len(got[0][0]), len(want[0][0])
+    assert ng == nw, f"{what}: {ng} groups, expected {nw}"
+    og, ow = canonical_order(got[:n_keys]), canonical_order(want[:n_keys])
+    for j, ((gv, gm), (wv, wm)) in enumerate(zip(got, want)):
+        assert gv.dtype == wv.dtype, f"{what}: column {j} dtype {gv.dtype} != {wv.dtype}"
+        gv, wv = gv[og], wv[ow]
+        gm = np.ones(ng, bool) if gm is None else gm[og]
+        wm = np.ones(nw, bool) if wm is None else wm[ow]
+        assert np.array_equal(gm, wm), f"{what}: column {j} validity differs at {np.flatnonzero(gm != wm)[:5]}"
+        a, b = gv[gm], wv[wm]
+        if gv.dtype.kind == "f" and j >= n_keys:
+            rtol = rtol_f32 if gv.dtype.itemsize == 4 else rtol_f64
+            nan_a, nan_b = np.isnan(a), np.isnan(b)
+            assert np.array_equal(nan_a, nan_b), f"{what}: column {j} NaN pattern differs"
+            a, b = a[~nan_a].astype(np.float64), b[~nan_b].astype(np.float64)
+            ok = (a == b) | (np.abs(a - b) <= rtol * np.maximum(np.abs(a), np.abs(b)))
+            assert ok.all(), (f"{what}: column {j}: {np.count_nonzero(~ok)} values beyond rtol={rtol}; first "
+                              f"{a[~ok][:3]} vs {b[~ok][:3]}")
+        else:
+            assert np.array_equal(_bits(a), _bits(b)), (
+                f"{what}: column {j} differs at {np.flatnonzero(_bits(a) != _bits(b))[:5]}: "
+                f"{a[_bits(a) != _bits(b)][:3]} vs {b[_bits(a) != _bits(b)][:3]}")
+
+
+def frame_to_np(df):
+    """polars_amd.DataFrame -> list of (values, valid mask or None)."""
+    return [(df[c].to_numpy(), df[c].valid_mask()) for c in df.columns]
+
+
+def oracle_to_np(out):
+    return [(v, None if m.all() else m) for _, v, m in out]
