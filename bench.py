@@ -1,0 +1,187 @@
+"""bench.py — db-benchmark-shaped hash group-by on MI355X: rows/s + fraction of the HBM roofline.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload q3|q1|q5|c3] [--rows R]
+
+A "step" is one pass of the hot path (plhip_group_by_agg through the C ABI) over one batch of synthetic rows
+that is already resident in HBM.  Default workload = BASELINE.json configs[1]: db-benchmark q3,
+sum(v1), mean(v3) by id3, 1e7 rows, 1e5 groups, one MI355X.  For N > 1 every rank holds its own 1e7-row shard
+(weak scaling); partial aggregates are exchanged with one all-to-all (RCCL) and merged on the owner rank.
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+WORKLOADS = {
+    # name: (keys, value columns, aggs [(value idx, kind)], wide dtypes, algorithmic bytes per row, out bytes per group)
+    "q1": (["id1"], ["v1"], [(0, "sum")], False),
+    "q3": (["id3"], ["v1", "v3"], [(0, "sum"), (1, "mean")], False),
+    "q5": (["id6"], ["v1", "v2", "v3"], [(0, "sum"), (1, "sum"), (2, "sum")], False),
+    "c3": (["id1", "id2", "id3"], ["v1", "v3"], [(0, "sum"), (0, "min"), (0, "max"), (1, "sum"), (1, "mean"), (0, "count")], True),
+}
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes(n_rows, n_groups, key_cols, val_cols, out_cols):
+    """every distinct input column read once, every output written once."""
+    from polars_amd._ffi import code_np_dtype
+
+    w = lambda c: code_np_dtype(c.dtype).itemsize
+    b = n_rows * (sum(w(c) for c in key_cols) + sum(w(c) for c in val_cols))
+    b += sum((n_rows + 7) // 8 for c in list(key_cols) + list(val_cols) if c.validity is not None)
+    b += n_groups * sum(code_np_dtype(cs.dtype).itemsize for cs in out_cols)
+    return b
+
+
+def cpu_baseline(tensors, wl, wide):
+    """The oracle (C restatement of the reference algorithm: P = pow2 <= threads partitions, every thread scans
+    all keys, per-group index lists, gather-fold aggregation), timed on this box's host cores."""
+    import numpy as np
+
+    from oracle import oracle as orc
+    from polars_amd import h2oai
+
+    keys_n, vals_n, aggs, _ = wl
+    host = {k: v.cpu().numpy() for k, v in tensors.items()}
+    cols = h2oai.to_columns({k: host[k] for k in host}, wide) if False else None
+    from polars_amd.column import Column
+    from polars_amd import _ffi
+
+    def mk(name):
+        dt = _ffi.U32 if (not wide and name in ("id1", "id2", "id3")) else None
+        a = host[name]
+        if dt == _ffi.U32:
+            a = a.view(np.uint32)
+        return Column(name, a)
+
+    keys = [mk(k) for k in keys_n]
+    vals = [mk(v) for v in vals_n]
+    threads = min(os.cpu_count() or 1, 16)  # the box's CPU share for one GPU
+    n = len(keys[0])
+    orc.lib()
+    t0 = time.perf_counter()
+    orc.group_by_agg(keys, vals, aggs, n_threads=threads)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "rows/s", "cores": threads, "kind": "port",
+            "sample": f"the full {n}-row workload, once ({dt:.2f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="q3", choices=sorted(WORKLOADS))
+    ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default 1e7; c3: 1e8)")
+    ap.add_argument("--strategy", default="auto")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    import polars_amd as pa
+    from polars_amd import _ffi, h2oai
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    _ffi.check(_ffi.lib().plhip_init(local_rank))
+
+    wl = WORKLOADS[args.workload]
+    keys_n, vals_n, aggs, wide = wl
+    n = args.rows or (100_000_000 if args.workload == "c3" else 10_000_000)
+    tensors = h2oai.generate(n, seed=108 + rank, device=dev, wide=wide, columns=keys_n + vals_n)
+    cols = h2oai.to_columns(tensors, wide)
+    keys = [cols[k] for k in keys_n]
+    vals = [cols[v] for v in vals_n]
+    agg_codes = [(ci, _ffi.AGG_NAMES[kind]) for ci, kind in aggs]
+    pa.set_strategy(args.strategy)
+    L = _ffi.lib()
+
+    if world > 1:
+        from polars_amd import distributed as pdist
+
+        def step():
+            return pdist.group_by_agg_sharded(keys, vals, aggs, device=dev)
+    else:
+        def step():
+            handle, out_cols = pa.group_by_agg_raw(keys, vals, agg_codes, _ffi.FLAG_OUTPUT_DEVICE)
+            g = L.plhip_result_num_rows(handle)
+            meta = list(out_cols)
+            L.plhip_result_free(handle)
+            return g, meta
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    kernel_ms, dom_ms = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        g, out_meta = step()
+        tot, dom, dom_name = pa.last_kernel_ms()
+        kernel_ms.append(tot)
+        dom_ms.append(dom)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        total_rows = n * world
+        abytes = algorithmic_bytes(n, g, keys, vals, out_meta) if world == 1 else algorithmic_bytes(n, g, keys, vals, [])
+        dom_avg = sum(dom_ms) / len(dom_ms)
+        tot_avg = sum(kernel_ms) / len(kernel_ms)
+        achieved = abytes / (dom_avg * 1e-3) / 1e9 if dom_avg > 0 else 0.0
+        line = {
+            "metric": "db-benchmark group-by rows/sec + % HBM roofline at 1/2/4/8 MI355X",
+            "value": total_rows / (dt / args.steps),
+            "unit": "rows/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32 keys, i64/f64 accumulators" if not wide else "i64 keys, i64/f64 accumulators",
+            "data": "synthetic",
+            "config": {"workload": f"db-benchmark {args.workload}: {', '.join(f'{k}({vals_n[c]})' for c, k in aggs)} by "
+                                   f"{','.join(keys_n)}, {n} rows per GPU, {g} groups", "strategy": pa.last_strategy(),
+                       "rows_per_gpu": n, "groups": int(g)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": dom_name,
+                         "kernel_ms": dom_avg, "algorithmic_bytes": abytes,
+                         "all_kernels_ms": tot_avg, "all_kernels_frac": abytes / (tot_avg * 1e-3) / 1e9 / HBM_PEAK_GBPS if tot_avg > 0 else 0.0},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(tensors, wl, wide)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
