@@ -97,8 +97,6 @@ typedef struct plhip_agg {
                                         two columns (sum, valid count) as in AggregationExpr::
                                         evaluate_partitioned (crates/polars-lazy/src/physical_plan/
                                         expressions/aggregation.rs:283-365) */
-#define PLHIP_FLAG_SORT_KEYS 8u      /* canonical output order: ascending by key tuple, nulls first
-                                        (test/bench convenience; no reference counterpart) */
 
 /* strategy override, PLHIP_STRATEGY env var or plhip_set_strategy(): mirrors the reference's
  * POLARS_NO_PARTITION / POLARS_FORCE_PARTITION switches

@@ -31,7 +31,6 @@ AGG_NAMES = {"sum": AGG_SUM, "mean": AGG_MEAN, "min": AGG_MIN, "max": AGG_MAX, "
 FLAG_MAINTAIN_ORDER = 1
 FLAG_OUTPUT_DEVICE = 2
 FLAG_PARTIAL = 4
-FLAG_SORT_KEYS = 8
 
 STRATEGIES = {"auto": 0, "global": 1, "lds": 2, "partitioned": 3}
 

@@ -17,7 +17,6 @@
 #include "../../include/plhip.h"
 #include "kernels.hpp"
 
-size_t lds_table_bytes(const Plan &p, uint32_t lcap); // kernels.hip
 
 // ---------------------------------------------------------------------------------------------------------
 // per-thread context
@@ -42,14 +41,14 @@ struct Scratch { // grow-only device buffer reused across calls (hipMalloc/hipFr
 struct Ctx {
   int device = -1;
   hipStream_t stream = nullptr;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   std::string err;
   std::string strategy = "";
-  float total_ms = 0.f, dom_ms = 0.f;
+  float total_ms = 0.f, dom_ms = 0.f, part_ms = 0.f, agg_ms = 0.f;
   std::string dom_kernel = "";
   int forced_strategy = -1; // -1: not set by the API (env / auto)
-  Scratch table, slots, sortkeys, flags, misc, rank, plans;
-  uint32_t *host_flags = nullptr; // pinned
+  Scratch table, slots, sortkeys, flags, misc, rank, plans, items, part;
+  uint32_t *host_flags = nullptr; // pinned, 64 bytes
 };
 
 thread_local Ctx g_ctx;
@@ -265,8 +264,8 @@ int dense_ids(const std::vector<KeyCol> &sub, int64_t n, Staging &st, KeyCol &ou
   K.single_key = 0; // nulls are codes: a null tuple member must get an id like any other value
   pack_keys(K, sub);
   const uint64_t cap = next_pow2(std::max<uint64_t>(2 * (uint64_t)n, 1024));
-  plan_layout(K, cap);
-  HIP_TRY(c.table.reserve(table_bytes(K, cap)));
+  plan_layout(K, cap + 2);
+  HIP_TRY(c.table.reserve(table_bytes(K, cap + 2)));
   HIP_TRY(c.flags.reserve(64));
   HIP_TRY(c.slots.reserve((cap + 2) * 8));
   HIP_TRY(c.rank.reserve((cap + 2) * 4));
@@ -277,7 +276,7 @@ int dense_ids(const std::vector<KeyCol> &sub, int64_t n, Staging &st, KeyCol &ou
   launch_table_init(K, t, c.stream);
   launch_sample_keys(K, t, n, 1, c.stream);
   launch_compact(K, t, (uint64_t *)c.slots.p, c.stream);
-  uint32_t f[8];
+  uint32_t f[16];
   int rc = read_flags(t, f);
   if (rc) return rc;
   if (f[FLAG_OVERFLOW]) return fail(PLHIP_ERR_COMPUTE, "hash table overflow while encoding wide keys");
@@ -348,7 +347,7 @@ int build_aggs(Lowered &L, const std::vector<DevCol> &vals, const plhip_agg_t *a
   P.n_vals = (int)vals.size();
   for (size_t i = 0; i < vals.size(); i++) {
     ValSpec &v = P.vals[i];
-    v.values = vals[i].values; v.validity = vals[i].validity; v.boff = vals[i].boff; v.dtype = (uint32_t)vals[i].dtype; v.pad = 0;
+    v.values = vals[i].values; v.validity = vals[i].validity; v.boff = vals[i].boff; v.dtype = (uint32_t)vals[i].dtype; v.valid_bytes = 0;
   }
   for (int k = 0; k < L.n_out_keys; k++) { // output keys are the ORIGINAL key columns, in order
     OutSpec o{};
@@ -441,13 +440,6 @@ int env_strategy() {
   return PLHIP_STRATEGY_AUTO;
 }
 
-// Largest power-of-two LDS table (slots) that fits `budget` bytes.
-uint32_t lds_cap_for(const Plan &P, size_t budget) {
-  uint32_t cap = 1u << 15;
-  while (cap > 64 && lds_table_bytes(P, cap) > budget) cap >>= 1;
-  return cap;
-}
-
 // Sampled cardinality estimate, the analogue of estimate_unique_count
 // (crates/polars-lazy/src/physical_plan/executors/group_by_partitioned.rs:115-157): insert every
 // (n/s)-th row's key into a scratch HBM table and count the distinct keys d, then invert
@@ -465,7 +457,7 @@ int read_flags(TableRef t, uint32_t *out8) {
   Ctx &c = g_ctx;
   HIP_TRY(hipMemcpyAsync(c.host_flags, t.flags, 32, hipMemcpyDeviceToHost, c.stream));
   HIP_TRY(hipStreamSynchronize(c.stream));
-  memcpy(out8, c.host_flags, 32);
+  memcpy(out8, c.host_flags, 32); // the first 8 flags are the ones the host reads
   return PLHIP_OK;
 }
 
@@ -477,15 +469,15 @@ int estimate_groups(const Plan &P, uint64_t &g_est) {
   Plan K = P;
   K.n_accs = 0;
   const uint64_t cap = 1u << 18;
-  HIP_TRY(c.table.reserve(table_bytes(K, cap)));
+  HIP_TRY(c.table.reserve(table_bytes(K, cap + 2)));
   HIP_TRY(c.flags.reserve(64));
   HIP_TRY(c.slots.reserve((cap + 2) * 8));
   TableRef t{(uint8_t *)c.table.p, cap, (uint32_t *)c.flags.p};
-  plan_layout(K, cap);
+  plan_layout(K, cap + 2);
   launch_table_init(K, t, c.stream);
   launch_sample_keys(K, t, s, n / s, c.stream);
   launch_compact(K, t, (uint64_t *)c.slots.p, c.stream);
-  uint32_t f[8];
+  uint32_t f[16];
   int rc = read_flags(t, f);
   if (rc) return rc;
   const double d = f[FLAG_NGROUPS];
@@ -505,6 +497,105 @@ int copy_out(const void *dev, size_t bytes, void **host) {
   *host = malloc(bytes ? bytes : 8);
   if (!*host) return fail(PLHIP_ERR_OOM, "host allocation failed");
   if (bytes) HIP_TRY(hipMemcpy(*host, dev, bytes, hipMemcpyDeviceToHost));
+  return PLHIP_OK;
+}
+
+} // namespace
+
+
+namespace {
+
+// bytes of the packed key as stored in LDS tables and partitioned intermediates
+int packed_key_bytes(const Plan &P, const std::vector<DevCol> &dk) {
+  if (P.single_key) return dtype_width(dk[0].dtype) <= 4 ? 4 : 8;
+  int total = 0;
+  for (int i = 0; i < P.n_keys; i++) total += (int)P.keys[i].bits;
+  return total <= 32 ? 4 : 8;
+}
+
+struct PartitionSetup {
+  uint32_t pbits = 0, lbits = 0;
+  int key_bytes = 8;
+};
+
+// Chooses the partition fan-out and the per-partition LDS table so that an average partition fills its
+// table to <= 25 % (hash skew head-room; a table that still overflows spills rows to the HBM table).
+bool plan_partitions(const Plan &P, uint64_t g_est, int key_bytes, uint32_t lbits2, uint32_t lbits1, PartitionSetup &PS) {
+  (void)P;
+  PS.key_bytes = key_bytes;
+  for (uint32_t lb : {lbits2, lbits1}) {
+    const uint64_t per_part = (1ull << lb) / 4;
+    uint32_t pb = 4;
+    while (pb < 12 && (g_est >> pb) > per_part) pb++;
+    if ((g_est >> pb) <= per_part) {
+      PS.pbits = pb;
+      uint32_t fit = 6;
+      while ((1ull << fit) < 4 * std::max<uint64_t>(g_est >> pb, 1) && fit < lb) fit++;
+      PS.lbits = fit;
+      return true;
+    }
+  }
+  return false;
+}
+
+int run_partitioned(const Plan &P, TableRef T, const PartitionSetup &PS, uint64_t dense_cap, uint64_t *slots_dev, bool need_rowidx) {
+  Ctx &c = g_ctx;
+  const int64_t n = P.n_rows;
+  const uint32_t np = 1u << PS.pbits;
+  uint32_t n_tiles = (uint32_t)std::min<int64_t>((n + 8191) / 8192, 16384);
+  if (n_tiles < 1) n_tiles = 1;
+  int64_t tile_rows = (n + n_tiles - 1) / n_tiles;
+  tile_rows = std::max<int64_t>(1024, (tile_rows + 1023) / 1024 * 1024);
+  n_tiles = (uint32_t)std::max<int64_t>(1, (n + tile_rows - 1) / tile_rows);
+  const uint32_t split_rows = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, std::max<uint64_t>(4ull * (uint64_t)n / np, 1 << 16));
+  const uint64_t max_items = np + (uint64_t)n / split_rows + 2;
+  // scratch: counts | totals | part_start | n_items,next_item | items
+  size_t off_counts = 0, off_totals = off_counts + (size_t)np * n_tiles * 4, off_start = off_totals + (size_t)np * 4;
+  size_t off_cnt = (off_start + (size_t)(np + 1) * 4 + 63) & ~(size_t)63, off_items = off_cnt + 64;
+  HIP_TRY(c.items.reserve(off_items + max_items * sizeof(WorkItem)));
+  uint8_t *sb = (uint8_t *)c.items.p;
+  uint32_t *counts = (uint32_t *)(sb + off_counts), *totals = (uint32_t *)(sb + off_totals), *pstart = (uint32_t *)(sb + off_start);
+  uint32_t *cnt = (uint32_t *)(sb + off_cnt);
+  WorkItem *items = (WorkItem *)(sb + off_items);
+  // intermediates: packed keys | row ids | value columns | validity bytes
+  PartOut O{};
+  O.key_bytes = (uint32_t)PS.key_bytes;
+  size_t bytes = ((size_t)n * PS.key_bytes + 255) & ~(size_t)255;
+  size_t off_row = bytes;
+  if (need_rowidx) bytes += ((size_t)n * 4 + 255) & ~(size_t)255;
+  size_t off_val[PLHIP_MAX_VALS], off_valid[PLHIP_MAX_VALS];
+  for (int v = 0; v < P.n_vals; v++) {
+    off_val[v] = bytes;
+    bytes += ((size_t)n * dtype_width((int)P.vals[v].dtype) + 255) & ~(size_t)255;
+    off_valid[v] = bytes;
+    if (P.vals[v].validity) bytes += ((size_t)n + 255) & ~(size_t)255;
+  }
+  HIP_TRY(c.part.reserve(bytes + 256));
+  uint8_t *pb = (uint8_t *)c.part.p;
+  O.keys = pb;
+  O.rowidx = need_rowidx ? (uint32_t *)(pb + off_row) : nullptr;
+  for (int v = 0; v < P.n_vals; v++) {
+    O.vals[v] = pb + off_val[v];
+    O.valid[v] = P.vals[v].validity ? pb + off_valid[v] : nullptr;
+  }
+  launch_part_hist(P, PS.pbits, tile_rows, n_tiles, counts, c.stream);
+  launch_part_scan(counts, np, n_tiles, totals, c.stream);
+  launch_part_plan(totals, np, pstart, items, cnt, cnt + 1, split_rows, c.stream);
+  launch_part_scatter(P, O, PS.pbits, tile_rows, n_tiles, counts, pstart, c.stream);
+  HIP_TRY(hipEventRecord(c.ev[4], c.stream));
+  // the aggregation pass reads the partitioned copies
+  Plan P2 = P;
+  P2.prepacked = 1;
+  P2.single_key = 0;
+  P2.keys[0].values = O.keys; P2.keys[0].validity = nullptr; P2.keys[0].boff = 0;
+  P2.keys[0].dtype = PS.key_bytes == 4 ? PLHIP_U32 : PLHIP_U64;
+  P2.rowidx = O.rowidx;
+  for (int v = 0; v < P.n_vals; v++) {
+    P2.vals[v].values = O.vals[v]; P2.vals[v].validity = O.valid[v]; P2.vals[v].boff = 0; P2.vals[v].valid_bytes = 1;
+  }
+  launch_lds_agg2(P2, T, items, cnt, (uint32_t)max_items, cnt + 1, PS.lbits, PS.key_bytes, dense_cap, slots_dev, c.stream);
+  HIP_TRY(hipEventRecord(c.ev[5], c.stream));
+  HIP_TRY(hipGetLastError());
   return PLHIP_OK;
 }
 
@@ -615,42 +706,89 @@ int32_t plhip_group_by_agg(const plhip_column_t *keys, int32_t n_keys, const plh
   // ---- strategy ------------------------------------------------------------------------------------
   int strategy = c.forced_strategy > 0 ? c.forced_strategy : env_strategy();
   uint64_t g_est = (uint64_t)n;
-  const size_t lds_budget = 150 * 1024;
-  const uint32_t lds_cap_max = lds_cap_for(P, lds_budget);
   if (n >= (1 << 14) && (rc = estimate_groups(P, g_est))) return rc;
+  const int key_bytes = packed_key_bytes(P, dk);
+  // largest LDS table (log2 slots) for two / one workgroup(s) per CU
+  uint32_t lbits2 = 13, lbits1 = 14;
+  while (lbits2 > 6 && lds2_table_bytes(P, lbits2, key_bytes) > 78 * 1024) lbits2--;
+  while (lbits1 > 6 && lds2_table_bytes(P, lbits1, key_bytes) > 150 * 1024) lbits1--;
   if (strategy == PLHIP_STRATEGY_AUTO) {
     if (n < (1 << 14)) strategy = PLHIP_STRATEGY_GLOBAL;
-    else strategy = (g_est <= lds_cap_max / 2) ? PLHIP_STRATEGY_LDS : PLHIP_STRATEGY_GLOBAL;
+    else if (g_est <= (1ull << lbits1) / 2) strategy = PLHIP_STRATEGY_LDS;
+    else strategy = PLHIP_STRATEGY_PARTITIONED;
   }
-  if (strategy == PLHIP_STRATEGY_PARTITIONED) strategy = PLHIP_STRATEGY_GLOBAL; // TODO(partitioned)
+  PartitionSetup PS;
+  if (strategy == PLHIP_STRATEGY_PARTITIONED) {
+    // the partitioned intermediates carry no null flag: a nullable single key is re-lowered as a packed code
+    if (P.single_key && dk[0].validity) {
+      std::vector<KeyCol> one(1);
+      one[0].col = dk[0]; one[0].nullable = true;
+      if ((rc = measure_key_columns(one, n))) return rc;
+      if (one[0].bits <= 64) { P.single_key = 0; pack_keys(P, one); }
+      else strategy = PLHIP_STRATEGY_GLOBAL;
+    }
+    if (strategy == PLHIP_STRATEGY_PARTITIONED && !plan_partitions(P, g_est, packed_key_bytes(P, dk), lbits2, lbits1, PS))
+      strategy = PLHIP_STRATEGY_GLOBAL; // more groups than one partition level can bring into LDS
+  }
 
-  uint32_t fl[8] = {0};
+  uint32_t fl[16] = {0};
   uint64_t cap = 0;
   TableRef T{};
   for (int attempt = 0;; attempt++) {
-    uint64_t want = attempt == 0 ? std::min<uint64_t>((uint64_t)n, g_est * 2 + 1024) : (uint64_t)n;
-    cap = next_pow2(std::max<uint64_t>(2 * want, 1024));
-    plan_layout(P, cap);
-    HIP_TRY(c.table.reserve(table_bytes(P, cap)));
+    uint64_t dense_cap = 0;
+    if (strategy == PLHIP_STRATEGY_PARTITIONED) {
+      dense_cap = attempt == 0 ? std::min<uint64_t>((uint64_t)n, std::max<uint64_t>(4 * g_est, 1 << 16)) : (uint64_t)n;
+      const uint64_t want = attempt == 0 ? std::min<uint64_t>((uint64_t)n, std::max<uint64_t>(g_est / 4, 1 << 15)) : (uint64_t)n;
+      cap = next_pow2(2 * want);
+    } else {
+      const uint64_t want = attempt == 0 ? std::min<uint64_t>((uint64_t)n, g_est * 2 + 1024) : (uint64_t)n;
+      cap = next_pow2(std::max<uint64_t>(2 * want, 1024));
+    }
+    const uint64_t n_slots = cap + 2 + dense_cap;
+    plan_layout(P, n_slots);
+    HIP_TRY(c.table.reserve(table_bytes(P, n_slots)));
     HIP_TRY(c.flags.reserve(64));
-    HIP_TRY(c.slots.reserve((cap + 2) * 8));
+    HIP_TRY(c.slots.reserve(n_slots * 8));
     T = TableRef{(uint8_t *)c.table.p, cap, (uint32_t *)c.flags.p};
+    uint64_t *slots_dev = (uint64_t *)c.slots.p;
     launch_table_init(P, T, c.stream);
     HIP_TRY(hipEventRecord(c.ev[1], c.stream));
-    if (strategy == PLHIP_STRATEGY_LDS) {
-      uint32_t lcap = lds_cap_max;
+    if (strategy == PLHIP_STRATEGY_PARTITIONED) {
+      if ((rc = run_partitioned(P, T, PS, dense_cap, slots_dev, L.first_acc >= 0))) return rc;
+      c.strategy = "partitioned";
+    } else if (strategy == PLHIP_STRATEGY_LDS) {
+      // unpartitioned input cut into row slices; every slice merges its LDS table into the HBM table
+      uint32_t lbits = lbits2;
       if (g_est < (uint64_t)n) { // size the LDS table to the estimate (4x head-room), not to the budget
-        uint32_t fit = (uint32_t)next_pow2(std::max<uint64_t>(4 * g_est, 256));
-        if (fit < lcap) lcap = fit;
+        uint32_t fit = 6;
+        while ((1ull << fit) < 4 * g_est && fit < lbits1) fit++;
+        lbits = fit <= lbits2 ? fit : lbits1;
       }
-      launch_agg_lds(P, T, lcap, c.stream);
-      c.strategy = "lds"; c.dom_kernel = "k_agg_lds";
+      const size_t lbytes = lds2_table_bytes(P, lbits, key_bytes);
+      const int64_t max_wgs = (int64_t)plhip_num_cus() * (lbytes <= 78 * 1024 ? 2 : 1);
+      int64_t n_items = std::max<int64_t>(1, std::min<int64_t>(max_wgs, (n + 4095) / 4096));
+      int64_t per = (n + n_items - 1) / n_items;
+      per = (per + 1023) / 1024 * 1024;
+      std::vector<WorkItem> items;
+      for (int64_t r = 0; r < n; r += per) items.push_back(WorkItem{r, std::min<int64_t>(n, r + per), 0u, 0u});
+      if (items.empty()) items.push_back(WorkItem{0, 0, 0u, 0u});
+      const uint32_t cnt[2] = {(uint32_t)items.size(), 0u};
+      HIP_TRY(c.items.reserve(items.size() * sizeof(WorkItem) + 64));
+      HIP_TRY(hipMemcpyAsync(c.items.p, cnt, 8, hipMemcpyHostToDevice, c.stream));
+      HIP_TRY(hipMemcpyAsync((uint8_t *)c.items.p + 64, items.data(), items.size() * sizeof(WorkItem), hipMemcpyHostToDevice, c.stream));
+      launch_lds_agg2(P, T, (const WorkItem *)((uint8_t *)c.items.p + 64), (const uint32_t *)c.items.p, (uint32_t)items.size(),
+                      (uint32_t *)c.items.p + 1, lbits, key_bytes, 0, slots_dev, c.stream);
+      c.strategy = "lds"; c.dom_kernel = "k_lds_agg2";
+      HIP_TRY(hipEventRecord(c.ev[4], c.stream));
+      HIP_TRY(hipEventRecord(c.ev[5], c.stream));
     } else {
       launch_agg_global(P, T, c.stream);
       c.strategy = "global"; c.dom_kernel = "k_agg_global";
+      HIP_TRY(hipEventRecord(c.ev[4], c.stream));
+      HIP_TRY(hipEventRecord(c.ev[5], c.stream));
     }
     HIP_TRY(hipEventRecord(c.ev[2], c.stream));
-    launch_compact(P, T, (uint64_t *)c.slots.p, c.stream);
+    launch_compact(P, T, slots_dev, c.stream);
     HIP_TRY(hipGetLastError());
     if ((rc = read_flags(T, fl))) return rc;
     if (!fl[FLAG_OVERFLOW]) break;
@@ -660,13 +798,10 @@ int32_t plhip_group_by_agg(const plhip_column_t *keys, int32_t n_keys, const plh
   uint64_t *slots = (uint64_t *)c.slots.p;
 
   // ---- ordering --------------------------------------------------------------------------------------
-  if ((flags & (PLHIP_FLAG_MAINTAIN_ORDER | PLHIP_FLAG_SORT_KEYS)) && G > 1) {
-    const bool by_first = (flags & PLHIP_FLAG_MAINTAIN_ORDER) || L.KG.enabled; // dense ids have no canonical order
-    // null group: slot list position 0 already (keys order: nulls first); by-first sorts everything
-    const uint64_t skip = (!by_first && fl[FLAG_NULL]) ? 1 : 0;
+  if ((flags & PLHIP_FLAG_MAINTAIN_ORDER) && G > 1) { // groups by first row (hashing.rs:32-79)
     HIP_TRY(c.sortkeys.reserve(G * 8));
-    launch_gather_sort_keys(P, T, slots + skip, G - skip, by_first ? L.first_acc : -1, (uint64_t *)c.sortkeys.p, c.stream);
-    HIP_TRY(sort_pairs_u64((uint64_t *)c.sortkeys.p, slots + skip, G - skip, by_first ? 32 : 64, c.stream));
+    launch_gather_sort_keys(P, T, slots, G, L.first_acc, (uint64_t *)c.sortkeys.p, c.stream);
+    HIP_TRY(sort_pairs_u64((uint64_t *)c.sortkeys.p, slots, G, 32, c.stream));
   }
 
   // ---- outputs ---------------------------------------------------------------------------------------
@@ -699,7 +834,18 @@ int32_t plhip_group_by_agg(const plhip_column_t *keys, int32_t n_keys, const plh
   if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
   if (e != hipSuccess) { delete R; return fail_hip(e, "group-by kernels"); }
   hipEventElapsedTime(&c.total_ms, c.ev[0], c.ev[3]);
-  hipEventElapsedTime(&c.dom_ms, c.ev[1], c.ev[2]);
+  {
+    // dominant kernel: the aggregation pass, or the partition scatter when that is the longer one
+    float t_all = 0.f, t_part = 0.f, t_agg = 0.f;
+    hipEventElapsedTime(&t_all, c.ev[1], c.ev[2]);
+    if (c.strategy == "partitioned") {
+      hipEventElapsedTime(&t_part, c.ev[1], c.ev[4]);
+      hipEventElapsedTime(&t_agg, c.ev[4], c.ev[5]);
+      c.part_ms = t_part; c.agg_ms = t_agg;
+      if (t_part > t_agg) { c.dom_ms = t_part; c.dom_kernel = "k_part_hist+k_part_scan+k_part_plan+k_part_scatter"; }
+      else { c.dom_ms = t_agg; c.dom_kernel = "k_lds_agg2"; }
+    } else { c.dom_ms = t_all; c.part_ms = 0.f; c.agg_ms = t_all; }
+  }
 
   if (!(flags & PLHIP_FLAG_OUTPUT_DEVICE)) {
     plhip_result *H = new (std::nothrow) plhip_result();

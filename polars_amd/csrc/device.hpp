@@ -16,11 +16,23 @@ DEVINL uint64_t folded_multiply(uint64_t s, uint64_t by) {
 }
 DEVINL uint64_t hash_key(uint64_t packed) { return folded_multiply(packed, PLHIP_MULTIPLE); }
 
+// Cheap 32-bit mixes for the partition id and the LDS slot (independent of each other and of the HBM
+// table's folded-multiply slot): Fibonacci hashing spreads dense integer keys evenly over the top bits.
+DEVINL uint32_t mix_a(uint64_t key) { return (uint32_t)key * 0x9E3779B1u + (uint32_t)(key >> 32) * 0x85EBCA77u; }
+DEVINL uint32_t part_of(uint32_t a, uint32_t pbits) { return pbits ? a >> (32 - pbits) : 0u; }
+DEVINL uint32_t lds_home(uint32_t a, uint32_t lbits) { return ((a ^ (a >> 15)) * 0xC2B2AE3Du) >> (32 - lbits); }
+
 // ---- column access -----------------------------------------------------------------------------------
 DEVINL bool bit_valid(const uint8_t *validity, int64_t boff, int64_t row) {
   if (!validity) return true;
   const int64_t b = boff + row;
   return (validity[b >> 3] >> (b & 7)) & 1;
+}
+DEVINL bool val_valid(const ValSpec &v, int64_t row) {
+  if (!v.validity) return true;
+  if (v.valid_bytes) return v.validity[row] != 0;
+  const int64_t b = v.boff + row;
+  return (v.validity[b >> 3] >> (b & 7)) & 1;
 }
 
 constexpr uint64_t SIGN64 = 0x8000000000000000ull;
@@ -30,9 +42,10 @@ constexpr uint64_t SIGN64 = 0x8000000000000000ull;
 // (crates/polars-core/src/frame/group_by/into_groups.rs:167-174).
 DEVINL uint64_t load_key_norm(const uint8_t *p, uint32_t dtype, int64_t row) {
   switch (dtype) {
-    case PLHIP_I8: return (uint64_t)(int64_t)((const int8_t *)p)[row] ^ SIGN64;
-    case PLHIP_I16: return (uint64_t)(int64_t)((const int16_t *)p)[row] ^ SIGN64;
-    case PLHIP_I32: return (uint64_t)(int64_t)((const int32_t *)p)[row] ^ SIGN64;
+    // signed keys of <= 4 bytes normalise inside 32 bits, so that they fit a 32-bit table slot
+    case PLHIP_I8: return (uint64_t)((uint32_t)(int32_t)((const int8_t *)p)[row] ^ 0x80000000u);
+    case PLHIP_I16: return (uint64_t)((uint32_t)(int32_t)((const int16_t *)p)[row] ^ 0x80000000u);
+    case PLHIP_I32: return (uint64_t)(((const uint32_t *)p)[row] ^ 0x80000000u);
     case PLHIP_I64: return ((const uint64_t *)p)[row] ^ SIGN64;
     case PLHIP_U8: return ((const uint8_t *)p)[row];
     case PLHIP_U16: return ((const uint16_t *)p)[row];
@@ -42,7 +55,8 @@ DEVINL uint64_t load_key_norm(const uint8_t *p, uint32_t dtype, int64_t row) {
 }
 DEVINL uint64_t key_denorm(uint64_t norm, uint32_t dtype) {
   switch (dtype) {
-    case PLHIP_I8: case PLHIP_I16: case PLHIP_I32: case PLHIP_I64: return norm ^ SIGN64;
+    case PLHIP_I8: case PLHIP_I16: case PLHIP_I32: return norm ^ 0x80000000ull; // stored truncated to the width
+    case PLHIP_I64: return norm ^ SIGN64;
     default: return norm;
   }
 }
@@ -96,6 +110,9 @@ DEVINL double f64_from_ordered(uint64_t e) {
 // slot.  Multi-key: range-compressed codes (null = 0) shifted into one word; `isnull` stays false.
 DEVINL uint64_t row_packed_key(const Plan &P, int64_t row, bool &isnull) {
   isnull = false;
+  if (P.prepacked)
+    return P.keys[0].dtype == PLHIP_U32 ? (uint64_t)((const uint32_t *)P.keys[0].values)[row]
+                                        : ((const uint64_t *)P.keys[0].values)[row];
   if (P.single_key) {
     const KeySpec &k = P.keys[0];
     if (!bit_valid(k.validity, k.boff, row)) { isnull = true; return 0; }
@@ -115,9 +132,9 @@ DEVINL uint64_t row_packed_key(const Plan &P, int64_t row, bool &isnull) {
 // Returns false when the row does not touch this accumulator (null source value).
 DEVINL bool acc_operand(const Plan &P, const AccSpec &a, int64_t row, uint64_t &operand) {
   if (a.op == ACC_CNT_ALL) { operand = 1; return true; }
-  if (a.op == ACC_FIRST_ROW) { operand = (uint64_t)row; return true; }
+  if (a.op == ACC_FIRST_ROW) { operand = P.rowidx ? (uint64_t)P.rowidx[row] : (uint64_t)row; return true; }
   const ValSpec &v = P.vals[a.src];
-  if (!bit_valid(v.validity, v.boff, row)) return false;
+  if (!val_valid(v, row)) return false;
   switch (a.conv) {
     case CONV_INT: operand = load_int64(v.values, v.dtype, row); break;
     case CONV_F64: operand = (uint64_t)__double_as_longlong(load_double(v.values, v.dtype, row)); break;

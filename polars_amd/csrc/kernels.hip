@@ -26,17 +26,17 @@
 // ---------------------------------------------------------------------------------------------------------
 static inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 
-void plan_layout(Plan &p, uint64_t cap) {
-  uint64_t off = align_up((cap + 2) * 8, 256);
+void plan_layout(Plan &p, uint64_t n_slots) {
+  uint64_t off = align_up(n_slots * 8, 256);
   for (int i = 0; i < p.n_accs; i++) {
     p.accs[i].offset = off;
-    off += align_up((cap + 2) * p.accs[i].width, 256);
+    off += align_up(n_slots * p.accs[i].width, 256);
   }
 }
 
-size_t table_bytes(const Plan &p, uint64_t cap) {
-  uint64_t off = align_up((cap + 2) * 8, 256);
-  for (int i = 0; i < p.n_accs; i++) off += align_up((cap + 2) * p.accs[i].width, 256);
+size_t table_bytes(const Plan &p, uint64_t n_slots) {
+  uint64_t off = align_up(n_slots * 8, 256);
+  for (int i = 0; i < p.n_accs; i++) off += align_up(n_slots * p.accs[i].width, 256);
   return off;
 }
 
@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(256) k_table_init(Plan P, TableRef T) {
       else ((uint32_t *)(T.base + A.offset))[i] = (uint32_t)A.init;
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x < 8) T.flags[threadIdx.x] = 0;
+  if (blockIdx.x == 0 && threadIdx.x < 16) T.flags[threadIdx.x] = 0;
 }
 
 void launch_table_init(const Plan &p, TableRef t, hipStream_t s) {
@@ -105,164 +105,34 @@ void launch_agg_global(const Plan &p, TableRef t, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// strategy "lds": per-workgroup LDS tables
-// ---------------------------------------------------------------------------------------------------------
-#define LDS_PROBE_LIMIT 64
-#define LDS_BLOCK 1024
-
-extern __shared__ __align__(16) uint8_t smem[];
-
-// LDS find-or-insert: ds_cmpst_rtn_b64 claim on the key word; same protocol as the HBM table.
-DEVINL uint32_t lds_slot(uint64_t *lkeys, uint32_t lcap, uint32_t *lused, uint64_t key, bool isnull) {
-  if (isnull) { if (!lused[1]) lused[1] = 1; return lcap + 1; }
-  if (key == PLHIP_EMPTY_KEY) { if (!lused[0]) lused[0] = 1; return lcap; }
-  const uint32_t mask = lcap - 1;
-  const uint64_t h = hash_key(key);
-  uint32_t s = (uint32_t)(h >> 40) & mask; // high bits: independent of the HBM table's slot bits
-  for (int i = 0; i < LDS_PROBE_LIMIT; i++) {
-    uint64_t k = lkeys[s];
-    if (k == key) return s;
-    if (k == PLHIP_EMPTY_KEY) {
-      k = atomicCAS((unsigned long long *)&lkeys[s], (unsigned long long)PLHIP_EMPTY_KEY, (unsigned long long)key);
-      if (k == PLHIP_EMPTY_KEY || k == key) return s;
-    }
-    s = (s + 1) & mask;
-  }
-  return ~0u;
-}
-
-__global__ void __launch_bounds__(LDS_BLOCK) k_agg_lds(Plan P, TableRef T, uint32_t lcap, int64_t rows_per_wg) {
-  __shared__ uint32_t lused[2];
-  __shared__ uint32_t loff[PLHIP_MAX_ACCS];
-  uint64_t *lkeys = (uint64_t *)smem;
-  const uint32_t lslots = lcap + 2;
-  if (threadIdx.x == 0) {
-    uint32_t off = lslots * 8;
-    for (int a = 0; a < P.n_accs; a++) { loff[a] = off; off += lslots * 8; } // 8-byte cells keep ds_*_b64 aligned
-    lused[0] = lused[1] = 0;
-  }
-  __syncthreads();
-  for (uint32_t i = threadIdx.x; i < lslots; i += blockDim.x) {
-    lkeys[i] = PLHIP_EMPTY_KEY;
-    for (int a = 0; a < P.n_accs; a++) {
-      if (P.accs[a].width == 8) ((uint64_t *)(smem + loff[a]))[i] = P.accs[a].init;
-      else ((uint32_t *)(smem + loff[a]))[i] = (uint32_t)P.accs[a].init;
-    }
-  }
-  __syncthreads();
-
-  uint64_t *gkeys = (uint64_t *)T.base;
-  const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
-  const int64_t r1 = (r0 + rows_per_wg < P.n_rows) ? r0 + rows_per_wg : P.n_rows;
-  uint32_t spilled = 0;
-  for (int64_t row = r0 + threadIdx.x; row < r1; row += blockDim.x) {
-    bool isnull;
-    const uint64_t key = row_packed_key(P, row, isnull);
-    const uint32_t ls = lds_slot(lkeys, lcap, lused, key, isnull);
-    if (ls != ~0u) {
-      for (int a = 0; a < P.n_accs; a++) {
-        AccSpec A = P.accs[a];
-        uint64_t operand;
-        if (acc_operand(P, A, row, operand)) { A.offset = loff[a]; acc_apply(smem, A, ls, operand); }
-      }
-    } else { // LDS table full along this probe sequence: fold the row straight into the HBM table
-      spilled++;
-      const uint64_t gs = gtable_slot(gkeys, T.cap, T.flags, key, false);
-      if (gs == ~0ull) continue;
-      for (int a = 0; a < P.n_accs; a++) {
-        const AccSpec &A = P.accs[a];
-        uint64_t operand;
-        if (acc_operand(P, A, row, operand)) acc_apply(T.base, A, gs, operand);
-      }
-    }
-  }
-  if (spilled) atomicAdd(&T.flags[FLAG_LDS_SPILL], spilled);
-  __syncthreads();
-
-  // merge: one HBM find-or-insert per occupied LDS slot, one global atomic per touched accumulator
-  for (uint32_t i = threadIdx.x; i < lslots; i += blockDim.x) {
-    const uint64_t key = lkeys[i];
-    bool occupied, isnull = false;
-    if (i < lcap) occupied = key != PLHIP_EMPTY_KEY;
-    else if (i == lcap) occupied = lused[0] != 0;
-    else { occupied = lused[1] != 0; isnull = true; }
-    if (!occupied) continue;
-    const uint64_t gs = gtable_slot(gkeys, T.cap, T.flags, i == lcap ? PLHIP_EMPTY_KEY : key, isnull);
-    if (gs == ~0ull) continue;
-    for (int a = 0; a < P.n_accs; a++) {
-      const AccSpec &A = P.accs[a];
-      const uint64_t part = (A.width == 8) ? ((uint64_t *)(smem + loff[a]))[i] : (uint64_t)((uint32_t *)(smem + loff[a]))[i];
-      if (part == A.init) continue; // identity: nothing to fold
-      acc_apply(T.base, A, gs, part);
-    }
-  }
-}
-
-static int g_num_cus = 0;
-static int num_cus() {
-  if (!g_num_cus) {
-    int dev = 0;
-    hipGetDevice(&dev);
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) g_num_cus = prop.multiProcessorCount;
-    if (g_num_cus <= 0) g_num_cus = 256;
-  }
-  return g_num_cus;
-}
-
-size_t lds_table_bytes(const Plan &p, uint32_t lcap) { return (size_t)(lcap + 2) * 8 * (1 + p.n_accs); }
-
-void launch_agg_lds(const Plan &p, TableRef t, uint32_t lcap, hipStream_t s) {
-  const size_t bytes = lds_table_bytes(p, lcap);
-  const int wg_per_cu = bytes <= 76 * 1024 ? 2 : 1;
-  int64_t max_wgs = (int64_t)num_cus() * wg_per_cu;
-  int64_t wgs = (p.n_rows + LDS_BLOCK * 4 - 1) / (LDS_BLOCK * 4); // at least 4 rows per thread
-  if (wgs < 1) wgs = 1;
-  if (wgs > max_wgs) wgs = max_wgs;
-  int64_t rows_per_wg = (p.n_rows + wgs - 1) / wgs;
-  rows_per_wg = (rows_per_wg + 63) / 64 * 64;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void *)k_agg_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(k_agg_lds, dim3((unsigned)wgs), dim3(LDS_BLOCK), bytes, s, p, t, lcap, rows_per_wg);
-}
-
-// ---------------------------------------------------------------------------------------------------------
 // compaction: occupied slots -> slot list (+ group count in flags[FLAG_NGROUPS])
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_compact(TableRef T, uint64_t *slots) {
   const uint64_t *keys = (const uint64_t *)T.base;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  const uint32_t has_null = T.flags[FLAG_NULL] ? 1u : 0u;
   const int lane = threadIdx.x & 63;
-  for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < T.cap + 1; base += stride) {
+  for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < T.cap + 2; base += stride) {
     const uint64_t i = base + threadIdx.x;
     bool occ = false;
     if (i < T.cap) occ = keys[i] != PLHIP_EMPTY_KEY;
     else if (i == T.cap) occ = T.flags[FLAG_SENTINEL] != 0;
+    else if (i == T.cap + 1) occ = T.flags[FLAG_NULL] != 0;
     // one counter atomic per wave: ballot + popcount prefix
     const unsigned long long m = __ballot(occ);
     uint32_t wbase = 0;
     if (m) {
       if (lane == 0) wbase = atomicAdd(&T.flags[FLAG_NGROUPS], (uint32_t)__popcll(m));
       wbase = __shfl(wbase, 0);
-      if (occ) slots[has_null + wbase + __popcll(m & ((1ull << lane) - 1))] = i;
+      if (occ) slots[wbase + __popcll(m & ((1ull << lane) - 1))] = i;
     }
   }
 }
 
-__global__ void k_compact_finish(TableRef T, uint64_t *slots) {
-  if (T.flags[FLAG_NULL]) { slots[0] = T.cap + 1; T.flags[FLAG_NGROUPS] += 1; }
-}
-
 void launch_compact(const Plan &p, TableRef t, uint64_t *slots, hipStream_t s) {
   (void)p;
-  uint64_t n = t.cap + 1;
+  uint64_t n = t.cap + 2;
   int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
   hipLaunchKernelGGL(k_compact, dim3(grid), dim3(256), 0, s, t, slots);
-  hipLaunchKernelGGL(k_compact_finish, dim3(1), dim3(1), 0, s, t, slots);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -273,8 +143,7 @@ __global__ void __launch_bounds__(256) k_gather_sort_keys(Plan P, TableRef T, co
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint64_t s = slots[i];
-  if (first_acc >= 0) out[i] = ((const uint32_t *)(T.base + P.accs[first_acc].offset))[s];
-  else out[i] = ((const uint64_t *)T.base)[s];
+  out[i] = ((const uint32_t *)(T.base + P.accs[first_acc].offset))[s];
 }
 
 void launch_gather_sort_keys(const Plan &p, TableRef t, const uint64_t *slots, uint64_t n, int by_first_acc,
@@ -350,7 +219,7 @@ __global__ void __launch_bounds__(256) k_finalize(Plan P, TableRef T, const OutP
           const KeySpec &K = P.keys[S.acc];
           uint64_t norm;
           if (P.single_key) {
-            valid = s != T.cap + 1;
+            valid = s != T.cap + 1; // only the hashed part can hold the null group
             norm = (s == T.cap) ? PLHIP_EMPTY_KEY : packed;
           } else {
             uint64_t code = K.bits >= 64 ? packed : ((packed >> K.shift) & ((1ull << K.bits) - 1));

@@ -5,8 +5,9 @@
 
 #include "plan.hpp"
 
-// Table flags (u32[8] in HBM): [0] overflow, [1] sentinel-key slot used, [2] null-key slot used,
-// [3] number of groups (written by the compaction kernel), [4] rows that overflowed an LDS table.
+// Table flags (u32[16] in HBM): [0] overflow, [1] sentinel-key slot used, [2] null-key slot used,
+// [3] number of groups (dense-area cursor of the LDS pass, then continued by the compaction kernel),
+// [4] rows that overflowed an LDS table.
 #define FLAG_OVERFLOW 0
 #define FLAG_SENTINEL 1
 #define FLAG_NULL 2
@@ -14,19 +15,41 @@
 #define FLAG_LDS_SPILL 4
 
 struct TableRef {
-  uint8_t *base;   // keys[cap+2] u64, then the accumulator arrays (AccSpec::offset)
-  uint64_t cap;    // power of two
-  uint32_t *flags; // u32[8]
+  uint8_t *base;   // keys[slots] u64, then the accumulator arrays (AccSpec::offset)
+  uint64_t cap;    // hashed part: power of two; slots cap / cap+1 are the reserved sentinel / null slots;
+                   // slots from cap+2 on are the dense result area of the partitioned path
+  uint32_t *flags; // u32[16]
 };
 
-size_t table_bytes(const Plan &p, uint64_t cap); // also fills nothing; offsets come from plan_layout
-void plan_layout(Plan &p, uint64_t cap);         // sets AccSpec::offset for a table of `cap` slots
+size_t table_bytes(const Plan &p, uint64_t n_slots); // n_slots = cap + 2 + dense capacity
+void plan_layout(Plan &p, uint64_t n_slots);         // sets AccSpec::offset for a table of n_slots slots
+
+struct PartOut {
+  uint8_t *keys;       // packed keys, key_bytes each
+  uint32_t *rowidx;    // original row ids or nullptr
+  uint8_t *vals[PLHIP_MAX_VALS];
+  uint8_t *valid[PLHIP_MAX_VALS]; // byte per row, or nullptr when the source column has no validity
+  uint32_t key_bytes;
+  uint32_t pad;
+};
+
+
+size_t lds2_table_bytes(const Plan &p, uint32_t lbits, int key_bytes);
+int plhip_num_cus();
+void launch_lds_agg2(const Plan &p, TableRef t, const WorkItem *items, const uint32_t *n_items_dev, uint32_t max_items,
+                     uint32_t *next_item_dev, uint32_t lbits, int key_bytes, uint64_t dense_cap, uint64_t *slots,
+                     hipStream_t s);
+void launch_part_hist(const Plan &p, uint32_t pbits, int64_t tile_rows, uint32_t n_tiles, uint32_t *counts, hipStream_t s);
+void launch_part_scan(uint32_t *counts, uint32_t np, uint32_t n_tiles, uint32_t *totals, hipStream_t s);
+void launch_part_plan(const uint32_t *totals, uint32_t np, uint32_t *part_start, WorkItem *items, uint32_t *n_items,
+                      uint32_t *next_item, uint32_t split_rows, hipStream_t s);
+void launch_part_scatter(const Plan &p, const PartOut &o, uint32_t pbits, int64_t tile_rows, uint32_t n_tiles,
+                         const uint32_t *offs, const uint32_t *part_start, hipStream_t s);
 
 void launch_table_init(const Plan &p, TableRef t, hipStream_t s);
 void launch_agg_global(const Plan &p, TableRef t, hipStream_t s);
-void launch_agg_lds(const Plan &p, TableRef t, uint32_t lds_cap, hipStream_t s);
-// slots[has_null .. G) = occupied hashed/sentinel slots in arbitrary order, slots[0] = null slot if used;
-// flags[FLAG_NGROUPS] = G.
+// appends the occupied slots of the hashed part (reserved slots included) to `slots`, continuing at
+// flags[FLAG_NGROUPS]; afterwards flags[FLAG_NGROUPS] = G.
 void launch_compact(const Plan &p, TableRef t, uint64_t *slots, hipStream_t s);
 // sort keys for the optional ordering step: FIRST_ROW accumulator (u32 -> u64) or the packed key
 void launch_gather_sort_keys(const Plan &p, TableRef t, const uint64_t *slots, uint64_t n, int by_first_acc,

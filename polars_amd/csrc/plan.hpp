@@ -58,7 +58,7 @@ struct ValSpec {
   const uint8_t *validity;
   int64_t boff;
   uint32_t dtype;
-  uint32_t pad;
+  uint32_t valid_bytes; // 1: `validity` is one byte per row (partitioned intermediates), 0: Arrow bitmap
 };
 
 struct AccSpec {
@@ -76,16 +76,21 @@ struct Plan {
   int32_t n_vals;
   int32_t n_accs;
   int32_t single_key; // 1: packed key = normalised key bits, null -> reserved slot; 0: range-packed tuple
+  const uint32_t *rowidx; // original row index of each row (partitioned intermediates) or nullptr = identity
+  int32_t prepacked;      // 1: keys[0].values already holds the packed key (u32 or u64), use it as is
+  int32_t pad0;
   KeySpec keys[PLHIP_MAX_KEYS];
   ValSpec vals[PLHIP_MAX_VALS];
   AccSpec accs[PLHIP_MAX_ACCS];
 };
 
-// A hash table in HBM: keys[cap + 2] (u64) followed by one array per accumulator.
-struct Table {
-  uint8_t *base;
-  uint64_t cap;       // power of two; slots cap and cap+1 are the reserved ones
-  uint32_t *overflow; // set to 1 when an insert found no free slot within the probe limit
+// One unit of work of the LDS aggregation kernel: a row range that ONE workgroup folds into its LDS table.
+// direct = 1: no other work item can hold the same keys (a whole hash partition) -> the groups are
+// written straight to the dense area of the table; direct = 0: merged into the hashed HBM table.
+struct WorkItem {
+  int64_t row0, row1;
+  uint32_t direct;
+  uint32_t pad;
 };
 
 enum OutKind : uint32_t {
