@@ -542,11 +542,8 @@ int run_partitioned(const Plan &P, TableRef T, const PartitionSetup &PS, uint64_
   Ctx &c = g_ctx;
   const int64_t n = P.n_rows;
   const uint32_t np = 1u << PS.pbits;
-  uint32_t n_tiles = (uint32_t)std::min<int64_t>((n + 8191) / 8192, 16384);
-  if (n_tiles < 1) n_tiles = 1;
-  int64_t tile_rows = (n + n_tiles - 1) / n_tiles;
-  tile_rows = std::max<int64_t>(1024, (tile_rows + 1023) / 1024 * 1024);
-  n_tiles = (uint32_t)std::max<int64_t>(1, (n + tile_rows - 1) / tile_rows);
+  const int64_t tile_rows = (int64_t)PART_SCATTER_R * 1024; // the scatter kernel sorts one tile in LDS
+  const uint32_t n_tiles = (uint32_t)std::max<int64_t>(1, (n + tile_rows - 1) / tile_rows);
   const uint32_t split_rows = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, std::max<uint64_t>(4ull * (uint64_t)n / np, 1 << 16));
   const uint64_t max_items = np + (uint64_t)n / split_rows + 2;
   // scratch: counts | totals | part_start | n_items,next_item | items

@@ -34,6 +34,7 @@ struct PartOut {
 };
 
 
+#define PART_SCATTER_R 8 // rows per thread of the partition scatter: its tile is 8192 rows
 size_t lds2_table_bytes(const Plan &p, uint32_t lbits, int key_bytes);
 int plhip_num_cus();
 void launch_lds_agg2(const Plan &p, TableRef t, const WorkItem *items, const uint32_t *n_items_dev, uint32_t max_items,

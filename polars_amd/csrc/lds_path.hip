@@ -100,7 +100,7 @@ DEVINL void load_operands(const ValSpec &V, uint32_t conv, const int64_t (&rows)
 }
 
 template <typename KS>
-__global__ void __launch_bounds__(A2_BLOCK)
+__global__ void __launch_bounds__(A2_BLOCK, 8) // 8 waves per SIMD = two 1024-thread workgroups per CU
 k_lds_agg2(Plan P, TableRef T, const WorkItem *__restrict__ items, const uint32_t *__restrict__ n_items_p,
            uint32_t *next_item, uint32_t lbits, uint64_t dense_cap, uint64_t *slots) {
   __shared__ uint32_t lused[2];
@@ -414,29 +414,147 @@ DEVINL uint32_t dtype_bytes(uint32_t dt) {
   }
 }
 
+// Exclusive scan of v[0..n) in LDS by one workgroup of PART_BLOCK threads (n <= PART_MAX); `tmp` holds one
+// word per wave.  Returns with a barrier passed; v[] holds the exclusive prefix.
+DEVINL void block_exclusive_scan(uint32_t *v, uint32_t n, uint32_t *tmp) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t per = (n + PART_BLOCK - 1) / PART_BLOCK; // consecutive entries per thread (<= 4)
+  const uint32_t b = tid * per;
+  uint32_t loc[PART_MAX / PART_BLOCK];
+  uint32_t sum = 0;
+#pragma unroll
+  for (uint32_t i = 0; i < PART_MAX / PART_BLOCK; i++) {
+    loc[i] = (i < per && b + i < n) ? v[b + i] : 0;
+    sum += loc[i];
+  }
+  uint32_t inc = sum; // inclusive scan across the wave
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(inc, off);
+    if (lane >= (uint32_t)off) inc += t;
+  }
+  if (lane == 63) tmp[wave] = inc;
+  __syncthreads();
+  if (wave == 0) {
+    uint32_t w = lane < PART_BLOCK / 64 ? tmp[lane] : 0;
+    uint32_t winc = w;
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {
+      const uint32_t t = __shfl_up(winc, off);
+      if (lane >= (uint32_t)off) winc += t;
+    }
+    if (lane < PART_BLOCK / 64) tmp[lane] = winc - w; // exclusive wave offsets
+  }
+  __syncthreads();
+  uint32_t run = tmp[wave] + inc - sum;
+#pragma unroll
+  for (uint32_t i = 0; i < PART_MAX / PART_BLOCK; i++)
+    if (i < per && b + i < n) { v[b + i] = run; run += loc[i]; }
+  __syncthreads();
+}
+
+// Scatter with an in-LDS counting sort of the tile: rows are ranked inside their partition (ds_add_rtn),
+// staged at their sorted position, then written out run by run, so every (tile, partition) run is one
+// contiguous, coalesced store stream instead of 4-byte stores to 2^pbits different lines.
+template <int R>
 __global__ void __launch_bounds__(PART_BLOCK) k_part_scatter(Plan P, PartOut O, uint32_t pbits, int64_t tile_rows, uint32_t n_tiles,
                                                              const uint32_t *__restrict__ offs, const uint32_t *__restrict__ part_start) {
-  __shared__ uint32_t cur[PART_MAX];
-  const uint32_t np = 1u << pbits;
-  for (uint32_t p = threadIdx.x; p < np; p += PART_BLOCK) cur[p] = part_start[p] + offs[(uint64_t)p * n_tiles + blockIdx.x];
+  __shared__ uint32_t tmp[PART_BLOCK / 64];
+  const uint32_t np = 1u << pbits, tid = threadIdx.x;
+  uint32_t *hist = (uint32_t *)smem2;              // [np] counts, then exclusive local starts
+  uint32_t *delta = hist + np;                      // [np] global run start - local run start
+  uint64_t *stage = (uint64_t *)(delta + np);       // [R * PART_BLOCK] one column of the sorted tile
+  uint16_t *spart = (uint16_t *)(stage + R * PART_BLOCK); // [R * PART_BLOCK] partition of each sorted position
+  for (uint32_t p = tid; p < np; p += PART_BLOCK) hist[p] = 0;
   __syncthreads();
   const int64_t r0 = (int64_t)blockIdx.x * tile_rows;
   const int64_t r1 = r0 + tile_rows < P.n_rows ? r0 + tile_rows : P.n_rows;
-  for (int64_t row = r0 + threadIdx.x; row < r1; row += PART_BLOCK) {
-    const uint64_t key = part_row_key(P, row);
-    const uint32_t dest = atomicAdd(&cur[part_of(mix_a(key), pbits)], 1u);
-    if (O.key_bytes == 4) ((uint32_t *)O.keys)[dest] = (uint32_t)key;
-    else ((uint64_t *)O.keys)[dest] = key;
-    if (O.rowidx) O.rowidx[dest] = (uint32_t)row;
-    for (int v = 0; v < P.n_vals; v++) {
-      const ValSpec &V = P.vals[v];
-      switch (dtype_bytes(V.dtype)) {
-        case 1: O.vals[v][dest] = V.values[row]; break;
-        case 2: ((uint16_t *)O.vals[v])[dest] = ((const uint16_t *)V.values)[row]; break;
-        case 4: ((uint32_t *)O.vals[v])[dest] = ((const uint32_t *)V.values)[row]; break;
-        default: ((uint64_t *)O.vals[v])[dest] = ((const uint64_t *)V.values)[row]; break;
+  const uint32_t nt = (uint32_t)(r1 - r0);
+  uint64_t key[R];
+  uint32_t pr[R]; // partition | rank << 12 ... later: sorted position
+  bool live[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const int64_t row = r0 + (int64_t)r * PART_BLOCK + tid;
+    live[r] = row < r1;
+    key[r] = live[r] ? part_row_key(P, row) : 0;
+  }
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    pr[r] = 0;
+    if (live[r]) {
+      const uint32_t p = part_of(mix_a(key[r]), pbits);
+      pr[r] = p | (atomicAdd(&hist[p], 1u) << 12);
+    }
+  }
+  __syncthreads();
+  for (uint32_t p = tid; p < np; p += PART_BLOCK) delta[p] = part_start[p] + offs[(uint64_t)p * n_tiles + blockIdx.x];
+  block_exclusive_scan(hist, np, tmp);
+  for (uint32_t p = tid; p < np; p += PART_BLOCK) delta[p] -= hist[p];
+#pragma unroll
+  for (int r = 0; r < R; r++)
+    if (live[r]) {
+      const uint32_t p = pr[r] & 0xFFFu;
+      const uint32_t pos = hist[p] + (pr[r] >> 12);
+      pr[r] = pos;
+      spart[pos] = (uint16_t)p;
+      if (O.key_bytes == 4) ((uint32_t *)stage)[pos] = (uint32_t)key[r];
+      else stage[pos] = key[r];
+    }
+  __syncthreads();
+  uint32_t dest[R];
+#pragma unroll
+  for (int i = 0; i < R; i++) {
+    const uint32_t j = i * PART_BLOCK + tid;
+    dest[i] = j < nt ? j + delta[spart[j]] : 0;
+    if (j < nt) {
+      if (O.key_bytes == 4) ((uint32_t *)O.keys)[dest[i]] = ((const uint32_t *)stage)[j];
+      else ((uint64_t *)O.keys)[dest[i]] = stage[j];
+    }
+  }
+  if (O.rowidx) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; r++) if (live[r]) ((uint32_t *)stage)[pr[r]] = (uint32_t)(r0 + (int64_t)r * PART_BLOCK + tid);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < R; i++) { const uint32_t j = i * PART_BLOCK + tid; if (j < nt) O.rowidx[dest[i]] = ((const uint32_t *)stage)[j]; }
+  }
+  for (int v = 0; v < P.n_vals; v++) {
+    const ValSpec V = P.vals[v];
+    const uint32_t w = dtype_bytes(V.dtype);
+    __syncthreads(); // the previous column has left the staging buffer
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      if (!live[r]) continue;
+      const int64_t row = r0 + (int64_t)r * PART_BLOCK + tid;
+      switch (w) {
+        case 1: ((uint8_t *)stage)[pr[r]] = V.values[row]; break;
+        case 2: ((uint16_t *)stage)[pr[r]] = ((const uint16_t *)V.values)[row]; break;
+        case 4: ((uint32_t *)stage)[pr[r]] = ((const uint32_t *)V.values)[row]; break;
+        default: stage[pr[r]] = ((const uint64_t *)V.values)[row]; break;
       }
-      if (O.valid[v]) O.valid[v][dest] = val_valid(V, row) ? 1 : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+      const uint32_t j = i * PART_BLOCK + tid;
+      if (j >= nt) continue;
+      switch (w) {
+        case 1: O.vals[v][dest[i]] = ((const uint8_t *)stage)[j]; break;
+        case 2: ((uint16_t *)O.vals[v])[dest[i]] = ((const uint16_t *)stage)[j]; break;
+        case 4: ((uint32_t *)O.vals[v])[dest[i]] = ((const uint32_t *)stage)[j]; break;
+        default: ((uint64_t *)O.vals[v])[dest[i]] = stage[j]; break;
+      }
+    }
+    if (O.valid[v]) {
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < R; r++)
+        if (live[r]) ((uint8_t *)stage)[pr[r]] = val_valid(V, r0 + (int64_t)r * PART_BLOCK + tid) ? 1 : 0;
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < R; i++) { const uint32_t j = i * PART_BLOCK + tid; if (j < nt) O.valid[v][dest[i]] = ((const uint8_t *)stage)[j]; }
     }
   }
 }
@@ -451,7 +569,15 @@ void launch_part_plan(const uint32_t *totals, uint32_t np, uint32_t *part_start,
                       uint32_t *next_item, uint32_t split_rows, hipStream_t s) {
   hipLaunchKernelGGL(k_part_plan, dim3(1), dim3(1024), 0, s, totals, np, part_start, items, n_items, next_item, split_rows);
 }
+// tile_rows must be PART_SCATTER_R * PART_BLOCK or less (the tile is sorted in LDS)
 void launch_part_scatter(const Plan &p, const PartOut &o, uint32_t pbits, int64_t tile_rows, uint32_t n_tiles,
                          const uint32_t *offs, const uint32_t *part_start, hipStream_t s) {
-  hipLaunchKernelGGL(k_part_scatter, dim3(n_tiles), dim3(PART_BLOCK), 0, s, p, o, pbits, tile_rows, n_tiles, offs, part_start);
+  const uint32_t np = 1u << pbits;
+  const size_t bytes = (size_t)np * 8 + (size_t)PART_SCATTER_R * PART_BLOCK * 10;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)k_part_scatter<PART_SCATTER_R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_part_scatter<PART_SCATTER_R>, dim3(n_tiles), dim3(PART_BLOCK), bytes, s, p, o, pbits, tile_rows, n_tiles, offs, part_start);
 }
