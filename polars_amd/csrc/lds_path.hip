@@ -13,6 +13,8 @@
 // Everything here is HBM/LDS-bound integer and f64-atomic work; no MFMA.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "device.hpp"
 #include "kernels.hpp"
 
@@ -23,6 +25,15 @@
 #define PART_MAX 4096
 
 extern __shared__ __align__(16) uint8_t smem2[];
+
+DEVINL uint32_t dtype_bytes(uint32_t dt) {
+  switch (dt) {
+    case PLHIP_I8: case PLHIP_U8: return 1;
+    case PLHIP_I16: case PLHIP_U16: return 2;
+    case PLHIP_I32: case PLHIP_U32: case PLHIP_F32: return 4;
+    default: return 8;
+  }
+}
 
 template <typename KS> struct KSEmpty;
 template <> struct KSEmpty<uint32_t> { static constexpr uint32_t v = 0xFFFFFFFFu; };
@@ -99,10 +110,105 @@ DEVINL void load_operands(const ValSpec &V, uint32_t conv, const int64_t (&rows)
   }
 }
 
+#define A2_NPRE 3 // value columns whose tile is prefetched into registers
+
 template <typename KS>
-__global__ void __launch_bounds__(A2_BLOCK, 8) // 8 waves per SIMD = two 1024-thread workgroups per CU
+struct TileRegs {
+  KS key[A2_R];
+  uint64_t raw[A2_NPRE][A2_R]; // raw bits, zero-extended from the column width
+  uint32_t vok[A2_NPRE];       // validity, bit r
+  uint32_t live, isnull;       // bit r
+};
+
+// Issues every load of one tile (keys + the first `npre` value columns); nothing here waits on them
+// except the generic multi-column key path, whose packing needs the loaded bits.
+template <typename KS>
+DEVINL void load_tile(const Plan &P, const KeySpec &K0, bool fast4, bool fast8, uint64_t kxor, uint32_t npre,
+                      int64_t tbase, int64_t row1, uint32_t tid, TileRegs<KS> &t) {
+  t.live = 0; t.isnull = 0;
+  int64_t rows[A2_R];
+#pragma unroll
+  for (int r = 0; r < A2_R; r++) {
+    const int64_t row = tbase + (int64_t)r * A2_BLOCK + tid;
+    if (row < row1) t.live |= 1u << r;
+    rows[r] = row < row1 ? row : row1 - 1; // clamped: every load below is unconditional, so they issue back to back
+  }
+  if (fast4) {
+#pragma unroll
+    for (int r = 0; r < A2_R; r++) t.key[r] = (KS)(((const uint32_t *)K0.values)[rows[r]] ^ (uint32_t)kxor);
+  } else if (fast8) {
+#pragma unroll
+    for (int r = 0; r < A2_R; r++) t.key[r] = (KS)(((const uint64_t *)K0.values)[rows[r]] ^ kxor);
+  } else {
+#pragma unroll
+    for (int r = 0; r < A2_R; r++) {
+      bool isn = false;
+      t.key[r] = (KS)row_packed_key(P, rows[r], isn);
+      if (isn) t.isnull |= 1u << r;
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < A2_NPRE; v++) {
+    t.vok[v] = t.live;
+    if ((uint32_t)v >= npre) continue;
+    const ValSpec V = P.vals[v];
+    switch (dtype_bytes(V.dtype)) {
+#define LD_RAW(T) _Pragma("unroll") for (int r = 0; r < A2_R; r++) t.raw[v][r] = (uint64_t)((const T *)V.values)[rows[r]]; break;
+      case 1: LD_RAW(uint8_t)
+      case 2: LD_RAW(uint16_t)
+      case 4: LD_RAW(uint32_t)
+      default: LD_RAW(uint64_t)
+#undef LD_RAW
+    }
+    if (V.validity) {
+      uint32_t m = 0;
+#pragma unroll
+      for (int r = 0; r < A2_R; r++) if (val_valid(V, rows[r])) m |= 1u << r;
+      t.vok[v] = m & t.live;
+    }
+  }
+}
+
+// raw column bits -> accumulator operands (same conversions as load_operands)
+DEVINL void raw_operands(uint32_t dtype, uint32_t conv, const uint64_t (&raw)[A2_R], uint64_t (&opnd)[A2_R]) {
+  if (conv == CONV_INT) {
+    switch (dtype) {
+#define CV_INT(T) _Pragma("unroll") for (int r = 0; r < A2_R; r++) opnd[r] = (uint64_t)(int64_t)(T)raw[r]; break;
+      case PLHIP_I8: CV_INT(int8_t)
+      case PLHIP_I16: CV_INT(int16_t)
+      case PLHIP_I32: CV_INT(int32_t)
+      default:
+#pragma unroll
+        for (int r = 0; r < A2_R; r++) opnd[r] = raw[r]; // unsigned widths are already zero-extended
+        break;
+#undef CV_INT
+    }
+    return;
+  }
+  double d[A2_R];
+  switch (dtype) {
+#define CV_F(EXPR) _Pragma("unroll") for (int r = 0; r < A2_R; r++) d[r] = (EXPR); break;
+    case PLHIP_F32: CV_F((double)__uint_as_float((uint32_t)raw[r]))
+    case PLHIP_F64: CV_F(__longlong_as_double((long long)raw[r]))
+    case PLHIP_I64: CV_F((double)(int64_t)raw[r])
+    case PLHIP_I32: CV_F((double)(int32_t)raw[r])
+    case PLHIP_I16: CV_F((double)(int16_t)raw[r])
+    case PLHIP_I8: CV_F((double)(int8_t)raw[r])
+    default: CV_F((double)raw[r])
+#undef CV_F
+  }
+#pragma unroll
+  for (int r = 0; r < A2_R; r++) {
+    if (conv == CONV_F64) opnd[r] = (uint64_t)__double_as_longlong(d[r]);
+    else if (conv == CONV_FMIN) opnd[r] = (d[r] != d[r]) ? ~0ull : f64_ordered(d[r]);
+    else opnd[r] = (d[r] != d[r]) ? 0ull : f64_ordered(d[r]);
+  }
+}
+
+template <typename KS>
+__global__ void __launch_bounds__(A2_BLOCK) // 8 waves per SIMD = two 1024-thread workgroups per CU
 k_lds_agg2(Plan P, TableRef T, const WorkItem *__restrict__ items, const uint32_t *__restrict__ n_items_p,
-           uint32_t *next_item, uint32_t lbits, uint64_t dense_cap, uint64_t *slots) {
+           uint32_t *next_item, uint32_t lbits, uint64_t dense_cap, uint64_t *slots, uint32_t diag) {
   __shared__ uint32_t lused[2];
   __shared__ uint32_t loff[PLHIP_MAX_ACCS];
   __shared__ uint32_t sh_item, sh_count, sh_cursor, sh_base;
@@ -122,6 +228,7 @@ k_lds_agg2(Plan P, TableRef T, const WorkItem *__restrict__ items, const uint32_
   const bool fast8 = (P.prepacked && K0.dtype != PLHIP_U32) ||
                      (!P.prepacked && P.single_key && !K0.validity && (K0.dtype == PLHIP_I64 || K0.dtype == PLHIP_U64 || K0.dtype == PLHIP_F64));
   const uint64_t kxor = P.prepacked ? 0ull : (K0.dtype == PLHIP_I32 ? 0x80000000ull : (K0.dtype == PLHIP_I64 ? SIGN64 : 0ull));
+  const uint32_t npre = P.n_vals < A2_NPRE ? (uint32_t)P.n_vals : (uint32_t)A2_NPRE;
 
   for (;;) {
     __syncthreads(); // previous item fully emitted; loff visible on the first trip
@@ -141,33 +248,36 @@ k_lds_agg2(Plan P, TableRef T, const WorkItem *__restrict__ items, const uint32_
     __syncthreads();
 
     uint32_t spilled = 0;
+    // Software pipeline: the columns of tile t+1 are in flight (registers) while tile t is probed and
+    // folded, so a wave exposes one HBM round trip per item instead of one per column per tile.
+    TileRegs<KS> cur, nxt;
+    if (W.row0 < W.row1) load_tile<KS>(P, K0, fast4, fast8, kxor, npre, W.row0, W.row1, tid, cur);
     for (int64_t tbase = W.row0; tbase < W.row1; tbase += (int64_t)A2_BLOCK * A2_R) {
+      const int64_t tnext = tbase + (int64_t)A2_BLOCK * A2_R;
+      if (tnext < W.row1) load_tile<KS>(P, K0, fast4, fast8, kxor, npre, tnext, W.row1, tid, nxt);
       int64_t rows[A2_R];
       bool live[A2_R];
-      uint64_t key[A2_R];
-      bool isnull[A2_R];
       uint32_t slot[A2_R];
 #pragma unroll
-      for (int r = 0; r < A2_R; r++) { rows[r] = tbase + (int64_t)r * A2_BLOCK + tid; live[r] = rows[r] < W.row1; isnull[r] = false; }
-      if (fast4) {
+      for (int r = 0; r < A2_R; r++) { rows[r] = tbase + (int64_t)r * A2_BLOCK + tid; live[r] = (cur.live >> r) & 1; }
+      if (diag & 2) { // DIAG: loads only
+        uint64_t acc = 0;
 #pragma unroll
-        for (int r = 0; r < A2_R; r++) key[r] = live[r] ? ((uint64_t)((const uint32_t *)K0.values)[rows[r]] ^ kxor) : 0;
-      } else if (fast8) {
-#pragma unroll
-        for (int r = 0; r < A2_R; r++) key[r] = live[r] ? (((const uint64_t *)K0.values)[rows[r]] ^ kxor) : 0;
-      } else {
-#pragma unroll
-        for (int r = 0; r < A2_R; r++) key[r] = live[r] ? row_packed_key(P, rows[r], isnull[r]) : 0;
+        for (int r = 0; r < A2_R; r++) acc += (uint64_t)cur.key[r] + cur.raw[0][r] + cur.raw[1][r] + cur.raw[2][r];
+        if (acc == 0x123456789abcdefull) lused[0] = 1;
+        cur = nxt;
+        continue;
       }
 #pragma unroll
       for (int r = 0; r < A2_R; r++) {
         slot[r] = 0;
         if (!live[r]) continue;
-        slot[r] = lds2_slot<KS>(lkeys, lbits, lused, key[r], isnull[r]);
+        const bool isnull = (cur.isnull >> r) & 1;
+        slot[r] = lds2_slot<KS>(lkeys, lbits, lused, (uint64_t)cur.key[r], isnull);
         if (slot[r] == ~0u) { // no room in LDS: fold this row into the hashed HBM table
           live[r] = false;
           spilled++;
-          const uint64_t gs = gtable_slot(gkeys, T.cap, T.flags, key[r], isnull[r]);
+          const uint64_t gs = gtable_slot(gkeys, T.cap, T.flags, (uint64_t)cur.key[r], isnull);
           if (gs != ~0ull)
             for (int a = 0; a < P.n_accs; a++) {
               const AccSpec &A = P.accs[a];
@@ -176,7 +286,7 @@ k_lds_agg2(Plan P, TableRef T, const WorkItem *__restrict__ items, const uint32_
             }
         }
       }
-      for (int a = 0; a < P.n_accs; a++) {
+      for (int a = 0; a < ((diag & 1) ? 0 : P.n_accs); a++) { // DIAG bit 0: probes only
         const AccSpec A = P.accs[a];
         uint8_t *lb = smem2 + loff[a];
         if (A.op == ACC_CNT_ALL) {
@@ -192,20 +302,41 @@ k_lds_agg2(Plan P, TableRef T, const WorkItem *__restrict__ items, const uint32_
         }
         const ValSpec V = P.vals[A.src];
         bool ok[A2_R];
-        if (V.validity) {
-#pragma unroll
-          for (int r = 0; r < A2_R; r++) ok[r] = live[r] && val_valid(V, rows[r]);
-        } else {
-#pragma unroll
-          for (int r = 0; r < A2_R; r++) ok[r] = live[r];
-        }
-        if (A.op == ACC_CNT_VALID) {
-#pragma unroll
-          for (int r = 0; r < A2_R; r++) if (ok[r]) atomicAdd((unsigned int *)(lb + slot[r] * 4), 1u);
-          continue;
-        }
         uint64_t opnd[A2_R];
-        load_operands(V, A.conv, rows, ok, opnd);
+        if (A.src < (int)npre) { // operands come from the prefetched registers
+          uint32_t vok = 0;
+          uint64_t raw[A2_R];
+          // wave-uniform select of the prefetched column (register arrays cannot be indexed dynamically)
+#pragma unroll
+          for (int v = 0; v < A2_NPRE; v++)
+            if (A.src == v) {
+              vok = cur.vok[v];
+#pragma unroll
+              for (int r = 0; r < A2_R; r++) raw[r] = cur.raw[v][r];
+            }
+#pragma unroll
+          for (int r = 0; r < A2_R; r++) ok[r] = live[r] && ((vok >> r) & 1);
+          if (A.op == ACC_CNT_VALID) {
+#pragma unroll
+            for (int r = 0; r < A2_R; r++) if (ok[r]) atomicAdd((unsigned int *)(lb + slot[r] * 4), 1u);
+            continue;
+          }
+          raw_operands(V.dtype, A.conv, raw, opnd);
+        } else {
+          if (V.validity) {
+#pragma unroll
+            for (int r = 0; r < A2_R; r++) ok[r] = live[r] && val_valid(V, rows[r]);
+          } else {
+#pragma unroll
+            for (int r = 0; r < A2_R; r++) ok[r] = live[r];
+          }
+          if (A.op == ACC_CNT_VALID) {
+#pragma unroll
+            for (int r = 0; r < A2_R; r++) if (ok[r]) atomicAdd((unsigned int *)(lb + slot[r] * 4), 1u);
+            continue;
+          }
+          load_operands(V, A.conv, rows, ok, opnd);
+        }
         switch (A.op) {
 #define APPLY(EXPR) _Pragma("unroll") for (int r = 0; r < A2_R; r++) if (ok[r]) { auto *p = lb + slot[r] * 8; EXPR; } break;
           case ACC_ADD_U64: APPLY(atomicAdd((unsigned long long *)p, (unsigned long long)opnd[r]))
@@ -218,10 +349,12 @@ k_lds_agg2(Plan P, TableRef T, const WorkItem *__restrict__ items, const uint32_
           default: break;
         }
       }
+      cur = nxt;
     }
     if (spilled) atomicAdd(&T.flags[FLAG_LDS_SPILL], spilled);
     __syncthreads();
 
+    if (diag & 4) continue; // DIAG: no emit
     if (W.direct) {
       // a whole partition: nobody else holds these keys -> dense result area, plain stores
       uint32_t mine = 0;
@@ -314,10 +447,12 @@ void launch_lds_agg2(const Plan &p, TableRef t, const WorkItem *items, const uin
     (void)hipFuncSetAttribute((const void *)k_lds_agg2<uint64_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
     attr_set = true;
   }
+  static int diag = -1;
+  if (diag < 0) { const char *e = getenv("PLHIP_DIAG"); diag = e ? atoi(e) : 0; }
   if (key_bytes == 4)
-    hipLaunchKernelGGL(k_lds_agg2<uint32_t>, dim3(grid), dim3(A2_BLOCK), bytes, s, p, t, items, n_items_dev, next_item_dev, lbits, dense_cap, slots);
+    hipLaunchKernelGGL(k_lds_agg2<uint32_t>, dim3(grid), dim3(A2_BLOCK), bytes, s, p, t, items, n_items_dev, next_item_dev, lbits, dense_cap, slots, (uint32_t)diag);
   else
-    hipLaunchKernelGGL(k_lds_agg2<uint64_t>, dim3(grid), dim3(A2_BLOCK), bytes, s, p, t, items, n_items_dev, next_item_dev, lbits, dense_cap, slots);
+    hipLaunchKernelGGL(k_lds_agg2<uint64_t>, dim3(grid), dim3(A2_BLOCK), bytes, s, p, t, items, n_items_dev, next_item_dev, lbits, dense_cap, slots, (uint32_t)diag);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -405,14 +540,6 @@ __global__ void __launch_bounds__(1024) k_part_plan(const uint32_t *__restrict__
   if (threadIdx.x == 1023) part_start[np] = sums[1023];
 }
 
-DEVINL uint32_t dtype_bytes(uint32_t dt) {
-  switch (dt) {
-    case PLHIP_I8: case PLHIP_U8: return 1;
-    case PLHIP_I16: case PLHIP_U16: return 2;
-    case PLHIP_I32: case PLHIP_U32: case PLHIP_F32: return 4;
-    default: return 8;
-  }
-}
 
 // Exclusive scan of v[0..n) in LDS by one workgroup of PART_BLOCK threads (n <= PART_MAX); `tmp` holds one
 // word per wave.  Returns with a barrier passed; v[] holds the exclusive prefix.
