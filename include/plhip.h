@@ -105,8 +105,23 @@ typedef enum plhip_strategy {
   PLHIP_STRATEGY_AUTO = 0,
   PLHIP_STRATEGY_GLOBAL = 1,     /* every row updates the HBM-resident table */
   PLHIP_STRATEGY_LDS = 2,        /* per-workgroup LDS tables, then one merge into the HBM table */
-  PLHIP_STRATEGY_PARTITIONED = 3 /* radix partition on hash bits, then one LDS table per partition */
+  PLHIP_STRATEGY_PARTITIONED = 3,/* radix partition on hash bits, then one LDS table per partition */
+  PLHIP_STRATEGY_DIRECT = 4,     /* LDS-only: per-workgroup LDS tables over row slices, merged in LDS (few groups) */
+  PLHIP_STRATEGY_TILESORT = 5    /* LDS-only: tiles sorted by hash partition in LDS, per-partition LDS tables, merged
+                                    in LDS (many groups); AUTO picks DIRECT / TILESORT when the query qualifies and
+                                    falls back to the strategies above otherwise */
 } plhip_strategy_t;
+
+/* Optional knowledge the caller has about the query.  struct_size = sizeof(plhip_options_t). */
+typedef struct plhip_options {
+  uint64_t struct_size;
+  int64_t n_groups_hint; /* upper bound on the number of groups, 0 = unknown.  For a Categorical key the
+                            reference knows it without looking at the data (the rev-map length it uses to size
+                            group_tuples_perfect, crates/polars-core/src/frame/group_by/perfect.rs:190-227);
+                            without a hint the library samples the keys, as estimate_unique_count does
+                            (crates/polars-lazy/src/physical_plan/executors/group_by_partitioned.rs:115-157).
+                            A wrong hint costs time, never correctness. */
+} plhip_options_t;
 
 typedef struct plhip_result plhip_result_t; /* opaque: a frame of output columns */
 typedef struct plhip_groups plhip_groups_t; /* opaque: GroupsProxy::Idx as CSR */
@@ -164,6 +179,11 @@ int32_t plhip_vec_hash(const plhip_column_t *keys, int32_t n_keys, uint64_t null
 int32_t plhip_group_by_agg(const plhip_column_t *keys, int32_t n_keys, const plhip_column_t *values,
                            int32_t n_values, const plhip_agg_t *aggs, int32_t n_aggs, uint32_t flags,
                            plhip_result_t **out);
+
+/* plhip_group_by_agg with caller-side knowledge (`opts` may be NULL). */
+int32_t plhip_group_by_agg_opts(const plhip_column_t *keys, int32_t n_keys, const plhip_column_t *values,
+                                int32_t n_values, const plhip_agg_t *aggs, int32_t n_aggs, uint32_t flags,
+                                const plhip_options_t *opts, plhip_result_t **out);
 
 /* ---- result frame accessors ------------------------------------------------------------------- */
 

@@ -32,7 +32,7 @@ FLAG_MAINTAIN_ORDER = 1
 FLAG_OUTPUT_DEVICE = 2
 FLAG_PARTIAL = 4
 
-STRATEGIES = {"auto": 0, "global": 1, "lds": 2, "partitioned": 3}
+STRATEGIES = {"auto": 0, "global": 1, "lds": 2, "partitioned": 3, "direct": 4, "tilesort": 5}
 
 STATUS_NAMES = {
     0: "OK", 1: "ComputeError", 2: "ShapeMismatch", 3: "OutOfMemory", 4: "UnsupportedDtype", 5: "HipError",
@@ -76,6 +76,12 @@ class AggStruct(C.Structure):
     """plhip_agg_t"""
 
     _fields_ = [("column", C.c_int32), ("kind", C.c_int32)]
+
+
+class OptionsStruct(C.Structure):
+    """plhip_options_t"""
+
+    _fields_ = [("struct_size", C.c_uint64), ("n_groups_hint", C.c_int64)]
 
 
 def np_dtype_code(dt) -> int:
@@ -139,6 +145,9 @@ def lib():
     L.plhip_vec_hash.restype = i32
     L.plhip_group_by_agg.argtypes = [P(ColumnStruct), i32, P(ColumnStruct), i32, P(AggStruct), i32, u32, P(vp)]
     L.plhip_group_by_agg.restype = i32
+    L.plhip_group_by_agg_opts.argtypes = [P(ColumnStruct), i32, P(ColumnStruct), i32, P(AggStruct), i32, u32,
+                                          P(OptionsStruct), P(vp)]
+    L.plhip_group_by_agg_opts.restype = i32
     L.plhip_result_num_rows.argtypes = [vp]
     L.plhip_result_num_rows.restype = i64
     L.plhip_result_num_columns.argtypes = [vp]
@@ -173,7 +182,7 @@ def check(status: int) -> None:
 
 EXPORTED_SYMBOLS = [
     "plhip_abi_version", "plhip_init", "plhip_last_error", "plhip_set_strategy", "plhip_last_strategy",
-    "plhip_last_kernel_ms", "plhip_vec_hash", "plhip_group_by_agg", "plhip_result_num_rows",
+    "plhip_last_kernel_ms", "plhip_vec_hash", "plhip_group_by_agg", "plhip_group_by_agg_opts", "plhip_result_num_rows",
     "plhip_result_num_columns", "plhip_result_column", "plhip_result_free", "plhip_group_tuples",
     "plhip_groups_num_groups", "plhip_groups_num_rows", "plhip_groups_buffers", "plhip_groups_free",
     "plhip_agg_groups",

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/plhip.h"
+#include "fast.hpp"
 #include "kernels.hpp"
 
 
@@ -47,7 +48,8 @@ struct Ctx {
   float total_ms = 0.f, dom_ms = 0.f, part_ms = 0.f, agg_ms = 0.f;
   std::string dom_kernel = "";
   int forced_strategy = -1; // -1: not set by the API (env / auto)
-  Scratch table, slots, sortkeys, flags, misc, rank, plans, items, part;
+  Scratch table, slots, sortkeys, flags, misc, rank, plans, items, part, dump, hdr, offs;
+  float k_ms[3] = {0.f, 0.f, 0.f}; // fast path: tile sort, fold, merge+emit
   uint32_t *host_flags = nullptr; // pinned, 64 bytes
 };
 
@@ -174,7 +176,42 @@ struct ResultCol {
   int dtype = 0;
   void *values = nullptr;   // device or host (malloc)
   uint8_t *validity = nullptr;
+  size_t vcap = 0, bcap = 0; // != 0: the device buffer came from the pool and goes back to it
 };
+
+namespace {
+// Device buffers of result frames are recycled: hipMalloc / hipFree cost more than a whole small query.
+struct DevPool {
+  std::mutex mu;
+  std::vector<std::pair<size_t, void *>> free_list;
+  size_t pooled = 0;
+  static size_t round_up(size_t b) { size_t c = 4096; while (c < b) c <<= 1; return c; }
+  hipError_t get(size_t bytes, void **p, size_t *cap) {
+    const size_t c = round_up(bytes);
+    {
+      std::lock_guard<std::mutex> g(mu);
+      for (size_t i = 0; i < free_list.size(); i++)
+        if (free_list[i].first == c) {
+          *p = free_list[i].second; *cap = c; pooled -= c;
+          free_list[i] = free_list.back(); free_list.pop_back();
+          return hipSuccess;
+        }
+    }
+    *cap = c;
+    return hipMalloc(p, c);
+  }
+  void put(void *p, size_t cap) {
+    if (!p) return;
+    {
+      std::lock_guard<std::mutex> g(mu);
+      if (pooled + cap <= ((size_t)4 << 30) && free_list.size() < 256) { free_list.emplace_back(cap, p); pooled += cap; return; }
+    }
+    hipFree(p);
+  }
+};
+DevPool g_pool;
+} // namespace
+
 struct plhip_result {
   std::vector<ResultCol> cols;
   int64_t n_rows = 0;
@@ -182,8 +219,10 @@ struct plhip_result {
   int device = 0;
   ~plhip_result() {
     for (auto &c : cols) {
-      if (on_device) { if (c.values) hipFree(c.values); if (c.validity) hipFree(c.validity); }
-      else { free(c.values); free(c.validity); }
+      if (on_device) {
+        if (c.vcap) g_pool.put(c.values, c.vcap); else if (c.values) hipFree(c.values);
+        if (c.bcap) g_pool.put(c.validity, c.bcap); else if (c.validity) hipFree(c.validity);
+      } else { free(c.values); free(c.validity); }
     }
   }
 };
@@ -437,6 +476,8 @@ int env_strategy() {
   if (!strcmp(e, "global")) return PLHIP_STRATEGY_GLOBAL;
   if (!strcmp(e, "lds")) return PLHIP_STRATEGY_LDS;
   if (!strcmp(e, "partitioned")) return PLHIP_STRATEGY_PARTITIONED;
+  if (!strcmp(e, "direct")) return PLHIP_STRATEGY_DIRECT;
+  if (!strcmp(e, "tilesort")) return PLHIP_STRATEGY_TILESORT;
   return PLHIP_STRATEGY_AUTO;
 }
 
@@ -598,6 +639,263 @@ int run_partitioned(const Plan &P, TableRef T, const PartitionSetup &PS, uint64_
 
 } // namespace
 
+
+namespace {
+
+// Hands the device-resident frame R (G rows) to the caller, copied to host memory unless
+// PLHIP_FLAG_OUTPUT_DEVICE is set.
+int finish_result(plhip_result *R, uint64_t G, uint32_t flags, plhip_result_t **out) {
+  Ctx &c = g_ctx;
+  int rc = PLHIP_OK;
+  if (!(flags & PLHIP_FLAG_OUTPUT_DEVICE)) {
+    plhip_result *H = new (std::nothrow) plhip_result();
+    if (!H) { delete R; return fail(PLHIP_ERR_OOM, "host allocation failed"); }
+    H->n_rows = R->n_rows; H->on_device = false; H->device = c.device;
+    for (auto &col : R->cols) {
+      ResultCol h;
+      h.dtype = col.dtype;
+      rc = copy_out(col.values, (size_t)G * dtype_width(col.dtype), &h.values);
+      if (!rc && col.validity) rc = copy_out(col.validity, (G / 64 + 1) * 8, (void **)&h.validity);
+      H->cols.push_back(h);
+      if (rc) { delete R; delete H; return rc; }
+    }
+    delete R;
+    R = H;
+  }
+  *out = R;
+  return PLHIP_OK;
+}
+
+int ceil_log2(uint64_t x) { int b = 0; while ((1ull << b) < x) b++; return b; }
+
+// The LDS-only pipeline (fast_path.hip).  Sets `handled` when it produced the result; otherwise the caller
+// runs the general path (stable order, wide key tuples, tiny inputs, more groups than one partition level
+// brings into LDS, or a cardinality estimate that turned out too low).
+int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t groups_hint, int strategy,
+             plhip_result_t **out, bool &handled) {
+  handled = false;
+  Ctx &c = g_ctx;
+  Plan &P = L.P;
+  const int64_t n = P.n_rows;
+  if ((flags & PLHIP_FLAG_MAINTAIN_ORDER) || L.KG.enabled || L.first_acc >= 0) return PLHIP_OK;
+  const bool forced = strategy == PLHIP_STRATEGY_DIRECT || strategy == PLHIP_STRATEGY_TILESORT;
+  if (n < 1 || (!forced && n < (1 << 15))) return PLHIP_OK;
+  for (int i = 1; i < P.n_accs; i++) // fold_batch loads a source column once for consecutive accumulators
+    for (int j = i; j > 0 && P.accs[j].src < P.accs[j - 1].src; j--) {
+      std::swap(P.accs[j], P.accs[j - 1]);
+      for (auto &o : L.outs) {
+        auto fix = [&](int32_t &x) { if (x == j) x = j - 1; else if (x == j - 1) x = j; };
+        if (o.kind != OUT_KEY) fix(o.acc);
+        fix(o.cnt_valid); fix(o.cnt_all);
+      }
+    }
+  const int key_bytes = packed_key_bytes(P, dk);
+  int keymode = 0;
+  uint64_t kxor = 0;
+  if (P.single_key && !dk[0].validity) {
+    const int w = dtype_width(dk[0].dtype);
+    if (w == 4) { keymode = 1; kxor = dk[0].dtype == PLHIP_I32 ? 0x80000000ull : 0ull; }
+    if (w == 8) { keymode = 2; kxor = dk[0].dtype == PLHIP_I64 ? 0x8000000000000000ull : 0ull; }
+  }
+  HIP_TRY(c.flags.reserve(64));
+  uint32_t *dflags = (uint32_t *)c.flags.p;
+  (void)hipGetLastError(); // launches below are checked with hipGetLastError: start clean
+
+  // ---- cardinality: the caller's hint (e.g. the category count of a categorical key) or a sample ----------
+  uint64_t g_est;
+  if (groups_hint > 0) g_est = (uint64_t)std::min<int64_t>(groups_hint, n);
+  else {
+    const int64_t ns = std::min<int64_t>(n, 1 << 14);
+    launch_estimate(P, ns, n / ns, dflags, c.stream);
+    HIP_TRY(hipGetLastError());
+    TableRef t{nullptr, 0, dflags};
+    uint32_t f[16];
+    int rc = read_flags(t, f);
+    if (rc) return rc;
+    const double d = f[FLAG_NGROUPS];
+    if (d >= 0.9 * (double)ns) g_est = (uint64_t)n;
+    else { // invert E[d] = G (1 - exp(-s / G))
+      double lo = d, hi = (double)n;
+      for (int it = 0; it < 60; it++) {
+        const double g = 0.5 * (lo + hi);
+        if (g * (1.0 - std::exp(-(double)ns / g)) < d) lo = g; else hi = g;
+      }
+      g_est = (uint64_t)std::min<double>((double)n, std::ceil(hi * 1.1));
+    }
+  }
+  g_est = std::max<uint64_t>(g_est, 1);
+
+  // ---- shape of the pipeline -----------------------------------------------------------------------------
+  const int cus = plhip_num_cus();
+  const size_t LDS_MAX = 150 * 1024; // fast_path.hip allows 152 KB of dynamic LDS per workgroup
+  bool direct = false;
+  uint32_t lbits = 0, block = 512;
+  {
+    const uint32_t lb = (uint32_t)std::max(6, ceil_log2(2 * g_est + 2));
+    if (lb <= 15 && fast_table_bytes(P, lb, key_bytes) <= LDS_MAX) { direct = true; lbits = lb; }
+  }
+  if (strategy == PLHIP_STRATEGY_TILESORT) direct = false;
+  if (strategy == PLHIP_STRATEGY_DIRECT && !direct) return PLHIP_OK;
+  const uint32_t pbits = 8, np = 1u << pbits;
+  uint32_t w = 1, S = 1, n_pg = 1, has_null_pg = 0, n_items = 0, mbits = 0;
+  int64_t rows_per_item = 0;
+  const uint32_t n_tiles = (uint32_t)((n + TS_TILE - 1) / TS_TILE);
+  if (direct) {
+    const size_t tb = fast_table_bytes(P, lbits, key_bytes);
+    int wg_per_cu;
+    if (tb <= 18 * 1024) { block = 256; wg_per_cu = 8; }
+    else if (tb <= 38 * 1024) { block = 512; wg_per_cu = 4; }
+    else if (tb <= 78 * 1024) { block = 1024; wg_per_cu = 2; }
+    else { block = 1024; wg_per_cu = 1; }
+    int64_t items = std::max<int64_t>(1, std::min<int64_t>((int64_t)cus * wg_per_cu, (n + 4095) / 4096));
+    rows_per_item = ((n + items - 1) / items + 1023) / 1024 * 1024;
+    n_items = (uint32_t)((n + rows_per_item - 1) / rows_per_item);
+    S = n_items;
+    const uint64_t entries = (uint64_t)n_items * std::min<uint64_t>(g_est, 1ull << lbits);
+    while (mbits < 6 && (entries >> mbits) > 16384) mbits++;
+  } else {
+    // groups per hash partition, with head-room for the sampling error and uneven partitions
+    const double gf = (double)g_est / np * 1.3 + 8;
+    uint32_t lb_max = 15;
+    while (lb_max > 6 && fast_table_bytes(P, lb_max, key_bytes) > 52 * 1024) lb_max--;
+    if (gf > 0.45 * (double)(1u << lb_max)) { // bigger tables, one workgroup per CU
+      lb_max = 15;
+      while (lb_max > 6 && fast_table_bytes(P, lb_max, key_bytes) > LDS_MAX) lb_max--;
+      block = 1024;
+      if (gf > 0.45 * (double)(1u << lb_max)) return PLHIP_OK; // needs a second partition level: general path
+    }
+    while (w < np && gf * (2 * w) <= 0.45 * (double)(1u << lb_max)) w *= 2;
+    lbits = 6;
+    while (gf * w > 0.45 * (double)(1u << lbits)) lbits++;
+    has_null_pg = (P.single_key && dk[0].validity) ? 1 : 0;
+    n_pg = np / w + has_null_pg;
+    S = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(n_tiles, (4 * cus + n_pg - 1) / n_pg));
+    n_items = n_pg * S;
+  }
+  const uint32_t lslots = (1u << lbits) + 2;
+  const uint64_t out_cap = direct ? (uint64_t)lslots << mbits : (uint64_t)n_pg * lslots;
+
+  // ---- scratch ---------------------------------------------------------------------------------------------
+  DumpRef D{};
+  D.cap = lslots;
+  D.item_stride = fast_dump_stride(P, lslots, key_bytes);
+  HIP_TRY(c.dump.reserve(D.item_stride * n_items + 256));
+  HIP_TRY(c.hdr.reserve((size_t)n_items * sizeof(DumpHdr)));
+  D.base = (uint8_t *)c.dump.p;
+  D.hdr = (DumpHdr *)c.hdr.p;
+  PartOut O{};
+  if (!direct) {
+    O.key_bytes = (uint32_t)key_bytes;
+    size_t bytes = ((size_t)n * key_bytes + 511) & ~(size_t)255;
+    size_t off_val[PLHIP_MAX_VALS], off_valid[PLHIP_MAX_VALS];
+    for (int v = 0; v < P.n_vals; v++) {
+      off_val[v] = bytes;
+      bytes += ((size_t)n * dtype_width((int)P.vals[v].dtype) + 511) & ~(size_t)255;
+      off_valid[v] = bytes;
+      if (P.vals[v].validity) bytes += ((size_t)n + 511) & ~(size_t)255;
+    }
+    HIP_TRY(c.part.reserve(bytes + 256));
+    HIP_TRY(c.offs.reserve((size_t)(np + 2) * n_tiles * 4));
+    uint8_t *pb = (uint8_t *)c.part.p;
+    O.keys = pb;
+    for (int v = 0; v < P.n_vals; v++) {
+      O.vals[v] = pb + off_val[v];
+      O.valid[v] = P.vals[v].validity ? pb + off_valid[v] : nullptr;
+    }
+  }
+
+  // ---- outputs (sized by the table capacities; G is only known at the end) ---------------------------------
+  plhip_result *R = new (std::nothrow) plhip_result();
+  if (!R) return fail(PLHIP_ERR_OOM, "host allocation failed");
+  R->on_device = true;
+  R->device = c.device;
+  OutPlan OP{};
+  OP.n_outs = (int)L.outs.size();
+  HIP_TRY(hipEventRecord(c.ev[0], c.stream));
+  HIP_TRY(hipMemsetAsync(dflags, 0, 64, c.stream));
+  for (size_t i = 0; i < L.outs.size(); i++) {
+    OutSpec o = L.outs[i];
+    ResultCol col;
+    col.dtype = (int)o.dtype;
+    hipError_t e = g_pool.get((size_t)out_cap * dtype_width((int)o.dtype), &col.values, &col.vcap);
+    if (e == hipSuccess && o.validity) {
+      e = g_pool.get((size_t)(out_cap / 64 + 2) * 8, (void **)&col.validity, &col.bcap);
+      if (e == hipSuccess) e = hipMemsetAsync(col.validity, 0, (size_t)(out_cap / 64 + 2) * 8, c.stream);
+    }
+    R->cols.push_back(col);
+    if (e != hipSuccess) { delete R; return fail_hip(e, "hipMalloc(output)"); }
+    o.values = (uint8_t *)col.values;
+    o.validity = col.validity;
+    OP.outs[i] = o;
+  }
+  hipError_t e = c.plans.reserve(sizeof(OutPlan));
+  if (e == hipSuccess) e = hipMemcpyAsync(c.plans.p, &OP, sizeof(OutPlan), hipMemcpyHostToDevice, c.stream);
+  if (e != hipSuccess) { delete R; return fail_hip(e, "output plan"); }
+
+  // ---- launches --------------------------------------------------------------------------------------------
+  hipEventRecord(c.ev[1], c.stream);
+  if (direct) {
+    bool quad = true;
+    auto aligned = [](const uint8_t *p, int wd) { return ((uintptr_t)p % (size_t)(4 * wd)) == 0; };
+    if (keymode && !aligned(dk[0].values, dtype_width(dk[0].dtype))) quad = false;
+    for (int v = 0; v < P.n_vals; v++) if (!aligned(P.vals[v].values, dtype_width((int)P.vals[v].dtype))) quad = false;
+    FoldRowsArgs A{};
+    A.D = D; A.flags = dflags; A.rows_per_item = rows_per_item; A.kxor = kxor; A.lbits = lbits; A.keymode = keymode;
+    hipEventRecord(c.ev[4], c.stream);
+    launch_fold_rows(P, A, key_bytes, quad, n_items, block, c.stream);
+    if ((e = hipGetLastError()) != hipSuccess) { delete R; return fail_hip(e, "k_fold_rows launch"); }
+    c.strategy = "direct";
+  } else {
+    launch_tile_sort(P, O, pbits, n_tiles, (uint32_t *)c.offs.p, keymode, kxor, key_bytes, c.stream);
+    if ((e = hipGetLastError()) != hipSuccess) { delete R; return fail_hip(e, "k_tile_sort launch"); }
+    hipEventRecord(c.ev[4], c.stream);
+    Plan P2 = P; // the fold pass reads the sorted copies
+    P2.prepacked = 1;
+    P2.single_key = 0;
+    P2.keys[0].values = O.keys; P2.keys[0].validity = nullptr; P2.keys[0].boff = 0;
+    P2.keys[0].dtype = key_bytes == 4 ? PLHIP_U32 : PLHIP_U64;
+    for (int v = 0; v < P.n_vals; v++) {
+      P2.vals[v].values = O.vals[v]; P2.vals[v].validity = O.valid[v]; P2.vals[v].boff = 0; P2.vals[v].valid_bytes = 1;
+    }
+    FoldRunsArgs A{};
+    A.D = D; A.flags = dflags; A.offs = (const uint32_t *)c.offs.p; A.lbits = lbits; A.np = np; A.w = w; A.n_pg = n_pg;
+    A.has_null_pg = has_null_pg; A.S = S; A.n_tiles = n_tiles;
+    launch_fold_runs(P2, A, key_bytes, block, c.stream);
+    if ((e = hipGetLastError()) != hipSuccess) { delete R; return fail_hip(e, "k_fold_runs launch"); }
+    c.strategy = "tilesort";
+  }
+  hipEventRecord(c.ev[5], c.stream);
+  MergeArgs M{};
+  M.D = D; M.flags = dflags; M.out_cap = out_cap; M.lbits = lbits; M.S = S; M.mbits = mbits;
+  launch_merge_emit(P, M, (const OutPlan *)c.plans.p, key_bytes, direct ? 1u : n_pg, block, c.stream);
+  if ((e = hipGetLastError()) != hipSuccess) { delete R; return fail_hip(e, "k_merge_emit launch"); }
+  hipEventRecord(c.ev[2], c.stream);
+  hipEventRecord(c.ev[3], c.stream);
+  e = hipGetLastError();
+  uint32_t fl[16] = {0};
+  if (e == hipSuccess) {
+    TableRef t{nullptr, 0, dflags};
+    int rc = read_flags(t, fl);
+    if (rc) { delete R; return rc; }
+  } else { delete R; return fail_hip(e, "group-by kernels"); }
+  hipEventElapsedTime(&c.total_ms, c.ev[0], c.ev[3]);
+  c.k_ms[0] = 0.f;
+  if (!direct) hipEventElapsedTime(&c.k_ms[0], c.ev[1], c.ev[4]);
+  hipEventElapsedTime(&c.k_ms[1], c.ev[4], c.ev[5]);
+  hipEventElapsedTime(&c.k_ms[2], c.ev[5], c.ev[2]);
+  const char *names[3] = {"k_tile_sort", direct ? "k_fold_rows" : "k_fold_runs", "k_merge_emit"};
+  int dom = 0;
+  for (int i = 1; i < 3; i++) if (c.k_ms[i] > c.k_ms[dom]) dom = i;
+  c.dom_ms = c.k_ms[dom]; c.dom_kernel = names[dom]; c.part_ms = c.k_ms[0]; c.agg_ms = c.k_ms[1];
+  if (fl[FLAG_OVERFLOW]) { delete R; return PLHIP_OK; } // estimate too low: the general path redoes the query
+  const uint64_t G = fl[FLAG_NGROUPS];
+  R->n_rows = (int64_t)G;
+  handled = true;
+  return finish_result(R, G, flags, out);
+}
+
+} // namespace
+
 // ---------------------------------------------------------------------------------------------------------
 // library entry points
 // ---------------------------------------------------------------------------------------------------------
@@ -620,7 +918,7 @@ int32_t plhip_init(int32_t device_id) {
 const char *plhip_last_error(void) { return g_ctx.err.c_str(); }
 
 int32_t plhip_set_strategy(int32_t strategy) {
-  if (strategy < 0 || strategy > PLHIP_STRATEGY_PARTITIONED) return fail(PLHIP_ERR_INVALID, "bad strategy");
+  if (strategy < 0 || strategy > PLHIP_STRATEGY_TILESORT) return fail(PLHIP_ERR_INVALID, "bad strategy");
   g_ctx.forced_strategy = strategy;
   return PLHIP_OK;
 }
@@ -669,6 +967,12 @@ int32_t plhip_vec_hash(const plhip_column_t *keys, int32_t n_keys, uint64_t null
 int32_t plhip_group_by_agg(const plhip_column_t *keys, int32_t n_keys, const plhip_column_t *values,
                            int32_t n_values, const plhip_agg_t *aggs, int32_t n_aggs, uint32_t flags,
                            plhip_result_t **out) {
+  return plhip_group_by_agg_opts(keys, n_keys, values, n_values, aggs, n_aggs, flags, nullptr, out);
+}
+
+int32_t plhip_group_by_agg_opts(const plhip_column_t *keys, int32_t n_keys, const plhip_column_t *values,
+                                int32_t n_values, const plhip_agg_t *aggs, int32_t n_aggs, uint32_t flags,
+                                const plhip_options_t *opts, plhip_result_t **out) {
   if (!out) return fail(PLHIP_ERR_INVALID, "out is NULL");
   *out = nullptr;
   // group_by/mod.rs:59-62
@@ -702,6 +1006,14 @@ int32_t plhip_group_by_agg(const plhip_column_t *keys, int32_t n_keys, const plh
 
   // ---- strategy ------------------------------------------------------------------------------------
   int strategy = c.forced_strategy > 0 ? c.forced_strategy : env_strategy();
+  if (strategy == PLHIP_STRATEGY_AUTO || strategy == PLHIP_STRATEGY_DIRECT || strategy == PLHIP_STRATEGY_TILESORT) {
+    int64_t hint = 0;
+    if (opts && opts->struct_size >= sizeof(plhip_options_t)) hint = opts->n_groups_hint;
+    bool handled = false;
+    if ((rc = run_fast(L, dk, flags, hint, strategy, out, handled))) return rc;
+    if (handled) return PLHIP_OK;
+    strategy = PLHIP_STRATEGY_AUTO;
+  }
   uint64_t g_est = (uint64_t)n;
   if (n >= (1 << 14) && (rc = estimate_groups(P, g_est))) return rc;
   const int key_bytes = packed_key_bytes(P, dk);
@@ -844,23 +1156,7 @@ int32_t plhip_group_by_agg(const plhip_column_t *keys, int32_t n_keys, const plh
     } else { c.dom_ms = t_all; c.part_ms = 0.f; c.agg_ms = t_all; }
   }
 
-  if (!(flags & PLHIP_FLAG_OUTPUT_DEVICE)) {
-    plhip_result *H = new (std::nothrow) plhip_result();
-    if (!H) { delete R; return fail(PLHIP_ERR_OOM, "host allocation failed"); }
-    H->n_rows = R->n_rows; H->on_device = false; H->device = c.device;
-    for (auto &col : R->cols) {
-      ResultCol h;
-      h.dtype = col.dtype;
-      rc = copy_out(col.values, (size_t)G * dtype_width(col.dtype), &h.values);
-      if (!rc && col.validity) rc = copy_out(col.validity, (G / 64 + 1) * 8, (void **)&h.validity);
-      H->cols.push_back(h);
-      if (rc) { delete R; delete H; return rc; }
-    }
-    delete R;
-    R = H;
-  }
-  *out = R;
-  return PLHIP_OK;
+  return finish_result(R, G, flags, out);
 }
 
 int64_t plhip_result_num_rows(const plhip_result_t *r) { return r ? r->n_rows : -1; }

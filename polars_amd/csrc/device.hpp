@@ -186,3 +186,89 @@ DEVINL uint64_t gtable_slot(uint64_t *keys, uint64_t cap, uint32_t *flags, uint6
   flags[0] = 1;
   return ~0ull;
 }
+
+// ---- accumulators -> the reference's output columns (shared by k_finalize and the fast path's merge) ----
+DEVINL void store_by_dtype_int(uint8_t *out, uint32_t dtype, uint64_t i, uint64_t v) {
+  switch (dtype) {
+    case PLHIP_I8: case PLHIP_U8: out[i] = (uint8_t)v; break;
+    case PLHIP_I16: case PLHIP_U16: ((uint16_t *)out)[i] = (uint16_t)v; break;
+    case PLHIP_I32: case PLHIP_U32: case PLHIP_F32: ((uint32_t *)out)[i] = (uint32_t)v; break;
+    default: ((uint64_t *)out)[i] = v; break;
+  }
+}
+DEVINL void store_float(uint8_t *out, uint32_t dtype, uint64_t i, double v) {
+  if (dtype == PLHIP_F32) ((float *)out)[i] = (float)v;
+  else ((double *)out)[i] = v;
+}
+
+// Output key column `S.acc` of group i from the packed key word.  Returns the key's validity.
+DEVINL bool finalize_key(const Plan &P, const OutSpec &S, uint64_t packed, bool null_slot, bool sentinel_slot, uint64_t i) {
+  const KeySpec &K = P.keys[S.acc];
+  bool valid = true;
+  uint64_t norm;
+  if (P.single_key) {
+    valid = !null_slot;
+    norm = sentinel_slot ? PLHIP_EMPTY_KEY : packed;
+  } else {
+    uint64_t code = K.bits >= 64 ? packed : ((packed >> K.shift) & ((1ull << K.bits) - 1));
+    if (K.nullable) { valid = code != 0; code -= 1; }
+    norm = code + K.minv;
+  }
+  store_by_dtype_int(S.values, K.dtype, i, valid ? key_denorm(norm, K.dtype) : 0);
+  return valid;
+}
+
+// One aggregate output (everything except OUT_KEY) of group i.  Returns its validity.
+DEVINL bool finalize_value(const OutSpec &S, uint64_t acc, uint32_t cnt_all, uint32_t cnt_valid, uint64_t i) {
+  bool valid = true;
+  switch (S.kind) {
+    case OUT_SUM_INT: // wrapping sum in the output width (aggregations/mod.rs:622-651); never null
+      store_by_dtype_int(S.values, S.dtype, i, acc);
+      break;
+    case OUT_SUM_F64:
+      store_float(S.values, S.dtype, i, __longlong_as_double((long long)acc));
+      break;
+    case OUT_MEAN_INT: case OUT_MEAN_UINT: { // aggregations/mod.rs:941-991
+      valid = cnt_valid != 0;
+      const double sum = S.kind == OUT_MEAN_INT ? (double)(long long)acc : (double)acc;
+      store_float(S.values, S.dtype, i, valid ? sum / (double)cnt_valid : 0.0);
+      break;
+    }
+    case OUT_MEAN_F64: { // aggregations/mod.rs:701-742: f32 sums are f32 before the division
+      valid = cnt_valid != 0;
+      double sum = __longlong_as_double((long long)acc);
+      if (S.dtype == PLHIP_F32) sum = (double)(float)sum;
+      store_float(S.values, S.dtype, i, valid ? sum / (double)cnt_valid : 0.0);
+      break;
+    }
+    case OUT_MIN_INT:
+      valid = S.cnt_valid >= 0 ? cnt_valid != 0 : true;
+      store_by_dtype_int(S.values, S.dtype, i, valid ? acc : 0);
+      break;
+    case OUT_FMIN: case OUT_FMAX: {
+      // aggregations/mod.rs:459-620 with TakeExtremum :240-259: fold from T::MAX (min) / T::MIN (max)
+      // ignoring NaN, so +-inf and all-NaN groups clamp to the init; a 1-row group returns its value.
+      valid = cnt_valid != 0;
+      const bool is_min = S.kind == OUT_FMIN;
+      const double big = S.dtype == PLHIP_F32 ? 3.4028234663852886e38 : 1.7976931348623157e308;
+      double r = 0.0;
+      if (valid) {
+        const bool only_nan = is_min ? acc == ~0ull : acc == 0ull;
+        if (cnt_all == 1) r = only_nan ? __longlong_as_double(0x7ff8000000000000ll) : f64_from_ordered(acc);
+        else if (only_nan) r = is_min ? big : -big;
+        else {
+          r = f64_from_ordered(acc);
+          if (is_min && r > big) r = big;
+          if (!is_min && r < -big) r = -big;
+        }
+      }
+      store_float(S.values, S.dtype, i, r);
+      break;
+    }
+    case OUT_COUNT: ((uint32_t *)S.values)[i] = (uint32_t)acc; break;
+    case OUT_RAW_U64: ((uint64_t *)S.values)[i] = acc; break;
+    case OUT_RAW_U32_AS_U64: ((uint64_t *)S.values)[i] = acc; break;
+    default: break;
+  }
+  return valid;
+}

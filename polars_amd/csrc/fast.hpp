@@ -1,0 +1,80 @@
+// fast.hpp — the LDS-only aggregation pipeline (fast_path.hip): no global atomics on the row path.
+//
+//   few groups   : k_fold_rows   (row slices -> per-workgroup LDS tables -> compact dumps)
+//                  k_merge_emit  (dumps -> merged LDS tables -> output columns)
+//   many groups  : k_tile_sort   (each 8192-row tile is sorted by hash partition in LDS and written back
+//                                 tile-contiguous; no histogram pre-pass, no global scatter, no atomics)
+//                  k_fold_runs   (one partition group x tile segment per workgroup: gathers its runs from
+//                                 every tile, LDS table, compact dump)
+//                  k_merge_emit
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.hpp"
+#include "plan.hpp"
+
+#define TS_BLOCK 1024
+#define TS_R 8
+#define TS_TILE (TS_BLOCK * TS_R) // rows per sorted tile
+#define TS_MAX_PBITS 9 // np + 1 histogram entries must not exceed TS_BLOCK (one per thread in the scan)
+
+struct DumpHdr {
+  uint32_t n_hash;   // entries with ordinary keys
+  uint32_t has_sent; // then one entry for the key equal to the empty sentinel
+  uint32_t has_null; // then one entry for the null key
+  uint32_t pad;
+};
+
+// Compact copies of LDS tables: item i owns [base + i * item_stride, ...): keys[cap], then every
+// accumulator's array[cap] (16-byte aligned each).
+struct DumpRef {
+  uint8_t *base;
+  DumpHdr *hdr;
+  uint64_t item_stride;
+  uint32_t cap;
+  uint32_t pad;
+};
+
+struct FoldRowsArgs {
+  DumpRef D;
+  uint32_t *flags;
+  int64_t rows_per_item; // multiple of 4
+  uint64_t kxor;
+  uint32_t lbits;
+  int32_t keymode; // 0: row_packed_key, 1: plain 4-byte column, 2: plain 8-byte column
+};
+
+struct FoldRunsArgs {
+  DumpRef D;
+  uint32_t *flags;
+  const uint32_t *offs; // [(np + 2)][n_tiles]: start of partition p inside tile t; row np + 1 = rows in the tile
+  uint32_t lbits;
+  uint32_t np;       // hash partitions of the tile sort (partition np = null keys)
+  uint32_t w;        // partitions per group
+  uint32_t n_pg;     // partition groups (the last one is the null partition when has_null_pg)
+  uint32_t has_null_pg;
+  uint32_t S;        // tile segments per group
+  uint32_t n_tiles;
+  uint32_t pad;
+};
+
+struct MergeArgs {
+  DumpRef D;
+  uint32_t *flags;
+  uint64_t out_cap; // rows the output buffers can hold
+  uint32_t lbits;
+  uint32_t S;     // dumps per partition group
+  uint32_t mbits; // merge workgroups per partition group = 1 << mbits (split by key hash)
+  uint32_t pad;
+};
+
+size_t fast_table_bytes(const Plan &p, uint32_t lbits, int key_bytes);  // LDS bytes of a fold / merge workgroup
+uint64_t fast_dump_stride(const Plan &p, uint32_t cap, int key_bytes);
+void launch_fold_rows(const Plan &p, const FoldRowsArgs &a, int key_bytes, bool quad, uint32_t n_items, uint32_t block, hipStream_t s);
+void launch_tile_sort(const Plan &p, const PartOut &o, uint32_t pbits, uint32_t n_tiles, uint32_t *offs, int keymode, uint64_t kxor,
+                      int key_bytes, hipStream_t s);
+void launch_fold_runs(const Plan &p2, const FoldRunsArgs &a, int key_bytes, uint32_t block, hipStream_t s);
+void launch_merge_emit(const Plan &p, const MergeArgs &a, const OutPlan *o_dev, int key_bytes, uint32_t n_pg, uint32_t block, hipStream_t s);
+// distinct keys among `n_sample` rows taken every `stride` rows -> flags[FLAG_NGROUPS]
+void launch_estimate(const Plan &p, int64_t n_sample, int64_t stride, uint32_t *flags, hipStream_t s);

@@ -262,7 +262,7 @@ def last_kernel_ms() -> tuple[float, float, str]:
 
 
 def group_by_agg_raw(keys: Sequence[Column], values: Sequence[Column], aggs: Sequence[tuple[int, int]],
-                     flags: int = 0):
+                     flags: int = 0, n_groups_hint: int = 0):
     """Thin call of plhip_group_by_agg.  Returns (handle, [ColumnStruct...]); the caller must
     plhip_result_free(handle).  Used by bench.py (device-resident outputs) and by _execute."""
     L = _ffi.lib()
@@ -270,7 +270,9 @@ def group_by_agg_raw(keys: Sequence[Column], values: Sequence[Column], aggs: Seq
     varr = (_ffi.ColumnStruct * max(1, len(values)))(*[v.struct() for v in values])
     aarr = (_ffi.AggStruct * max(1, len(aggs)))(*[_ffi.AggStruct(c, k) for c, k in aggs])
     handle = C.c_void_p()
-    _ffi.check(L.plhip_group_by_agg(karr, len(keys), varr, len(values), aarr, len(aggs), flags, C.byref(handle)))
+    opts = _ffi.OptionsStruct(C.sizeof(_ffi.OptionsStruct), int(n_groups_hint))
+    _ffi.check(L.plhip_group_by_agg_opts(karr, len(keys), varr, len(values), aarr, len(aggs), flags, C.byref(opts),
+                                         C.byref(handle)))
     cols = []
     for i in range(L.plhip_result_num_columns(handle)):
         cs = _ffi.ColumnStruct()

@@ -12,7 +12,7 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 KA = util.load_known_answers()
-STRATEGIES = ["auto", "global", "lds", "partitioned"]
+STRATEGIES = ["auto", "global", "lds", "partitioned", "direct", "tilesort"]
 
 
 @pytest.fixture(autouse=True)
@@ -91,6 +91,9 @@ def rand_col(rng, name, dt, n, card=None, null_frac=0.0, nan_frac=0.0, lo=None, 
 def check_parity(oracle, keys, values, aggs, strategy="auto", maintain_order=False, what=""):
     want, _ = oracle.group_by_agg(keys, values, aggs, maintain_order=maintain_order)
     got = run_product(keys, values, aggs, maintain_order, strategy)
+    ran = pa.last_strategy()
+    if strategy in ("direct", "tilesort") and ran != strategy:
+        FELL_BACK.append((what, strategy, ran))
     g, w = util.frame_to_np(got), util.oracle_to_np(want)
     if maintain_order:  # row order itself is part of the contract
         for (gv, _), (wv, _) in zip(g[:len(keys)], w[:len(keys)]):
@@ -100,6 +103,16 @@ def check_parity(oracle, keys, values, aggs, strategy="auto", maintain_order=Fal
 
 
 ALL_AGGS = ["sum", "mean", "min", "max", "count"]
+FELL_BACK: list = []  # (case, forced strategy, strategy that ran): the LDS-only pipeline declined the query
+
+
+def test_zz_fast_path_coverage():
+    """The forced LDS-only strategies may decline (stable order, wide key tuples, more groups than fit);
+    they must not decline the plain cases."""
+    declined = {w for w, _, _ in FELL_BACK}
+    allowed = ("multi-key", "stable", "card=None", "n=0")
+    bad = [d for d in declined if not any(d.startswith(a) or a in d for a in allowed)]
+    assert not bad, f"fast path declined: {sorted(bad)}"
 
 
 @pytest.mark.parametrize("strategy", STRATEGIES)
