@@ -150,6 +150,10 @@ const char *plhip_last_strategy(void);
  * part of it spent in the dominant kernel.  Used by bench.py for `roofline.achieved`. */
 int32_t plhip_last_kernel_ms(float *total_ms, float *dominant_ms, const char **dominant_kernel);
 
+/* Per-kernel device time of the last call when it ran the LDS-only pipeline (strategy "direct" /
+ * "tilesort"): k_tile_sort (0 for "direct"), k_fold_rows / k_fold_runs, k_merge_emit. */
+int32_t plhip_last_kernel_breakdown(float *tile_sort_ms, float *fold_ms, float *merge_emit_ms);
+
 /* ---- hashing ------------------------------------------------------------------------------------ */
 
 /* VecHash::vec_hash on keys[0] then VecHash::vec_hash_combine for keys[1..]

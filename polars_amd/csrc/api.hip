@@ -705,15 +705,17 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
   uint64_t g_est;
   if (groups_hint > 0) g_est = (uint64_t)std::min<int64_t>(groups_hint, n);
   else {
-    const int64_t ns = std::min<int64_t>(n, 1 << 14);
-    launch_estimate(P, ns, n / ns, dflags, c.stream);
+    const int64_t ns = std::min<int64_t>(n, 1 << 18);
+    const uint32_t est_wgs = ns <= (1 << 14) ? 1u : 16u; // 16 LDS sets of 32K slots hold any 256K-key sample
+    HIP_TRY(hipMemsetAsync(dflags, 0, 64, c.stream));
+    launch_estimate(P, ns, n / ns, est_wgs, dflags, c.stream);
     HIP_TRY(hipGetLastError());
     TableRef t{nullptr, 0, dflags};
     uint32_t f[16];
     int rc = read_flags(t, f);
     if (rc) return rc;
     const double d = f[FLAG_NGROUPS];
-    if (d >= 0.9 * (double)ns) g_est = (uint64_t)n;
+    if (d >= 0.95 * (double)ns) g_est = (uint64_t)n;
     else { // invert E[d] = G (1 - exp(-s / G))
       double lo = d, hi = (double)n;
       for (int it = 0; it < 60; it++) {
@@ -727,9 +729,9 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
 
   // ---- shape of the pipeline -----------------------------------------------------------------------------
   const int cus = plhip_num_cus();
-  const size_t LDS_MAX = 150 * 1024; // fast_path.hip allows 152 KB of dynamic LDS per workgroup
+  const size_t LDS_MAX = 136 * 1024; // fast_path.hip allows 140 KB of dynamic LDS per workgroup
   bool direct = false;
-  uint32_t lbits = 0, block = 512;
+  uint32_t lbits = 0, block = 1024;
   {
     const uint32_t lb = (uint32_t)std::max(6, ceil_log2(2 * g_est + 2));
     if (lb <= 15 && fast_table_bytes(P, lb, key_bytes) <= LDS_MAX) { direct = true; lbits = lb; }
@@ -741,38 +743,38 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
   int64_t rows_per_item = 0;
   const uint32_t n_tiles = (uint32_t)((n + TS_TILE - 1) / TS_TILE);
   if (direct) {
+    // the fold kernel holds ~112 VGPRs: 4 waves per SIMD = 1024 threads per CU, as few workgroups as the
+    // table size allows (each workgroup dumps its table once)
     const size_t tb = fast_table_bytes(P, lbits, key_bytes);
+    // pre-instantiated shapes need < 64 VGPRs (8 waves per SIMD), the run-time shape ~112 (4 waves per SIMD)
+    const bool st = fast_shape_id(P) >= 0;
     int wg_per_cu;
-    if (tb <= 18 * 1024) { block = 256; wg_per_cu = 8; }
-    else if (tb <= 38 * 1024) { block = 512; wg_per_cu = 4; }
-    else if (tb <= 78 * 1024) { block = 1024; wg_per_cu = 2; }
+    if (tb <= 18 * 1024 && st) { block = 256; wg_per_cu = 8; }
+    else if (tb <= 36 * 1024) { block = st ? 512 : 256; wg_per_cu = 4; }
+    else if (tb <= 72 * 1024) { block = st ? 1024 : 512; wg_per_cu = 2; }
     else { block = 1024; wg_per_cu = 1; }
-    int64_t items = std::max<int64_t>(1, std::min<int64_t>((int64_t)cus * wg_per_cu, (n + 4095) / 4096));
-    rows_per_item = ((n + items - 1) / items + 1023) / 1024 * 1024;
+    const int64_t step = (int64_t)block * (st ? 8 : 4); // rows one workgroup folds per loop trip
+    int64_t items = std::max<int64_t>(1, std::min<int64_t>((int64_t)cus * wg_per_cu, (n + step - 1) / step));
+    rows_per_item = ((n + items - 1) / items + step - 1) / step * step;
     n_items = (uint32_t)((n + rows_per_item - 1) / rows_per_item);
     S = n_items;
     const uint64_t entries = (uint64_t)n_items * std::min<uint64_t>(g_est, 1ull << lbits);
-    while (mbits < 6 && (entries >> mbits) > 16384) mbits++;
+    while (mbits < FP_MAX_MBITS && (entries >> mbits) > 4096) mbits++;
   } else {
     // groups per hash partition, with head-room for the sampling error and uneven partitions
     const double gf = (double)g_est / np * 1.3 + 8;
     uint32_t lb_max = 15;
-    while (lb_max > 6 && fast_table_bytes(P, lb_max, key_bytes) > 52 * 1024) lb_max--;
-    if (gf > 0.45 * (double)(1u << lb_max)) { // bigger tables, one workgroup per CU
-      lb_max = 15;
-      while (lb_max > 6 && fast_table_bytes(P, lb_max, key_bytes) > LDS_MAX) lb_max--;
-      block = 1024;
-      if (gf > 0.45 * (double)(1u << lb_max)) return PLHIP_OK; // needs a second partition level: general path
-    }
-    while (w < np && gf * (2 * w) <= 0.45 * (double)(1u << lb_max)) w *= 2;
+    while (lb_max > 6 && fast_table_bytes(P, lb_max, key_bytes) > LDS_MAX) lb_max--;
+    if (gf > 0.45 * (double)(1u << lb_max)) return PLHIP_OK; // needs a second partition level: general path
     lbits = 6;
     while (gf * w > 0.45 * (double)(1u << lbits)) lbits++;
     has_null_pg = (P.single_key && dk[0].validity) ? 1 : 0;
     n_pg = np / w + has_null_pg;
-    S = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(n_tiles, (4 * cus + n_pg - 1) / n_pg));
+    S = 1; // one workgroup per partition: it writes the output columns itself
     n_items = n_pg * S;
+    block = 1024;
   }
-  const uint32_t lslots = (1u << lbits) + 2;
+  const uint32_t lslots = (1u << lbits) + 66; // hashed slots + sentinel + null + 64 trash slots (fast_path.hip)
   const uint64_t out_cap = direct ? (uint64_t)lslots << mbits : (uint64_t)n_pg * lslots;
 
   // ---- scratch ---------------------------------------------------------------------------------------------
@@ -840,7 +842,7 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
     if (keymode && !aligned(dk[0].values, dtype_width(dk[0].dtype))) quad = false;
     for (int v = 0; v < P.n_vals; v++) if (!aligned(P.vals[v].values, dtype_width((int)P.vals[v].dtype))) quad = false;
     FoldRowsArgs A{};
-    A.D = D; A.flags = dflags; A.rows_per_item = rows_per_item; A.kxor = kxor; A.lbits = lbits; A.keymode = keymode;
+    A.D = D; A.flags = dflags; A.rows_per_item = rows_per_item; A.kxor = kxor; A.lbits = lbits; A.keymode = keymode; A.mbits = mbits;
     hipEventRecord(c.ev[4], c.stream);
     launch_fold_rows(P, A, key_bytes, quad, n_items, block, c.stream);
     if ((e = hipGetLastError()) != hipSuccess) { delete R; return fail_hip(e, "k_fold_rows launch"); }
@@ -850,25 +852,24 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
     if ((e = hipGetLastError()) != hipSuccess) { delete R; return fail_hip(e, "k_tile_sort launch"); }
     hipEventRecord(c.ev[4], c.stream);
     Plan P2 = P; // the fold pass reads the sorted copies
-    P2.prepacked = 1;
-    P2.single_key = 0;
-    P2.keys[0].values = O.keys; P2.keys[0].validity = nullptr; P2.keys[0].boff = 0;
-    P2.keys[0].dtype = key_bytes == 4 ? PLHIP_U32 : PLHIP_U64;
-    for (int v = 0; v < P.n_vals; v++) {
+    for (int v = 0; v < P.n_vals; v++) { // the key specs stay: k_fold_runs reads the packed keys from A.pkeys
       P2.vals[v].values = O.vals[v]; P2.vals[v].validity = O.valid[v]; P2.vals[v].boff = 0; P2.vals[v].valid_bytes = 1;
     }
     FoldRunsArgs A{};
+    A.pkeys = O.keys; A.out_cap = out_cap;
     A.D = D; A.flags = dflags; A.offs = (const uint32_t *)c.offs.p; A.lbits = lbits; A.np = np; A.w = w; A.n_pg = n_pg;
     A.has_null_pg = has_null_pg; A.S = S; A.n_tiles = n_tiles;
-    launch_fold_runs(P2, A, key_bytes, block, c.stream);
+    launch_fold_runs(P2, A, (const OutPlan *)c.plans.p, key_bytes, block, c.stream);
     if ((e = hipGetLastError()) != hipSuccess) { delete R; return fail_hip(e, "k_fold_runs launch"); }
     c.strategy = "tilesort";
   }
   hipEventRecord(c.ev[5], c.stream);
   MergeArgs M{};
   M.D = D; M.flags = dflags; M.out_cap = out_cap; M.lbits = lbits; M.S = S; M.mbits = mbits;
-  launch_merge_emit(P, M, (const OutPlan *)c.plans.p, key_bytes, direct ? 1u : n_pg, block, c.stream);
-  if ((e = hipGetLastError()) != hipSuccess) { delete R; return fail_hip(e, "k_merge_emit launch"); }
+  if (direct || S > 1) {
+    launch_merge_emit(P, M, (const OutPlan *)c.plans.p, key_bytes, direct ? 1u : n_pg, 1024, c.stream);
+    if ((e = hipGetLastError()) != hipSuccess) { delete R; return fail_hip(e, "k_merge_emit launch"); }
+  }
   hipEventRecord(c.ev[2], c.stream);
   hipEventRecord(c.ev[3], c.stream);
   e = hipGetLastError();
@@ -929,6 +930,13 @@ int32_t plhip_last_kernel_ms(float *total_ms, float *dominant_ms, const char **d
   if (total_ms) *total_ms = g_ctx.total_ms;
   if (dominant_ms) *dominant_ms = g_ctx.dom_ms;
   if (dominant_kernel) *dominant_kernel = g_ctx.dom_kernel.c_str();
+  return PLHIP_OK;
+}
+
+int32_t plhip_last_kernel_breakdown(float *tile_sort_ms, float *fold_ms, float *merge_emit_ms) {
+  if (tile_sort_ms) *tile_sort_ms = g_ctx.k_ms[0];
+  if (fold_ms) *fold_ms = g_ctx.k_ms[1];
+  if (merge_emit_ms) *merge_emit_ms = g_ctx.k_ms[2];
   return PLHIP_OK;
 }
 

@@ -19,11 +19,14 @@
 #define TS_TILE (TS_BLOCK * TS_R) // rows per sorted tile
 #define TS_MAX_PBITS 9 // np + 1 histogram entries must not exceed TS_BLOCK (one per thread in the scan)
 
+#define FP_MAX_MBITS 6
 struct DumpHdr {
-  uint32_t n_hash;   // entries with ordinary keys
+  uint32_t n_hash;   // entries with ordinary keys, grouped by merge bucket
   uint32_t has_sent; // then one entry for the key equal to the empty sentinel
   uint32_t has_null; // then one entry for the null key
   uint32_t pad;
+  uint32_t boff[(1 << FP_MAX_MBITS) + 1]; // bucket b = entries [boff[b], boff[b + 1])
+  uint32_t pad2[3];
 };
 
 // Compact copies of LDS tables: item i owns [base + i * item_stride, ...): keys[cap], then every
@@ -43,11 +46,15 @@ struct FoldRowsArgs {
   uint64_t kxor;
   uint32_t lbits;
   int32_t keymode; // 0: row_packed_key, 1: plain 4-byte column, 2: plain 8-byte column
+  uint32_t mbits;  // the dump is grouped into 1 << mbits merge buckets
+  uint32_t pad;
 };
 
 struct FoldRunsArgs {
   DumpRef D;
   uint32_t *flags;
+  const uint8_t *pkeys; // packed keys of the sorted tiles
+  uint64_t out_cap;     // S == 1: the workgroup writes the output columns itself
   const uint32_t *offs; // [(np + 2)][n_tiles]: start of partition p inside tile t; row np + 1 = rows in the tile
   uint32_t lbits;
   uint32_t np;       // hash partitions of the tile sort (partition np = null keys)
@@ -69,12 +76,13 @@ struct MergeArgs {
   uint32_t pad;
 };
 
+int fast_shape_id(const Plan &p); // index of the pre-instantiated shape the plan matches, or -1 (run-time shape)
 size_t fast_table_bytes(const Plan &p, uint32_t lbits, int key_bytes);  // LDS bytes of a fold / merge workgroup
 uint64_t fast_dump_stride(const Plan &p, uint32_t cap, int key_bytes);
 void launch_fold_rows(const Plan &p, const FoldRowsArgs &a, int key_bytes, bool quad, uint32_t n_items, uint32_t block, hipStream_t s);
 void launch_tile_sort(const Plan &p, const PartOut &o, uint32_t pbits, uint32_t n_tiles, uint32_t *offs, int keymode, uint64_t kxor,
                       int key_bytes, hipStream_t s);
-void launch_fold_runs(const Plan &p2, const FoldRunsArgs &a, int key_bytes, uint32_t block, hipStream_t s);
+void launch_fold_runs(const Plan &p2, const FoldRunsArgs &a, const OutPlan *o_dev, int key_bytes, uint32_t block, hipStream_t s);
 void launch_merge_emit(const Plan &p, const MergeArgs &a, const OutPlan *o_dev, int key_bytes, uint32_t n_pg, uint32_t block, hipStream_t s);
 // distinct keys among `n_sample` rows taken every `stride` rows -> flags[FLAG_NGROUPS]
-void launch_estimate(const Plan &p, int64_t n_sample, int64_t stride, uint32_t *flags, hipStream_t s);
+void launch_estimate(const Plan &p, int64_t n_sample, int64_t stride, uint32_t n_wgs, uint32_t *flags, hipStream_t s);

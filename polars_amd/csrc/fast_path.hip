@@ -76,32 +76,40 @@ DEVINL void ltab_init(const Plan &P, uint8_t *sm, uint32_t lslots) {
 // column base is aligned to 4 elements, so one (two for 8-byte types) vector load fetches them.
 template <int B, bool QUAD>
 DEVINL void load_raw(const uint8_t *vals, uint32_t w, const uint32_t (&row)[B], uint64_t (&raw)[B]) {
-  if (QUAD) {
-    const size_t r0 = row[0];
+  if (QUAD) { // every group of four rows is one aligned quad: vector loads
+    static_assert(!QUAD || B % 4 == 0, "quads");
     switch (w) {
-      case 1: {
-        const uint32_t q = *(const uint32_t *)(vals + r0);
+      case 1:
 #pragma unroll
-        for (int b = 0; b < B; b++) raw[b] = (q >> (8 * b)) & 0xFFu;
+        for (int g = 0; g < B / 4; g++) {
+          const uint32_t q = *(const uint32_t *)(vals + (size_t)row[4 * g]);
+#pragma unroll
+          for (int b = 0; b < 4; b++) raw[4 * g + b] = (q >> (8 * b)) & 0xFFu;
+        }
         break;
-      }
-      case 2: {
-        const uint2 q = *(const uint2 *)(vals + r0 * 2);
-        raw[0] = q.x & 0xFFFFu; raw[1] = q.x >> 16; raw[2 % B] = q.y & 0xFFFFu; raw[3 % B] = q.y >> 16;
+      case 2:
+#pragma unroll
+        for (int g = 0; g < B / 4; g++) {
+          const uint2 q = *(const uint2 *)(vals + (size_t)row[4 * g] * 2);
+          raw[4 * g] = q.x & 0xFFFFu; raw[4 * g + 1] = q.x >> 16; raw[4 * g + 2] = q.y & 0xFFFFu; raw[4 * g + 3] = q.y >> 16;
+        }
         break;
-      }
-      case 4: {
-        const uint4 q = *(const uint4 *)(vals + r0 * 4);
-        raw[0] = q.x; raw[1 % B] = q.y; raw[2 % B] = q.z; raw[3 % B] = q.w;
+      case 4:
+#pragma unroll
+        for (int g = 0; g < B / 4; g++) {
+          const uint4 q = *(const uint4 *)(vals + (size_t)row[4 * g] * 4);
+          raw[4 * g] = q.x; raw[4 * g + 1] = q.y; raw[4 * g + 2] = q.z; raw[4 * g + 3] = q.w;
+        }
         break;
-      }
-      default: {
-        const uint4 q0 = *(const uint4 *)(vals + r0 * 8);
-        const uint4 q1 = *(const uint4 *)(vals + r0 * 8 + 16);
-        raw[0] = (uint64_t)q0.x | ((uint64_t)q0.y << 32); raw[1 % B] = (uint64_t)q0.z | ((uint64_t)q0.w << 32);
-        raw[2 % B] = (uint64_t)q1.x | ((uint64_t)q1.y << 32); raw[3 % B] = (uint64_t)q1.z | ((uint64_t)q1.w << 32);
+      default:
+#pragma unroll
+        for (int g = 0; g < B / 4; g++) {
+          const uint4 q0 = *(const uint4 *)(vals + (size_t)row[4 * g] * 8);
+          const uint4 q1 = *(const uint4 *)(vals + (size_t)row[4 * g] * 8 + 16);
+          raw[4 * g] = (uint64_t)q0.x | ((uint64_t)q0.y << 32); raw[4 * g + 1] = (uint64_t)q0.z | ((uint64_t)q0.w << 32);
+          raw[4 * g + 2] = (uint64_t)q1.x | ((uint64_t)q1.y << 32); raw[4 * g + 3] = (uint64_t)q1.z | ((uint64_t)q1.w << 32);
+        }
         break;
-      }
     }
     return;
   }
@@ -151,23 +159,72 @@ DEVINL void raw_to_operands(uint32_t dtype, uint32_t conv, const uint64_t (&raw)
   }
 }
 
+
+// ---- query shapes ---------------------------------------------------------------------------------------
+// The fold code is written once against a "shape" (value dtypes + accumulator list).  RtShape reads it from
+// the Plan at run time (any query); StShape carries it in its type, so the accumulator loop unrolls and every
+// dtype / op switch folds away: straight-line code for the shapes instantiated at the end of this file.
+#define ACC_ENC(op, conv, src, width) ((uint32_t)(op) | ((uint32_t)(conv) << 8) | ((uint32_t)((src) + 1) << 16) | ((uint32_t)(width) << 24))
+template <uint32_t... V>
+struct USeq {
+  static constexpr int N = (int)sizeof...(V);
+  __host__ __device__ __forceinline__ static constexpr uint32_t at(int i) {
+    constexpr uint32_t a[N + 1] = {V..., 0u};
+    return a[i];
+  }
+};
+struct RtShape {
+  static constexpr bool STATIC = false;
+  static constexpr int NA = 0;
+  DEVINL static int n_vals(const Plan &P) { return P.n_vals; }
+  DEVINL static uint32_t val_dtype(const Plan &P, int c) { return P.vals[c].dtype; }
+  DEVINL static bool val_nullable(const Plan &P, int c) { return P.vals[c].validity != nullptr; }
+  DEVINL static int n_accs(const Plan &P) { return P.n_accs; }
+  DEVINL static uint32_t acc_op(const Plan &P, int a) { return P.accs[a].op; }
+  DEVINL static uint32_t acc_conv(const Plan &P, int a) { return P.accs[a].conv; }
+  DEVINL static int acc_src(const Plan &P, int a) { return P.accs[a].src; }
+  DEVINL static uint32_t acc_width(const Plan &P, int a) { return P.accs[a].width; }
+};
+template <typename VD, typename AC> // value dtypes (no validity bitmaps), ACC_ENC-coded accumulators
+struct StShape {
+  static constexpr bool STATIC = true;
+  static constexpr int NA = AC::N;
+  __host__ __device__ __forceinline__ static constexpr int n_vals(const Plan &) { return VD::N; }
+  __host__ __device__ __forceinline__ static constexpr uint32_t val_dtype(const Plan &, int c) { return VD::at(c); }
+  __host__ __device__ __forceinline__ static constexpr bool val_nullable(const Plan &, int) { return false; }
+  __host__ __device__ __forceinline__ static constexpr int n_accs(const Plan &) { return AC::N; }
+  __host__ __device__ __forceinline__ static constexpr uint32_t acc_op(const Plan &, int a) { return AC::at(a) & 0xFFu; }
+  __host__ __device__ __forceinline__ static constexpr uint32_t acc_conv(const Plan &, int a) { return (AC::at(a) >> 8) & 0xFFu; }
+  __host__ __device__ __forceinline__ static constexpr int acc_src(const Plan &, int a) { return (int)((AC::at(a) >> 16) & 0xFFu) - 1; }
+  __host__ __device__ __forceinline__ static constexpr uint32_t acc_width(const Plan &, int a) { return AC::at(a) >> 24; }
+};
+
+template <int I, int N, typename F>
+DEVINL void static_for(F &&f) {
+  if constexpr (I < N) {
+    f(I);
+    static_for<I + 1, N>(f);
+  }
+}
+
+// LDS table: lcap hashed slots, then the slot of the key equal to the empty sentinel, the slot of the null
+// key, and 64 trash slots (one per lane: no bank conflicts, no same-address serialisation) that rows which do
+// not count (tail lanes, null values) are steered to, so that the accumulator updates need no predication.
+#define FP_EXTRA_SLOTS 66u
+DEVINL uint32_t lslots_of(uint32_t lbits) { return (1u << lbits) + FP_EXTRA_SLOTS; }
+
 // Folds B rows per lane into the workgroup's LDS table.  row[] are in-bounds for every lane (dead lanes are
-// clamped by the caller); bit b of `live` says whether row[b] counts.  The dtype / op switches are
-// wave-uniform and sit outside the per-row loops.
-template <typename KS, int B, bool QUAD>
+// clamped by the caller); bit b of `live` says whether row[b] counts.  All global loads of the batch (keys
+// and the first NPRE value columns) are issued before the first LDS probe, so a wave exposes one memory
+// round trip per batch; the B probes of a lane advance together, one batched LDS read per probe step.
+template <typename KS, int B, bool QUAD, int NPRE, typename SH>
 DEVINL void fold_batch(const Plan &P, uint8_t *sm, uint32_t lbits, uint32_t *used, const uint32_t (&row)[B], uint32_t live,
-                       int keymode, uint64_t kxor, bool force_null) {
-  const uint32_t lcap = 1u << lbits, lslots = lcap + 2;
+                       int keymode, const uint8_t *kvals, uint64_t kxor, bool force_null) {
+  const uint32_t lcap = 1u << lbits, lslots = lcap + FP_EXTRA_SLOTS, trash = lcap + 2 + (threadIdx.x & 63), mask = lcap - 1;
   KS *lkeys = (KS *)sm;
-  const KeySpec &K0 = P.keys[0];
-  uint32_t slot[B];
-  if (force_null) {
-    if (live) used[1] = 1;
-#pragma unroll
-    for (int b = 0; b < B; b++) slot[b] = lcap + 1;
-  } else {
-    KS key[B];
-    uint32_t nullm = 0;
+  KS key[B];
+  uint32_t nullm = 0;
+  if (!force_null) {
     if (keymode == 0) {
 #pragma unroll
       for (int b = 0; b < B; b++) {
@@ -176,107 +233,188 @@ DEVINL void fold_batch(const Plan &P, uint8_t *sm, uint32_t lbits, uint32_t *use
         if (isn) nullm |= 1u << b;
       }
     } else {
-      uint64_t raw[B];
-      load_raw<B, QUAD>(K0.values, keymode == 1 ? 4u : 8u, row, raw);
+      uint64_t kraw[B];
+      load_raw<B, QUAD>(kvals, keymode == 1 ? 4u : 8u, row, kraw);
 #pragma unroll
-      for (int b = 0; b < B; b++) key[b] = (KS)(raw[b] ^ kxor);
-    }
-#pragma unroll
-    for (int b = 0; b < B; b++) {
-      slot[b] = 0;
-      if (!((live >> b) & 1)) continue;
-      if ((nullm >> b) & 1) { used[1] = 1; slot[b] = lcap + 1; continue; }
-      slot[b] = ltab_slot<KS>(lkeys, lbits, used, key[b]);
-      if (slot[b] == ~0u) { live &= ~(1u << b); slot[b] = 0; }
+      for (int b = 0; b < B; b++) key[b] = (KS)(kraw[b] ^ kxor);
     }
   }
+  uint64_t pre[NPRE ? NPRE : 1][B];
+#pragma unroll
+  for (int c = 0; c < NPRE; c++)
+    if (c < SH::n_vals(P)) load_raw<B, QUAD>(P.vals[c].values, wbytes(SH::val_dtype(P, c)), row, pre[c]);
+
+  // ---- slots -----------------------------------------------------------------------------------------------
+  uint32_t slot[B];
+  if (force_null) {
+    if (live) used[1] = 1;
+#pragma unroll
+    for (int b = 0; b < B; b++) slot[b] = ((live >> b) & 1) ? lcap + 1 : trash;
+  } else {
+    uint32_t pend = 0, sentm = 0;
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+      const bool lv = (live >> b) & 1, isn = (nullm >> b) & 1, sent = key[b] == KE<KS>::v;
+      slot[b] = !lv ? trash : isn ? lcap + 1 : sent ? lcap : lds_home(mix_a((uint64_t)key[b]), lbits);
+      if (lv && !isn && sent) sentm = 1;
+      if (lv && !isn && !sent) pend |= 1u << b;
+    }
+    if (nullm & live) used[1] = 1;
+    if (sentm) used[0] = 1;
+    for (int step = 0; pend; step++) {
+      KS k[B];
+#pragma unroll
+      for (int b = 0; b < B; b++) k[b] = lkeys[slot[b] < lcap ? slot[b] : 0]; // batched; only pending rows look at it
+#pragma unroll
+      for (int b = 0; b < B; b++) {
+        if (!((pend >> b) & 1)) continue;
+        KS kb = k[b];
+        if (kb == KE<KS>::v) kb = cas_key(&lkeys[slot[b]], KE<KS>::v, key[b]); // returns EMPTY when the claim won
+        if (kb == key[b] || kb == KE<KS>::v) pend &= ~(1u << b);
+        else slot[b] = (slot[b] + 1) & mask;
+      }
+      if (step >= FP_PROBE_LIMIT && pend) { // table full: the host redoes the query on the general path
+        used[2] = 1;
+#pragma unroll
+        for (int b = 0; b < B; b++) if ((pend >> b) & 1) { slot[b] = trash; live &= ~(1u << b); }
+        pend = 0;
+      }
+    }
+  }
+
+  // ---- accumulators: unconditional LDS atomics, rows that do not count go to the trash slot ----------------
   uint32_t off = al8(lslots * (uint32_t)sizeof(KS));
   int cur_src = -1;
   uint64_t raw[B];
-  uint32_t ok = 0;
-  for (int a = 0; a < P.n_accs; a++) {
-    const AccSpec A = P.accs[a];
+  uint32_t vslot[B]; // slot[] with the null values of the current source column steered to the trash slot
+#pragma unroll
+  for (int b = 0; b < B; b++) { raw[b] = 0; vslot[b] = slot[b]; }
+  auto body = [&](int a) {
+    const uint32_t op = SH::acc_op(P, a), width = SH::acc_width(P, a);
+    const int src = SH::acc_src(P, a);
     uint8_t *lb = sm + off;
-    off += al8(lslots * A.width);
-    if (A.op == ACC_CNT_ALL) {
+    off += al8(lslots * width);
+    if (op == ACC_CNT_ALL) {
 #pragma unroll
-      for (int b = 0; b < B; b++) if ((live >> b) & 1) atomicAdd((unsigned int *)(lb + slot[b] * 4), 1u);
-      continue;
+      for (int b = 0; b < B; b++) atomicAdd((unsigned int *)(lb + slot[b] * 4), 1u);
+      return;
     }
-    if (A.op == ACC_FIRST_ROW) {
+    if (op == ACC_FIRST_ROW) {
 #pragma unroll
-      for (int b = 0; b < B; b++)
-        if ((live >> b) & 1) atomicMin((unsigned int *)(lb + slot[b] * 4), P.rowidx ? P.rowidx[row[b]] : row[b]);
-      continue;
+      for (int b = 0; b < B; b++) atomicMin((unsigned int *)(lb + slot[b] * 4), P.rowidx ? P.rowidx[row[b]] : row[b]);
+      return;
     }
-    if (A.src != cur_src) { // accumulators are ordered by source column: one load serves all of them
-      cur_src = A.src;
-      const ValSpec V = P.vals[A.src];
-      load_raw<B, QUAD>(V.values, wbytes(V.dtype), row, raw);
-      ok = live;
-      if (V.validity) {
+    if (src != cur_src) { // accumulators are ordered by source column: one fetch serves all of them
+      cur_src = src;
+      if (src < NPRE) {
+        // wave-uniform select of the prefetched column (register arrays cannot be indexed dynamically)
 #pragma unroll
-        for (int b = 0; b < B; b++) if (!val_valid(V, (int64_t)row[b])) ok &= ~(1u << b);
+        for (int c = 0; c < NPRE; c++)
+          if (src == c) {
+#pragma unroll
+            for (int b = 0; b < B; b++) raw[b] = pre[c][b];
+          }
+      } else {
+        load_raw<B, QUAD>(P.vals[src].values, wbytes(SH::val_dtype(P, src)), row, raw);
+      }
+#pragma unroll
+      for (int b = 0; b < B; b++) vslot[b] = slot[b];
+      if (SH::val_nullable(P, src)) {
+        const ValSpec V = P.vals[src];
+#pragma unroll
+        for (int b = 0; b < B; b++) if (!val_valid(V, (int64_t)row[b])) vslot[b] = trash;
       }
     }
-    if (A.op == ACC_CNT_VALID) {
+    if (op == ACC_CNT_VALID) {
 #pragma unroll
-      for (int b = 0; b < B; b++) if ((ok >> b) & 1) atomicAdd((unsigned int *)(lb + slot[b] * 4), 1u);
-      continue;
+      for (int b = 0; b < B; b++) atomicAdd((unsigned int *)(lb + vslot[b] * 4), 1u);
+      return;
     }
     uint64_t opnd[B];
-    raw_to_operands<B>(P.vals[A.src].dtype, A.conv, raw, opnd);
-    switch (A.op) {
-#define APPLY(EXPR) _Pragma("unroll") for (int b = 0; b < B; b++) if ((ok >> b) & 1) { auto *p = lb + slot[b] * 8; EXPR; } break;
-      case ACC_ADD_U64: APPLY(atomicAdd((unsigned long long *)p, (unsigned long long)opnd[b]))
-      case ACC_ADD_F64: APPLY(atomicAdd((double *)p, __longlong_as_double((long long)opnd[b])))
-      case ACC_MIN_I64: APPLY(atomicMin((long long *)p, (long long)opnd[b]))
-      case ACC_MAX_I64: APPLY(atomicMax((long long *)p, (long long)opnd[b]))
-      case ACC_MIN_U64: APPLY(atomicMin((unsigned long long *)p, (unsigned long long)opnd[b]))
-      case ACC_MAX_U64: APPLY(atomicMax((unsigned long long *)p, (unsigned long long)opnd[b]))
-#undef APPLY
-      default: break;
+    raw_to_operands<B>(SH::val_dtype(P, src), SH::acc_conv(P, a), raw, opnd);
+    if (op == ACC_ADD_U64) {
+#pragma unroll
+      for (int b = 0; b < B; b++) atomicAdd((unsigned long long *)(lb + vslot[b] * 8), (unsigned long long)opnd[b]);
+    } else if (op == ACC_ADD_F64) {
+#pragma unroll
+      for (int b = 0; b < B; b++) atomicAdd((double *)(lb + vslot[b] * 8), __longlong_as_double((long long)opnd[b]));
+    } else if (op == ACC_MIN_I64) {
+#pragma unroll
+      for (int b = 0; b < B; b++) atomicMin((long long *)(lb + vslot[b] * 8), (long long)opnd[b]);
+    } else if (op == ACC_MAX_I64) {
+#pragma unroll
+      for (int b = 0; b < B; b++) atomicMax((long long *)(lb + vslot[b] * 8), (long long)opnd[b]);
+    } else if (op == ACC_MIN_U64) {
+#pragma unroll
+      for (int b = 0; b < B; b++) atomicMin((unsigned long long *)(lb + vslot[b] * 8), (unsigned long long)opnd[b]);
+    } else if (op == ACC_MAX_U64) {
+#pragma unroll
+      for (int b = 0; b < B; b++) atomicMax((unsigned long long *)(lb + vslot[b] * 8), (unsigned long long)opnd[b]);
     }
-  }
+  };
+  if constexpr (SH::STATIC) static_for<0, SH::NA>(body);
+  else for (int a = 0; a < SH::n_accs(P); a++) body(a);
 }
 
-// Occupied slots -> list[] (u16 slot numbers, ordinary keys first, then the sentinel slot, then the null
-// slot).  Returns the number of ordinary entries; every thread of the workgroup must call it.
+DEVINL uint32_t merge_bucket(uint64_t key, uint32_t mbits) {
+  return mbits ? (mix_a(key) * 0x85EBCA77u) >> (32 - mbits) : 0u;
+}
+
+// Occupied slots -> list[] (u16 slot numbers) grouped by merge bucket; bk[0..nb] receives the bucket
+// offsets (bk[nb] = number of ordinary entries).  Every thread of the workgroup must call it.
 template <typename KS>
-DEVINL uint32_t build_list(const KS *lkeys, uint32_t lcap, uint16_t *list, uint32_t *sh_cnt) {
-  const uint32_t lane = threadIdx.x & 63;
-  if (threadIdx.x == 0) *sh_cnt = 0;
+DEVINL uint32_t build_list(const KS *lkeys, uint32_t lcap, uint32_t mbits, uint16_t *list, uint32_t *bk /* [2 * 65] */) {
+  const uint32_t nb = 1u << mbits;
+  uint32_t *cur = bk + 65;
+  for (uint32_t b = threadIdx.x; b <= nb; b += blockDim.x) { bk[b] = 0; cur[b] = 0; }
   __syncthreads();
-  for (uint32_t i0 = 0; i0 < lcap; i0 += blockDim.x) {
-    const uint32_t i = i0 + threadIdx.x;
-    const bool occ = i < lcap && lkeys[i] != KE<KS>::v;
-    const unsigned long long m = __ballot(occ);
-    if (m) {
-      uint32_t wbase = 0;
-      if (lane == 0) wbase = atomicAdd(sh_cnt, (uint32_t)__popcll(m));
-      wbase = __shfl(wbase, 0);
-      if (occ) list[wbase + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)i;
+  if (mbits) {
+    for (uint32_t i = threadIdx.x; i < lcap; i += blockDim.x) {
+      const KS k = lkeys[i];
+      if (k != KE<KS>::v) atomicAdd(&bk[merge_bucket((uint64_t)k, mbits) + 1], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) for (uint32_t b = 0; b < nb; b++) { bk[b + 1] += bk[b]; }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) cur[b] = bk[b];
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < lcap; i += blockDim.x) {
+      const KS k = lkeys[i];
+      if (k != KE<KS>::v) list[atomicAdd(&cur[merge_bucket((uint64_t)k, mbits)], 1u)] = (uint16_t)i;
+    }
+  } else {
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t i0 = 0; i0 < lcap; i0 += blockDim.x) {
+      const uint32_t i = i0 + threadIdx.x;
+      const bool occ = i < lcap && lkeys[i] != KE<KS>::v;
+      const unsigned long long m = __ballot(occ);
+      if (m) {
+        uint32_t wbase = 0;
+        if (lane == 0) wbase = atomicAdd(&bk[1], (uint32_t)__popcll(m));
+        wbase = __shfl(wbase, 0);
+        if (occ) list[wbase + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)i;
+      }
     }
   }
   __syncthreads();
-  return *sh_cnt;
+  return bk[nb];
 }
 
-// LDS table -> compact dump of item `item`
+// LDS table -> compact dump of item `item`, entries grouped by merge bucket
 template <typename KS>
-DEVINL void dump_table(const Plan &P, uint8_t *sm, uint32_t lbits, uint32_t *used, uint32_t *sh_cnt, uint16_t *list,
+DEVINL void dump_table(const Plan &P, uint8_t *sm, uint32_t lbits, uint32_t mbits, uint32_t *used, uint32_t *bk, uint16_t *list,
                        const DumpRef &D, uint32_t item) {
-  const uint32_t lcap = 1u << lbits, lslots = lcap + 2;
+  const uint32_t lcap = 1u << lbits, lslots = lcap + FP_EXTRA_SLOTS;
   const KS *lkeys = (const KS *)sm;
-  const uint32_t n_hash = build_list<KS>(lkeys, lcap, list, sh_cnt);
+  const uint32_t n_hash = build_list<KS>(lkeys, lcap, mbits, list, bk);
   const uint32_t hs = used[0] ? 1u : 0u, hn = used[1] ? 1u : 0u;
+  DumpHdr *H = &D.hdr[item];
   if (threadIdx.x == 0) {
     if (hs) list[n_hash] = (uint16_t)lcap;
     if (hn) list[n_hash + hs] = (uint16_t)(lcap + 1);
-    DumpHdr h;
-    h.n_hash = n_hash; h.has_sent = hs; h.has_null = hn; h.pad = 0;
-    D.hdr[item] = h;
+    H->n_hash = n_hash; H->has_sent = hs; H->has_null = hn; H->pad = 0;
   }
+  for (uint32_t b = threadIdx.x; b <= (1u << mbits); b += blockDim.x) H->boff[b] = bk[b];
   __syncthreads();
   const uint32_t n = n_hash + hs + hn;
   uint8_t *base = D.base + (uint64_t)item * D.item_stride;
@@ -305,65 +443,136 @@ DEVINL uint32_t table_lds_bytes(const Plan &P, uint32_t lslots, uint32_t key_byt
   return off;
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// few groups: row slices of the input columns
-// ---------------------------------------------------------------------------------------------------------
-template <typename KS, bool QUAD>
-__global__ void __launch_bounds__(1024) k_fold_rows(Plan P, FoldRowsArgs A) {
-  __shared__ __align__(16) uint32_t sh[8]; // [0..2] used flags, [4] list counter
-  const uint32_t lslots = (1u << A.lbits) + 2;
-  if (threadIdx.x < 8) sh[threadIdx.x] = 0;
-  ltab_init<KS>(P, fsm, lslots);
-  __syncthreads();
-  const int64_t row0 = (int64_t)blockIdx.x * A.rows_per_item;
-  const int64_t row1 = row0 + A.rows_per_item < P.n_rows ? row0 + A.rows_per_item : P.n_rows;
-  for (int64_t base = row0 + (int64_t)threadIdx.x * 4; base < row1; base += (int64_t)blockDim.x * 4) {
-    uint32_t row[4];
-    uint32_t live = 0;
-#pragma unroll
-    for (int b = 0; b < 4; b++) {
-      const int64_t r = base + b;
-      if (r < row1) live |= 1u << b;
-      row[b] = (uint32_t)(r < row1 ? r : base);
-    }
-    // a partial quad at the very end of the column may not be read with a vector load
-    if (QUAD && live != 0xFu) fold_batch<KS, 4, false>(P, fsm, A.lbits, sh, row, live, A.keymode, A.kxor, false);
-    else fold_batch<KS, 4, QUAD>(P, fsm, A.lbits, sh, row, live, A.keymode, A.kxor, false);
+// LDS table -> output columns.  A workgroup takes a block of output rows with one global atomic; inside it
+// thread k writes row base + k of every column (coalesced); validity bits go out as three 32-bit ORs per wave
+// into a zeroed bitmap.
+template <typename KS>
+DEVINL void emit_table(const Plan &P, uint8_t *sm, uint32_t lbits, uint32_t *used, uint32_t *bk, uint16_t *list,
+                       const OutPlan *__restrict__ Op, uint32_t *flags, uint64_t out_cap) {
+  __shared__ uint32_t e_loff[PLHIP_MAX_ACCS];
+  __shared__ uint32_t e_base;
+  const uint32_t lcap = 1u << lbits, lslots = lcap + FP_EXTRA_SLOTS;
+  const KS *lkeys = (const KS *)sm;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t n_hash = build_list<KS>(lkeys, lcap, 0, list, bk);
+  const uint32_t hs = used[0] ? 1u : 0u, hn = used[1] ? 1u : 0u;
+  const uint32_t n = n_hash + hs + hn;
+  if (threadIdx.x == 0) {
+    if (hs) list[n_hash] = (uint16_t)lcap;
+    if (hn) list[n_hash + hs] = (uint16_t)(lcap + 1);
+    uint32_t off = al8(lslots * (uint32_t)sizeof(KS));
+    for (int a = 0; a < P.n_accs; a++) { e_loff[a] = off; off += al8(lslots * P.accs[a].width); }
+    e_base = n ? atomicAdd(&flags[FLAG_NGROUPS], n) : 0;
   }
   __syncthreads();
-  if (sh[2] && threadIdx.x == 0) A.flags[FLAG_OVERFLOW] = 1;
-  uint16_t *list = (uint16_t *)(fsm + table_lds_bytes(P, lslots, sizeof(KS)));
-  dump_table<KS>(P, fsm, A.lbits, sh, &sh[4], list, A.D, blockIdx.x);
+  const uint64_t gbase = e_base;
+  if (gbase + n > out_cap) { // the outputs are sized from the table capacities: only after an overflow elsewhere
+    if (threadIdx.x == 0) flags[FLAG_OVERFLOW] = 1;
+    return;
+  }
+  const OutPlan &O = *Op;
+  for (uint32_t k0 = 0; k0 < n; k0 += blockDim.x) { // a wave covers 64 consecutive output rows
+    const uint32_t k = k0 + threadIdx.x;
+    const bool livek = k < n;
+    const uint32_t s = livek ? list[k] : 0;
+    const uint64_t i = gbase + k;
+    const uint64_t packed = livek ? (uint64_t)lkeys[s] : 0;
+    for (int o = 0; o < O.n_outs; o++) {
+      const OutSpec &S = O.outs[o];
+      bool valid = false;
+      if (livek) {
+        if (S.kind == OUT_KEY) valid = finalize_key(P, S, packed, s == lcap + 1, s == lcap, i);
+        else {
+          uint64_t acc = 0;
+          if (S.acc >= 0) acc = P.accs[S.acc].width == 8 ? ((const uint64_t *)(sm + e_loff[S.acc]))[s] : ((const uint32_t *)(sm + e_loff[S.acc]))[s];
+          const uint32_t cnt_all = S.cnt_all >= 0 ? ((const uint32_t *)(sm + e_loff[S.cnt_all]))[s] : 0;
+          const uint32_t cnt_valid = S.cnt_valid >= 0 ? ((const uint32_t *)(sm + e_loff[S.cnt_valid]))[s] : cnt_all;
+          valid = finalize_value(S, acc, cnt_all, cnt_valid, i);
+        }
+      }
+      if (S.validity) {
+        const unsigned long long mk = __ballot(valid);
+        if (mk) {
+          const uint64_t i0 = gbase + (k0 + (threadIdx.x & ~63u));
+          const uint32_t sft = (uint32_t)(i0 & 31);
+          const unsigned long long lo = mk << sft, hi = sft ? mk >> (64 - sft) : 0ull;
+          const uint32_t word = lane == 0 ? (uint32_t)lo : lane == 1 ? (uint32_t)(lo >> 32) : (uint32_t)hi;
+          if (lane < 3 && word) atomicOr((unsigned int *)S.validity + (i0 >> 5) + lane, word);
+        }
+      }
+    }
+  }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// many groups, pass 1: sort every tile by hash partition (in LDS) and write it back tile-contiguous
-// ---------------------------------------------------------------------------------------------------------
-// exclusive scan of v[0..n), n <= blockDim.x = TS_BLOCK, one entry per thread
-DEVINL uint32_t block_scan_excl(uint32_t x, uint32_t *tmp) {
-  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// exclusive scan of one value per thread over the workgroup (blockDim.x a multiple of 64, <= 1024)
+DEVINL uint32_t block_scan_excl(uint32_t x, uint32_t *tmp /* [16] */) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   uint32_t inc = x;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
     const uint32_t t = __shfl_up(inc, off);
     if (lane >= (uint32_t)off) inc += t;
   }
+  __syncthreads(); // tmp may still be read from a previous call
   if (lane == 63) tmp[wave] = inc;
   __syncthreads();
   if (wave == 0) {
-    const uint32_t wv = lane < TS_BLOCK / 64 ? tmp[lane] : 0;
+    const uint32_t wv = lane < nw ? tmp[lane] : 0;
     uint32_t winc = wv;
 #pragma unroll
-    for (int off = 1; off < TS_BLOCK / 64; off <<= 1) {
+    for (int off = 1; off < 16; off <<= 1) {
       const uint32_t t = __shfl_up(winc, off);
       if (lane >= (uint32_t)off) winc += t;
     }
-    if (lane < TS_BLOCK / 64) tmp[lane] = winc - wv;
+    if (lane < nw) tmp[lane] = winc - wv;
   }
   __syncthreads();
   return tmp[wave] + inc - x;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// few groups: row slices of the input columns
+// ---------------------------------------------------------------------------------------------------------
+#define ROWS_NPRE 3
+template <typename KS, bool QUAD, typename SH>
+__global__ void __launch_bounds__(1024) k_fold_rows(Plan P, FoldRowsArgs A) {
+  __shared__ __align__(16) uint32_t sh[8]; // [0..2] used flags
+  __shared__ __align__(16) uint32_t bk[136];
+  const uint32_t lslots = lslots_of(A.lbits);
+  if (threadIdx.x < 8) sh[threadIdx.x] = 0;
+  ltab_init<KS>(P, fsm, lslots);
+  __syncthreads();
+  const int64_t row0 = (int64_t)blockIdx.x * A.rows_per_item;
+  const int64_t row1 = row0 + A.rows_per_item < P.n_rows ? row0 + A.rows_per_item : P.n_rows;
+  constexpr int ROWS_B = SH::STATIC ? 8 : 4; // rows per lane per batch (static shapes are light on registers)
+  const int64_t step = (int64_t)blockDim.x * ROWS_B;
+  for (int64_t base = row0; base < row1; base += step) {
+    uint32_t row[ROWS_B];
+    uint32_t live = 0;
+#pragma unroll
+    for (int g = 0; g < ROWS_B / 4; g++) { // quad g of this lane: a wave reads 1 KB of a 4-byte column per instruction
+      const int64_t q = base + ((int64_t)g * blockDim.x + threadIdx.x) * 4;
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const int64_t r = q + b;
+        if (r < row1) live |= 1u << (4 * g + b);
+        row[4 * g + b] = (uint32_t)(r < row1 ? r : row0);
+      }
+    }
+    if (!live) continue;
+    // a batch that holds the end of the column is read with scalar loads: its last quad may be cut
+    if (QUAD && live != (1u << ROWS_B) - 1u) fold_batch<KS, ROWS_B, false, ROWS_NPRE, SH>(P, fsm, A.lbits, sh, row, live, A.keymode, P.keys[0].values, A.kxor, false);
+    else fold_batch<KS, ROWS_B, QUAD, ROWS_NPRE, SH>(P, fsm, A.lbits, sh, row, live, A.keymode, P.keys[0].values, A.kxor, false);
+  }
+  __syncthreads();
+  if (sh[2] && threadIdx.x == 0) A.flags[FLAG_OVERFLOW] = 1;
+  uint16_t *list = (uint16_t *)(fsm + table_lds_bytes(P, lslots, sizeof(KS)));
+  dump_table<KS>(P, fsm, A.lbits, A.mbits, sh, bk, list, A.D, blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// many groups, pass 1: sort every tile by hash partition (in LDS) and write it back tile-contiguous
+// ---------------------------------------------------------------------------------------------------------
 // one column of the tile: registers -> sorted position in LDS -> coalesced 16-byte stores
 template <typename T>
 DEVINL void stage_and_store(uint8_t *stage, const T (&x)[TS_R], const uint32_t (&pos)[TS_R], uint32_t live, uint8_t *dst, uint32_t nt) {
@@ -434,14 +643,23 @@ __global__ void __launch_bounds__(TS_BLOCK) k_tile_sort(Plan P, PartOut O, uint3
     const uint32_t w = wbytes(V.dtype);
     uint64_t raw[TS_R];
     load_raw<TS_R, false>(V.values, w, row, raw);
-    switch (w) {
-#define STAGE(T) { T x[TS_R]; _Pragma("unroll") for (int r = 0; r < TS_R; r++) x[r] = (T)raw[r]; \
-                   stage_and_store<T>(fsm, x, pos, live, O.vals[v] + (size_t)r0 * sizeof(T), nt); } break;
-      case 1: STAGE(uint8_t)
-      case 2: STAGE(uint16_t)
-      case 4: STAGE(uint32_t)
-      default: STAGE(uint64_t)
-#undef STAGE
+    if (w == 8) {
+      stage_and_store<uint64_t>(fsm, raw, pos, live, O.vals[v] + (size_t)r0 * 8, nt);
+    } else if (w == 4) {
+      uint32_t x[TS_R];
+#pragma unroll
+      for (int r = 0; r < TS_R; r++) x[r] = (uint32_t)raw[r];
+      stage_and_store<uint32_t>(fsm, x, pos, live, O.vals[v] + (size_t)r0 * 4, nt);
+    } else if (w == 2) {
+      uint16_t x[TS_R];
+#pragma unroll
+      for (int r = 0; r < TS_R; r++) x[r] = (uint16_t)raw[r];
+      stage_and_store<uint16_t>(fsm, x, pos, live, O.vals[v] + (size_t)r0 * 2, nt);
+    } else {
+      uint8_t x[TS_R];
+#pragma unroll
+      for (int r = 0; r < TS_R; r++) x[r] = (uint8_t)raw[r];
+      stage_and_store<uint8_t>(fsm, x, pos, live, O.vals[v] + (size_t)r0, nt);
     }
     if (O.valid[v]) {
       uint8_t x[TS_R];
@@ -453,14 +671,16 @@ __global__ void __launch_bounds__(TS_BLOCK) k_tile_sort(Plan P, PartOut O, uint3
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// many groups, pass 2: one (partition group, tile segment) per workgroup
+// many groups, pass 2: one (partition group, tile segment) per workgroup.  A wave takes RUNS_B tiles at a
+// time; batch element b of every lane is a row of tile b's run, so all loads of RUNS_B runs are in flight
+// together.  With one segment per group the workgroup writes the output columns itself.
 // ---------------------------------------------------------------------------------------------------------
-#define FR_U 4 // tiles whose runs one wave concatenates
-#define FR_B 4 // rows per lane per pass
-template <typename KS>
-__global__ void __launch_bounds__(1024) k_fold_runs(Plan P, FoldRunsArgs A) {
+#define RUNS_NPRE 3
+template <typename KS, typename SH>
+__global__ void __launch_bounds__(1024) k_fold_runs(Plan P, FoldRunsArgs A, const OutPlan *__restrict__ Op) {
   __shared__ __align__(16) uint32_t sh[8];
-  const uint32_t lslots = (1u << A.lbits) + 2;
+  __shared__ __align__(16) uint32_t bk[136];
+  const uint32_t lslots = lslots_of(A.lbits);
   if (threadIdx.x < 8) sh[threadIdx.x] = 0;
   ltab_init<KS>(P, fsm, lslots);
   __syncthreads();
@@ -471,53 +691,57 @@ __global__ void __launch_bounds__(1024) k_fold_runs(Plan P, FoldRunsArgs A) {
   const uint32_t t0 = seg * per, t1 = t0 + per < A.n_tiles ? t0 + per : A.n_tiles;
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const uint32_t *o0 = A.offs + (uint64_t)p0 * A.n_tiles, *o1 = A.offs + (uint64_t)p1 * A.n_tiles;
-  for (uint32_t t = t0 + wave * FR_U; t < t1; t += nw * FR_U) {
-    // lanes 0..U-1 fetch the run bounds of tiles t..t+U-1; every lane then gets the prefix sums
-    uint32_t st = 0, len = 0;
-    if (lane < FR_U && t + lane < t1) { st = o0[t + lane]; len = o1[t + lane] - st; }
-    uint32_t s_[FR_U], c_[FR_U + 1];
-    c_[0] = 0;
+  constexpr int RUNS_B = SH::STATIC ? 8 : 4; // tiles per wave batch
+  const int keymode = sizeof(KS) == 4 ? 1 : 2; // the sorted copies hold packed keys of sizeof(KS) bytes
+  // lanes 0..B-1 hold the run bounds of the wave's next batch of tiles (fetched one batch ahead)
+  uint32_t t = t0 + wave * RUNS_B;
+  uint32_t st = 0, len = 0;
+  if (lane < RUNS_B && t + lane < t1) { st = o0[t + lane]; len = o1[t + lane] - st; }
+  while (t < t1) {
+    const uint32_t tn = t + nw * RUNS_B;
+    uint32_t stn = 0, lenn = 0;
+    if (lane < RUNS_B && tn + lane < t1) { stn = o0[tn + lane]; lenn = o1[tn + lane] - stn; }
+    uint32_t s_[RUNS_B], n_[RUNS_B], maxlen = 0;
 #pragma unroll
-    for (int u = 0; u < FR_U; u++) {
-      s_[u] = (uint32_t)__shfl((int)st, u) + (t + u) * (uint32_t)TS_TILE;
-      c_[u + 1] = c_[u] + (uint32_t)__shfl((int)len, u);
+    for (int b = 0; b < RUNS_B; b++) {
+      s_[b] = (uint32_t)__builtin_amdgcn_readlane((int)st, b) + (t + b) * (uint32_t)TS_TILE;
+      n_[b] = (uint32_t)__builtin_amdgcn_readlane((int)len, b);
+      maxlen = n_[b] > maxlen ? n_[b] : maxlen;
     }
-    const uint32_t tot = c_[FR_U];
-    for (uint32_t j0 = 0; j0 < tot; j0 += 64 * FR_B) {
-      uint32_t row[FR_B];
+    for (uint32_t i0 = 0; i0 < maxlen; i0 += 64) {
+      uint32_t row[RUNS_B];
       uint32_t live = 0;
+      const uint32_t i = i0 + lane;
 #pragma unroll
-      for (int b = 0; b < FR_B; b++) {
-        uint32_t j = j0 + (uint32_t)b * 64 + lane;
-        if (j < tot) live |= 1u << b;
-        else j = 0; // clamp dead lanes to the first row of the group (tot > 0 here)
-        uint32_t base = s_[0], c = 0;
-#pragma unroll
-        for (int u = 1; u < FR_U; u++) if (j >= c_[u]) { base = s_[u]; c = c_[u]; }
-        row[b] = base + (j - c);
+      for (int b = 0; b < RUNS_B; b++) {
+        if (i < n_[b]) live |= 1u << b;
+        row[b] = s_[b] + (i < n_[b] ? i : 0); // dead lanes read the run's first row (or the padded row behind the data)
       }
-      // the first tile of the group may hold no rows of this partition: clamp to any in-bounds row
-      fold_batch<KS, FR_B, false>(P, fsm, A.lbits, sh, row, live, P.keys[0].dtype == PLHIP_U32 ? 1 : 2, 0ull, null_pg);
+      fold_batch<KS, RUNS_B, false, RUNS_NPRE, SH>(P, fsm, A.lbits, sh, row, live, keymode, A.pkeys, 0ull, null_pg);
     }
+    t = tn; st = stn; len = lenn;
   }
   __syncthreads();
   if (sh[2] && threadIdx.x == 0) A.flags[FLAG_OVERFLOW] = 1;
   uint16_t *list = (uint16_t *)(fsm + table_lds_bytes(P, lslots, sizeof(KS)));
-  dump_table<KS>(P, fsm, A.lbits, sh, &sh[4], list, A.D, item);
+  if (A.S == 1) emit_table<KS>(P, fsm, A.lbits, sh, bk, list, Op, A.flags, A.out_cap);
+  else dump_table<KS>(P, fsm, A.lbits, 0, sh, bk, list, A.D, item);
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // merge the dumps of one partition group (split over 2^mbits workgroups by key hash) and write the outputs
 // ---------------------------------------------------------------------------------------------------------
-DEVINL uint32_t merge_bucket(uint64_t key, uint32_t mbits) {
-  return mbits ? (mix_a(key) * 0x85EBCA77u) >> (32 - mbits) : 0u;
-}
-
+#define MG_MAX_S 2048
+#define MG_U 4
 template <typename KS>
 __global__ void __launch_bounds__(1024) k_merge_emit(Plan P, MergeArgs A, const OutPlan *__restrict__ Op) {
   __shared__ __align__(16) uint32_t sh[8];
-  __shared__ __align__(16) uint32_t loff[PLHIP_MAX_ACCS];
-  const uint32_t lcap = 1u << A.lbits, lslots = lcap + 2;
+  __shared__ __align__(16) uint32_t bk[136];
+  __shared__ __align__(16) uint32_t tmp[16];
+  __shared__ __align__(16) uint32_t pre[MG_MAX_S + 1]; // flat index of each dump's first entry of this bucket
+  __shared__ __align__(16) uint32_t bst[MG_MAX_S];     // entry index where the bucket starts inside the dump
+  __shared__ uint32_t loff[PLHIP_MAX_ACCS];
+  const uint32_t lcap = 1u << A.lbits, lslots = lcap + FP_EXTRA_SLOTS;
   KS *lkeys = (KS *)fsm;
   if (threadIdx.x < 8) sh[threadIdx.x] = 0;
   if (threadIdx.x == 0) {
@@ -525,40 +749,100 @@ __global__ void __launch_bounds__(1024) k_merge_emit(Plan P, MergeArgs A, const 
     for (int a = 0; a < P.n_accs; a++) { loff[a] = off; off += al8(lslots * P.accs[a].width); }
   }
   ltab_init<KS>(P, fsm, lslots);
-  __syncthreads();
   const uint32_t pg = blockIdx.x >> A.mbits, m = blockIdx.x & ((1u << A.mbits) - 1);
-  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  for (uint32_t s = wave; s < A.S; s += nw) {
-    const uint32_t item = pg * A.S + s;
-    const DumpHdr h = A.D.hdr[item];
-    const uint8_t *base = A.D.base + (uint64_t)item * A.D.item_stride;
-    const KS *dkeys = (const KS *)base;
-    const uint32_t n = h.n_hash + (m == 0 ? h.has_sent + h.has_null : 0);
-    for (uint32_t k = lane; k < n; k += 64) {
-      uint32_t slot;
-      if (k < h.n_hash) {
-        const KS key = dkeys[k];
-        if (merge_bucket((uint64_t)key, A.mbits) != m) continue;
-        slot = ltab_slot<KS>(lkeys, A.lbits, sh, key);
-        if (slot == ~0u) continue;
-      } else if (k == h.n_hash && h.has_sent) { sh[0] = 1; slot = lcap; }
-      else { sh[1] = 1; slot = lcap + 1; }
-      uint64_t goff = al16((uint64_t)A.D.cap * sizeof(KS));
-      for (int a = 0; a < P.n_accs; a++) {
-        const AccSpec Ac = P.accs[a];
-        const uint64_t part = Ac.width == 8 ? ((const uint64_t *)(base + goff))[k] : (uint64_t)((const uint32_t *)(base + goff))[k];
-        goff += al16((uint64_t)A.D.cap * Ac.width);
-        if (part == Ac.init) continue; // identity: nothing to fold
-        uint8_t *p = fsm + loff[a] + slot * Ac.width;
+  // bucket extents of every dump of the group, then their prefix sums
+  const uint32_t chunk = (A.S + blockDim.x - 1) / blockDim.x;
+  const uint32_t s_lo = threadIdx.x * chunk, s_hi = s_lo + chunk < A.S ? s_lo + chunk : A.S;
+  uint32_t mine = 0;
+  for (uint32_t s = s_lo; s < s_hi; s++) {
+    const DumpHdr *H = &A.D.hdr[pg * A.S + s];
+    const uint32_t b0 = H->boff[m], b1 = H->boff[m + 1];
+    bst[s] = b0;
+    pre[s] = b1 - b0;
+    mine += b1 - b0;
+  }
+  uint32_t run = block_scan_excl(mine, tmp);
+  for (uint32_t s = s_lo; s < s_hi; s++) { const uint32_t c = pre[s]; pre[s] = run; run += c; }
+  if (threadIdx.x == blockDim.x - 1) pre[A.S] = run;
+  __syncthreads();
+  const uint32_t total = pre[A.S];
+  const uint64_t koff = al16((uint64_t)A.D.cap * sizeof(KS));
+  for (uint32_t f0 = 0; f0 < total; f0 += blockDim.x * MG_U) {
+    const uint8_t *base[MG_U];
+    uint32_t k[MG_U], slot[MG_U];
+    KS key[MG_U];
+    bool lv[MG_U];
+#pragma unroll
+    for (int u = 0; u < MG_U; u++) {
+      const uint32_t f = f0 + u * blockDim.x + threadIdx.x;
+      lv[u] = f < total;
+      uint32_t lo = 0, hi = A.S; // largest s with pre[s] <= f
+      const uint32_t ff = lv[u] ? f : 0;
+      while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pre[mid] <= ff) lo = mid; else hi = mid; }
+      base[u] = A.D.base + (uint64_t)(pg * A.S + lo) * A.D.item_stride;
+      k[u] = bst[lo] + (ff - pre[lo]);
+    }
+#pragma unroll
+    for (int u = 0; u < MG_U; u++) key[u] = lv[u] ? ((const KS *)base[u])[k[u]] : (KS)0;
+#pragma unroll
+    for (int u = 0; u < MG_U; u++) {
+      slot[u] = 0;
+      if (!lv[u]) continue;
+      slot[u] = ltab_slot<KS>(lkeys, A.lbits, sh, key[u]);
+      if (slot[u] == ~0u) { lv[u] = false; slot[u] = 0; }
+    }
+    uint64_t goff = koff;
+    for (int a = 0; a < P.n_accs; a++) {
+      const AccSpec Ac = P.accs[a];
+      uint64_t part[MG_U];
+#pragma unroll
+      for (int u = 0; u < MG_U; u++)
+        part[u] = !lv[u] ? Ac.init : (Ac.width == 8 ? ((const uint64_t *)(base[u] + goff))[k[u]] : (uint64_t)((const uint32_t *)(base[u] + goff))[k[u]]);
+      goff += al16((uint64_t)A.D.cap * Ac.width);
+#pragma unroll
+      for (int u = 0; u < MG_U; u++) {
+        if (!lv[u] || part[u] == Ac.init) continue; // identity: nothing to fold
+        uint8_t *p = fsm + loff[a] + slot[u] * Ac.width;
         switch (Ac.op) {
-          case ACC_ADD_U64: atomicAdd((unsigned long long *)p, (unsigned long long)part); break;
-          case ACC_ADD_F64: atomicAdd((double *)p, __longlong_as_double((long long)part)); break;
-          case ACC_MIN_I64: atomicMin((long long *)p, (long long)part); break;
-          case ACC_MAX_I64: atomicMax((long long *)p, (long long)part); break;
-          case ACC_MIN_U64: atomicMin((unsigned long long *)p, (unsigned long long)part); break;
-          case ACC_MAX_U64: atomicMax((unsigned long long *)p, (unsigned long long)part); break;
-          case ACC_CNT_ALL: case ACC_CNT_VALID: atomicAdd((unsigned int *)p, (unsigned int)part); break;
-          case ACC_FIRST_ROW: atomicMin((unsigned int *)p, (unsigned int)part); break;
+          case ACC_ADD_U64: atomicAdd((unsigned long long *)p, (unsigned long long)part[u]); break;
+          case ACC_ADD_F64: atomicAdd((double *)p, __longlong_as_double((long long)part[u])); break;
+          case ACC_MIN_I64: atomicMin((long long *)p, (long long)part[u]); break;
+          case ACC_MAX_I64: atomicMax((long long *)p, (long long)part[u]); break;
+          case ACC_MIN_U64: atomicMin((unsigned long long *)p, (unsigned long long)part[u]); break;
+          case ACC_MAX_U64: atomicMax((unsigned long long *)p, (unsigned long long)part[u]); break;
+          case ACC_CNT_ALL: case ACC_CNT_VALID: atomicAdd((unsigned int *)p, (unsigned int)part[u]); break;
+          case ACC_FIRST_ROW: atomicMin((unsigned int *)p, (unsigned int)part[u]); break;
+        }
+      }
+    }
+  }
+  if (m == 0) { // the reserved entries (sentinel key, null key) sit behind the ordinary ones
+    for (uint32_t s = threadIdx.x; s < A.S; s += blockDim.x) {
+      const uint32_t item = pg * A.S + s;
+      const DumpHdr *H = &A.D.hdr[item];
+      const uint32_t nh = H->n_hash, hs = H->has_sent, hn = H->has_null;
+      const uint8_t *base = A.D.base + (uint64_t)item * A.D.item_stride;
+      for (uint32_t e = 0; e < hs + hn; e++) {
+        const bool is_sent = e == 0 && hs;
+        const uint32_t slot = is_sent ? lcap : lcap + 1;
+        sh[is_sent ? 0 : 1] = 1;
+        uint64_t goff = koff;
+        for (int a = 0; a < P.n_accs; a++) {
+          const AccSpec Ac = P.accs[a];
+          const uint64_t part = Ac.width == 8 ? ((const uint64_t *)(base + goff))[nh + e] : (uint64_t)((const uint32_t *)(base + goff))[nh + e];
+          goff += al16((uint64_t)A.D.cap * Ac.width);
+          if (part == Ac.init) continue;
+          uint8_t *p = fsm + loff[a] + slot * Ac.width;
+          switch (Ac.op) {
+            case ACC_ADD_U64: atomicAdd((unsigned long long *)p, (unsigned long long)part); break;
+            case ACC_ADD_F64: atomicAdd((double *)p, __longlong_as_double((long long)part)); break;
+            case ACC_MIN_I64: atomicMin((long long *)p, (long long)part); break;
+            case ACC_MAX_I64: atomicMax((long long *)p, (long long)part); break;
+            case ACC_MIN_U64: atomicMin((unsigned long long *)p, (unsigned long long)part); break;
+            case ACC_MAX_U64: atomicMax((unsigned long long *)p, (unsigned long long)part); break;
+            case ACC_CNT_ALL: case ACC_CNT_VALID: atomicAdd((unsigned int *)p, (unsigned int)part); break;
+            case ACC_FIRST_ROW: atomicMin((unsigned int *)p, (unsigned int)part); break;
+          }
         }
       }
     }
@@ -566,59 +850,16 @@ __global__ void __launch_bounds__(1024) k_merge_emit(Plan P, MergeArgs A, const 
   __syncthreads();
   if (sh[2] && threadIdx.x == 0) A.flags[FLAG_OVERFLOW] = 1;
   uint16_t *list = (uint16_t *)(fsm + table_lds_bytes(P, lslots, sizeof(KS)));
-  const uint32_t n_hash = build_list<KS>(lkeys, lcap, list, &sh[4]);
-  const uint32_t hs = sh[0] ? 1u : 0u, hn = sh[1] ? 1u : 0u;
-  const uint32_t n = n_hash + hs + hn;
-  if (threadIdx.x == 0) {
-    if (hs) list[n_hash] = (uint16_t)lcap;
-    if (hn) list[n_hash + hs] = (uint16_t)(lcap + 1);
-    sh[5] = n ? atomicAdd(&A.flags[FLAG_NGROUPS], n) : 0;
-  }
-  __syncthreads();
-  const uint64_t gbase = sh[5];
-  if (gbase + n > A.out_cap) { // the host sized the outputs from the table capacities: cannot happen unless they overflowed
-    if (threadIdx.x == 0) A.flags[FLAG_OVERFLOW] = 1;
-    return;
-  }
-  const OutPlan &O = *Op;
-  for (uint32_t k0 = 0; k0 < n; k0 += blockDim.x) { // a wave covers 64 consecutive output rows
-    const uint32_t k = k0 + threadIdx.x;
-    const bool livek = k < n;
-    const uint32_t s = livek ? list[k] : 0;
-    const uint64_t i = gbase + k;
-    const uint64_t packed = livek ? (uint64_t)lkeys[s] : 0;
-    for (int o = 0; o < O.n_outs; o++) {
-      const OutSpec &S = O.outs[o];
-      bool valid = false;
-      if (livek) {
-        if (S.kind == OUT_KEY) valid = finalize_key(P, S, packed, s == lcap + 1, s == lcap, i);
-        else {
-          uint64_t acc = 0;
-          if (S.acc >= 0) acc = P.accs[S.acc].width == 8 ? ((const uint64_t *)(fsm + loff[S.acc]))[s] : ((const uint32_t *)(fsm + loff[S.acc]))[s];
-          const uint32_t cnt_all = S.cnt_all >= 0 ? ((const uint32_t *)(fsm + loff[S.cnt_all]))[s] : 0;
-          const uint32_t cnt_valid = S.cnt_valid >= 0 ? ((const uint32_t *)(fsm + loff[S.cnt_valid]))[s] : cnt_all;
-          valid = finalize_value(S, acc, cnt_all, cnt_valid, i);
-        }
-      }
-      if (S.validity) { // bits [i0, i0 + 64) of a zeroed bitmap; other workgroups own the neighbouring bits
-        const unsigned long long mk = __ballot(valid);
-        if (mk) {
-          const uint64_t i0 = gbase + (k0 + (threadIdx.x & ~63u));
-          const uint32_t sft = (uint32_t)(i0 & 31);
-          const unsigned long long lo = mk << sft, hi = sft ? mk >> (64 - sft) : 0ull;
-          uint32_t word = lane == 0 ? (uint32_t)lo : lane == 1 ? (uint32_t)(lo >> 32) : (uint32_t)hi;
-          if (lane < 3 && word) atomicOr((unsigned int *)S.validity + (i0 >> 5) + lane, word);
-        }
-      }
-    }
-  }
+  emit_table<KS>(P, fsm, A.lbits, sh, bk, list, Op, A.flags, A.out_cap);
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// sampled cardinality (the analogue of estimate_unique_count, group_by_partitioned.rs:115-157): one
-// workgroup inserts 32-bit key fingerprints of a strided sample into an LDS set and counts them
+// sampled cardinality (the analogue of estimate_unique_count, group_by_partitioned.rs:115-157): workgroup j
+// of EST_WGS walks the same strided sample and keeps the keys whose hash falls into its share in an LDS set
+// of 32-bit fingerprints; the distinct counts add up to the sample's exact distinct count.
 // ---------------------------------------------------------------------------------------------------------
 #define EST_BITS 15
+#define EST_U 8
 __global__ void __launch_bounds__(1024) k_estimate(Plan P, int64_t n_sample, int64_t stride, uint32_t *flags) {
   __shared__ uint32_t set[1 << EST_BITS];
   __shared__ uint32_t cnt;
@@ -626,32 +867,78 @@ __global__ void __launch_bounds__(1024) k_estimate(Plan P, int64_t n_sample, int
   if (threadIdx.x == 0) cnt = 0;
   __syncthreads();
   uint32_t mine = 0;
-  for (int64_t i = threadIdx.x; i < n_sample; i += blockDim.x) {
-    bool isn;
-    const uint64_t key = row_packed_key(P, i * stride, isn);
-    uint32_t f = isn ? 0x7FFFFFFEu : (uint32_t)(hash_key(key) >> 32);
-    if (f == 0xFFFFFFFFu) f = 0x7FFFFFFFu;
-    uint32_t s = f & ((1u << EST_BITS) - 1);
-    for (int it = 0; it < (1 << EST_BITS); it++) {
-      uint32_t k = set[s];
-      if (k == f) break;
-      if (k == 0xFFFFFFFFu) {
-        k = atomicCAS(&set[s], 0xFFFFFFFFu, f);
-        if (k == 0xFFFFFFFFu) { mine++; break; }
+  for (int64_t i0 = 0; i0 < n_sample; i0 += (int64_t)blockDim.x * EST_U) {
+    uint64_t h[EST_U];
+    bool lv[EST_U];
+#pragma unroll
+    for (int u = 0; u < EST_U; u++) { // the loads of one batch are independent: they are in flight together
+      const int64_t i = i0 + (int64_t)u * blockDim.x + threadIdx.x;
+      lv[u] = i < n_sample;
+      bool isn;
+      const uint64_t key = row_packed_key(P, (lv[u] ? i : 0) * stride, isn);
+      h[u] = isn ? 0x9E3779B97F4A7C15ull : hash_key(key);
+    }
+#pragma unroll
+    for (int u = 0; u < EST_U; u++) {
+      if (!lv[u] || (uint32_t)(h[u] >> 20) % gridDim.x != blockIdx.x) continue;
+      uint32_t f = (uint32_t)(h[u] >> 32);
+      if (f == 0xFFFFFFFFu) f = 0x7FFFFFFFu;
+      uint32_t s = f & ((1u << EST_BITS) - 1);
+      for (int it = 0; it < (1 << EST_BITS); it++) {
+        uint32_t k = set[s];
         if (k == f) break;
+        if (k == 0xFFFFFFFFu) {
+          k = atomicCAS(&set[s], 0xFFFFFFFFu, f);
+          if (k == 0xFFFFFFFFu) { mine++; break; }
+          if (k == f) break;
+        }
+        s = (s + 1) & ((1u << EST_BITS) - 1);
       }
-      s = (s + 1) & ((1u << EST_BITS) - 1);
     }
   }
   if (mine) atomicAdd(&cnt, mine);
   __syncthreads();
-  if (threadIdx.x == 0) flags[FLAG_NGROUPS] = cnt;
+  if (threadIdx.x == 0 && cnt) atomicAdd(&flags[FLAG_NGROUPS], cnt);
+}
+
+// ---- pre-instantiated shapes (accumulators in lowered order: sorted by source column, counters first) ------
+using ShSumI32 = StShape<USeq<PLHIP_I32>, USeq<ACC_ENC(ACC_ADD_U64, CONV_INT, 0, 8)>>;                                  // q1
+using ShSumI32MeanF64 = StShape<USeq<PLHIP_I32, PLHIP_F64>,                                                             // q3
+                                USeq<ACC_ENC(ACC_CNT_ALL, CONV_NONE, -1, 4), ACC_ENC(ACC_ADD_U64, CONV_INT, 0, 8),
+                                     ACC_ENC(ACC_ADD_F64, CONV_F64, 1, 8)>>;
+using ShSum3 = StShape<USeq<PLHIP_I32, PLHIP_I32, PLHIP_F64>,                                                           // q5
+                       USeq<ACC_ENC(ACC_ADD_U64, CONV_INT, 0, 8), ACC_ENC(ACC_ADD_U64, CONV_INT, 1, 8),
+                            ACC_ENC(ACC_ADD_F64, CONV_F64, 2, 8)>>;
+using ShWide = StShape<USeq<PLHIP_I64, PLHIP_F64>,                                         // i64 sum/min/max, f64 sum/mean, count
+                       USeq<ACC_ENC(ACC_CNT_ALL, CONV_NONE, -1, 4), ACC_ENC(ACC_ADD_U64, CONV_INT, 0, 8),
+                            ACC_ENC(ACC_MIN_I64, CONV_INT, 0, 8), ACC_ENC(ACC_MAX_I64, CONV_INT, 0, 8),
+                            ACC_ENC(ACC_ADD_F64, CONV_F64, 1, 8)>>;
+using ShSumF64 = StShape<USeq<PLHIP_F64>, USeq<ACC_ENC(ACC_ADD_F64, CONV_F64, 0, 8)>>;
+using ShSumI64 = StShape<USeq<PLHIP_I64>, USeq<ACC_ENC(ACC_ADD_U64, CONV_INT, 0, 8)>>;
+#define FP_SHAPES(X) X(0, ShSumI32) X(1, ShSumI32MeanF64) X(2, ShSum3) X(3, ShWide) X(4, ShSumF64) X(5, ShSumI64)
+
+template <typename SH>
+bool shape_matches(const Plan &p) {
+  if (p.n_vals != SH::n_vals(p) || p.n_accs != SH::n_accs(p)) return false;
+  for (int c = 0; c < p.n_vals; c++)
+    if (p.vals[c].dtype != SH::val_dtype(p, c) || p.vals[c].validity) return false;
+  for (int a = 0; a < p.n_accs; a++)
+    if (p.accs[a].op != SH::acc_op(p, a) || p.accs[a].conv != SH::acc_conv(p, a) || p.accs[a].src != SH::acc_src(p, a) ||
+        p.accs[a].width != SH::acc_width(p, a))
+      return false;
+  return true;
+}
+int find_shape(const Plan &p) {
+#define X(i, SH) if (shape_matches<SH>(p)) return i;
+  FP_SHAPES(X)
+#undef X
+  return -1;
 }
 
 template <typename F>
 void allow_big_lds(F f) {
-  // static LDS (flags, histogram) comes on top of the dynamic part: leave 8 KB for it
-  if (hipFuncSetAttribute((const void *)f, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess) (void)hipGetLastError();
+  // static LDS (flags, histogram, merge prefix arrays) comes on top of the dynamic part
+  if (hipFuncSetAttribute((const void *)f, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess) (void)hipGetLastError();
 }
 
 } // namespace
@@ -660,7 +947,7 @@ void allow_big_lds(F f) {
 // host side
 // ---------------------------------------------------------------------------------------------------------
 size_t fast_table_bytes(const Plan &p, uint32_t lbits, int key_bytes) {
-  const size_t lslots = ((size_t)1 << lbits) + 2;
+  const size_t lslots = ((size_t)1 << lbits) + FP_EXTRA_SLOTS;
   size_t off = (lslots * key_bytes + 7) & ~(size_t)7;
   for (int a = 0; a < p.n_accs; a++) off += (lslots * p.accs[a].width + 7) & ~(size_t)7;
   return off + lslots * 2 + 16; // + the u16 slot list of the dump / emit step
@@ -672,20 +959,34 @@ uint64_t fast_dump_stride(const Plan &p, uint32_t cap, int key_bytes) {
   return (off + 255) & ~255ull;
 }
 
-void launch_fold_rows(const Plan &p, const FoldRowsArgs &a, int key_bytes, bool quad, uint32_t n_items, uint32_t block, hipStream_t s) {
+template <typename KS, bool QUAD, typename SH>
+void launch_fold_rows_t(const Plan &p, const FoldRowsArgs &a, size_t bytes, uint32_t n_items, uint32_t block, hipStream_t s) {
   static bool once = false;
-  if (!once) {
-    allow_big_lds(k_fold_rows<uint32_t, true>); allow_big_lds(k_fold_rows<uint32_t, false>);
-    allow_big_lds(k_fold_rows<uint64_t, true>); allow_big_lds(k_fold_rows<uint64_t, false>);
-    once = true;
-  }
+  if (!once) { allow_big_lds(k_fold_rows<KS, QUAD, SH>); once = true; }
+  hipLaunchKernelGGL((k_fold_rows<KS, QUAD, SH>), dim3(n_items), dim3(block), bytes, s, p, a);
+}
+
+int fast_shape_id(const Plan &p) { return find_shape(p); }
+
+void launch_fold_rows(const Plan &p, const FoldRowsArgs &a, int key_bytes, bool quad, uint32_t n_items, uint32_t block, hipStream_t s) {
   const size_t bytes = fast_table_bytes(p, a.lbits, key_bytes);
+  const int sid = quad ? find_shape(p) : -1; // static shapes are built for the aligned (vector load) case only
+  switch (sid) {
+#define X(i, SH)                                                                                   \
+  case i:                                                                                          \
+    if (key_bytes == 4) launch_fold_rows_t<uint32_t, true, SH>(p, a, bytes, n_items, block, s);    \
+    else launch_fold_rows_t<uint64_t, true, SH>(p, a, bytes, n_items, block, s);                   \
+    return;
+    FP_SHAPES(X)
+#undef X
+    default: break;
+  }
   if (key_bytes == 4) {
-    if (quad) hipLaunchKernelGGL((k_fold_rows<uint32_t, true>), dim3(n_items), dim3(block), bytes, s, p, a);
-    else hipLaunchKernelGGL((k_fold_rows<uint32_t, false>), dim3(n_items), dim3(block), bytes, s, p, a);
+    if (quad) launch_fold_rows_t<uint32_t, true, RtShape>(p, a, bytes, n_items, block, s);
+    else launch_fold_rows_t<uint32_t, false, RtShape>(p, a, bytes, n_items, block, s);
   } else {
-    if (quad) hipLaunchKernelGGL((k_fold_rows<uint64_t, true>), dim3(n_items), dim3(block), bytes, s, p, a);
-    else hipLaunchKernelGGL((k_fold_rows<uint64_t, false>), dim3(n_items), dim3(block), bytes, s, p, a);
+    if (quad) launch_fold_rows_t<uint64_t, true, RtShape>(p, a, bytes, n_items, block, s);
+    else launch_fold_rows_t<uint64_t, false, RtShape>(p, a, bytes, n_items, block, s);
   }
 }
 
@@ -698,13 +999,27 @@ void launch_tile_sort(const Plan &p, const PartOut &o, uint32_t pbits, uint32_t 
   else hipLaunchKernelGGL(k_tile_sort<uint64_t>, dim3(n_tiles), dim3(TS_BLOCK), bytes, s, p, o, pbits, n_tiles, offs, keymode, kxor);
 }
 
-void launch_fold_runs(const Plan &p2, const FoldRunsArgs &a, int key_bytes, uint32_t block, hipStream_t s) {
+template <typename KS, typename SH>
+void launch_fold_runs_t(const Plan &p2, const FoldRunsArgs &a, const OutPlan *o_dev, size_t bytes, uint32_t block, hipStream_t s) {
   static bool once = false;
-  if (!once) { allow_big_lds(k_fold_runs<uint32_t>); allow_big_lds(k_fold_runs<uint64_t>); once = true; }
+  if (!once) { allow_big_lds(k_fold_runs<KS, SH>); once = true; }
+  hipLaunchKernelGGL((k_fold_runs<KS, SH>), dim3(a.n_pg * a.S), dim3(block), bytes, s, p2, a, o_dev);
+}
+
+void launch_fold_runs(const Plan &p2, const FoldRunsArgs &a, const OutPlan *o_dev, int key_bytes, uint32_t block, hipStream_t s) {
   const size_t bytes = fast_table_bytes(p2, a.lbits, key_bytes);
-  const uint32_t grid = a.n_pg * a.S;
-  if (key_bytes == 4) hipLaunchKernelGGL(k_fold_runs<uint32_t>, dim3(grid), dim3(block), bytes, s, p2, a);
-  else hipLaunchKernelGGL(k_fold_runs<uint64_t>, dim3(grid), dim3(block), bytes, s, p2, a);
+  switch (find_shape(p2)) {
+#define X(i, SH)                                                                              \
+  case i:                                                                                     \
+    if (key_bytes == 4) launch_fold_runs_t<uint32_t, SH>(p2, a, o_dev, bytes, block, s);      \
+    else launch_fold_runs_t<uint64_t, SH>(p2, a, o_dev, bytes, block, s);                     \
+    return;
+    FP_SHAPES(X)
+#undef X
+    default: break;
+  }
+  if (key_bytes == 4) launch_fold_runs_t<uint32_t, RtShape>(p2, a, o_dev, bytes, block, s);
+  else launch_fold_runs_t<uint64_t, RtShape>(p2, a, o_dev, bytes, block, s);
 }
 
 void launch_merge_emit(const Plan &p, const MergeArgs &a, const OutPlan *o_dev, int key_bytes, uint32_t n_pg, uint32_t block, hipStream_t s) {
@@ -716,6 +1031,6 @@ void launch_merge_emit(const Plan &p, const MergeArgs &a, const OutPlan *o_dev, 
   else hipLaunchKernelGGL(k_merge_emit<uint64_t>, dim3(grid), dim3(block), bytes, s, p, a, o_dev);
 }
 
-void launch_estimate(const Plan &p, int64_t n_sample, int64_t stride, uint32_t *flags, hipStream_t s) {
-  hipLaunchKernelGGL(k_estimate, dim3(1), dim3(1024), 0, s, p, n_sample, stride, flags);
+void launch_estimate(const Plan &p, int64_t n_sample, int64_t stride, uint32_t n_wgs, uint32_t *flags, hipStream_t s) {
+  hipLaunchKernelGGL(k_estimate, dim3(n_wgs), dim3(1024), 0, s, p, n_sample, stride, flags);
 }

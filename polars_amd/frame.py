@@ -261,6 +261,12 @@ def last_kernel_ms() -> tuple[float, float, str]:
     return t.value, d.value, (k.value or b"").decode()
 
 
+def last_kernel_breakdown() -> tuple[float, float, float]:
+    a, b, c = C.c_float(), C.c_float(), C.c_float()
+    _ffi.check(_ffi.lib().plhip_last_kernel_breakdown(C.byref(a), C.byref(b), C.byref(c)))
+    return a.value, b.value, c.value
+
+
 def group_by_agg_raw(keys: Sequence[Column], values: Sequence[Column], aggs: Sequence[tuple[int, int]],
                      flags: int = 0, n_groups_hint: int = 0):
     """Thin call of plhip_group_by_agg.  Returns (handle, [ColumnStruct...]); the caller must
