@@ -733,8 +733,13 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
   bool direct = false;
   uint32_t lbits = 0, block = 1024;
   {
-    const uint32_t lb = (uint32_t)std::max(6, ceil_log2(2 * g_est + 2));
-    if (lb <= 15 && fast_table_bytes(P, lb, key_bytes) <= LDS_MAX) { direct = true; lbits = lb; }
+    // sparse tables (<= 1/8 full when LDS allows) keep most probes at the home slot
+    uint32_t lb = (uint32_t)std::max(6, ceil_log2(2 * g_est + 2));
+    if (lb <= 15 && fast_table_bytes(P, lb, key_bytes) <= LDS_MAX) {
+      direct = true;
+      while (lb < 15 && (1ull << lb) < 8 * g_est && fast_table_bytes(P, lb + 1, key_bytes) <= 64 * 1024) lb++;
+      lbits = lb;
+    }
   }
   if (strategy == PLHIP_STRATEGY_TILESORT) direct = false;
   if (strategy == PLHIP_STRATEGY_DIRECT && !direct) return PLHIP_OK;
@@ -768,6 +773,7 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
     if (gf > 0.45 * (double)(1u << lb_max)) return PLHIP_OK; // needs a second partition level: general path
     lbits = 6;
     while (gf * w > 0.45 * (double)(1u << lbits)) lbits++;
+    while (lbits < lb_max && gf * w > 0.125 * (double)(1u << lbits) && fast_table_bytes(P, lbits + 1, key_bytes) <= 100 * 1024) lbits++;
     has_null_pg = (P.single_key && dk[0].validity) ? 1 : 0;
     n_pg = np / w + has_null_pg;
     S = 1; // one workgroup per partition: it writes the output columns itself
@@ -858,14 +864,14 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
     FoldRunsArgs A{};
     A.pkeys = O.keys; A.out_cap = out_cap;
     A.D = D; A.flags = dflags; A.offs = (const uint32_t *)c.offs.p; A.lbits = lbits; A.np = np; A.w = w; A.n_pg = n_pg;
-    A.has_null_pg = has_null_pg; A.S = S; A.n_tiles = n_tiles;
+    A.has_null_pg = has_null_pg; A.S = S; A.n_tiles = n_tiles; A.pbits = pbits;
     launch_fold_runs(P2, A, (const OutPlan *)c.plans.p, key_bytes, block, c.stream);
     if ((e = hipGetLastError()) != hipSuccess) { delete R; return fail_hip(e, "k_fold_runs launch"); }
     c.strategy = "tilesort";
   }
   hipEventRecord(c.ev[5], c.stream);
   MergeArgs M{};
-  M.D = D; M.flags = dflags; M.out_cap = out_cap; M.lbits = lbits; M.S = S; M.mbits = mbits;
+  M.D = D; M.flags = dflags; M.out_cap = out_cap; M.lbits = lbits; M.S = S; M.mbits = mbits; M.pshift = direct ? 0u : pbits;
   if (direct || S > 1) {
     launch_merge_emit(P, M, (const OutPlan *)c.plans.p, key_bytes, direct ? 1u : n_pg, 1024, c.stream);
     if ((e = hipGetLastError()) != hipSuccess) { delete R; return fail_hip(e, "k_merge_emit launch"); }

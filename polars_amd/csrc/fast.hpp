@@ -63,7 +63,7 @@ struct FoldRunsArgs {
   uint32_t has_null_pg;
   uint32_t S;        // tile segments per group
   uint32_t n_tiles;
-  uint32_t pad;
+  uint32_t pbits; // log2(np): the hash bits the tile sort consumed
 };
 
 struct MergeArgs {
@@ -73,7 +73,7 @@ struct MergeArgs {
   uint32_t lbits;
   uint32_t S;     // dumps per partition group
   uint32_t mbits; // merge workgroups per partition group = 1 << mbits (split by key hash)
-  uint32_t pad;
+  uint32_t pshift; // hash bits consumed by the tile sort (0 for row-slice dumps)
 };
 
 int fast_shape_id(const Plan &p); // index of the pre-instantiated shape the plan matches, or -1 (run-time shape)

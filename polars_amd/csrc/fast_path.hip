@@ -37,12 +37,18 @@ DEVINL uint64_t cas_key(uint64_t *p, uint64_t expect, uint64_t val) {
 
 // used[0]: sentinel slot taken, used[1]: null slot taken, used[2]: table full
 #define FP_PROBE_LIMIT 96
+// Home slot: the bits of the Fibonacci product right below the `pshift` bits the tile sort partitions on
+// (pshift = 0 when the rows were not partitioned): one multiply and one bit-field extract per row.
+DEVINL uint32_t mix_key(uint32_t k) { return k * 0x9E3779B1u; }
+DEVINL uint32_t mix_key(uint64_t k) { return mix_a(k); }
+DEVINL uint32_t home_slot(uint32_t a, uint32_t lbits, uint32_t pshift) { return (a << pshift) >> (32 - lbits); }
+
 template <typename KS>
-DEVINL uint32_t ltab_slot(KS *lkeys, uint32_t lbits, uint32_t *used, KS k0) {
+DEVINL uint32_t ltab_slot(KS *lkeys, uint32_t lbits, uint32_t pshift, uint32_t *used, KS k0) {
   const uint32_t lcap = 1u << lbits;
   if (k0 == KE<KS>::v) { used[0] = 1; return lcap; }
   const uint32_t mask = lcap - 1;
-  uint32_t s = lds_home(mix_a((uint64_t)k0), lbits);
+  uint32_t s = home_slot(mix_key(k0), lbits, pshift);
   for (int i = 0; i < FP_PROBE_LIMIT; i++) {
     KS k = lkeys[s];
     if (k == k0) return s;
@@ -219,7 +225,7 @@ DEVINL uint32_t lslots_of(uint32_t lbits) { return (1u << lbits) + FP_EXTRA_SLOT
 // round trip per batch; the B probes of a lane advance together, one batched LDS read per probe step.
 template <typename KS, int B, bool QUAD, int NPRE, typename SH>
 DEVINL void fold_batch(const Plan &P, uint8_t *sm, uint32_t lbits, uint32_t *used, const uint32_t (&row)[B], uint32_t live,
-                       int keymode, const uint8_t *kvals, uint64_t kxor, bool force_null) {
+                       int keymode, const uint8_t *kvals, uint64_t kxor, bool force_null, uint32_t pshift) {
   const uint32_t lcap = 1u << lbits, lslots = lcap + FP_EXTRA_SLOTS, trash = lcap + 2 + (threadIdx.x & 63), mask = lcap - 1;
   KS *lkeys = (KS *)sm;
   KS key[B];
@@ -245,42 +251,56 @@ DEVINL void fold_batch(const Plan &P, uint8_t *sm, uint32_t lbits, uint32_t *use
     if (c < SH::n_vals(P)) load_raw<B, QUAD>(P.vals[c].values, wbytes(SH::val_dtype(P, c)), row, pre[c]);
 
   // ---- slots -----------------------------------------------------------------------------------------------
+  // Every row probes, dead rows too: the caller clamps them to a real row of the same table, so at worst they
+  // look up a key that is (or will be) there anyway; they are steered to the trash slot afterwards.  That
+  // keeps the common path free of per-row branches: hash, one batched LDS read, compare.
   uint32_t slot[B];
   if (force_null) {
     if (live) used[1] = 1;
 #pragma unroll
-    for (int b = 0; b < B; b++) slot[b] = ((live >> b) & 1) ? lcap + 1 : trash;
+    for (int b = 0; b < B; b++) slot[b] = lcap + 1;
   } else {
-    uint32_t pend = 0, sentm = 0;
+    bool any_sent = false;
 #pragma unroll
     for (int b = 0; b < B; b++) {
-      const bool lv = (live >> b) & 1, isn = (nullm >> b) & 1, sent = key[b] == KE<KS>::v;
-      slot[b] = !lv ? trash : isn ? lcap + 1 : sent ? lcap : lds_home(mix_a((uint64_t)key[b]), lbits);
-      if (lv && !isn && sent) sentm = 1;
-      if (lv && !isn && !sent) pend |= 1u << b;
+      slot[b] = home_slot(mix_key(key[b]), lbits, pshift);
+      any_sent |= key[b] == KE<KS>::v;
     }
-    if (nullm & live) used[1] = 1;
-    if (sentm) used[0] = 1;
-    for (int step = 0; pend; step++) {
-      KS k[B];
+    KS k[B];
 #pragma unroll
-      for (int b = 0; b < B; b++) k[b] = lkeys[slot[b] < lcap ? slot[b] : 0]; // batched; only pending rows look at it
+    for (int b = 0; b < B; b++) k[b] = lkeys[slot[b]];
+    uint32_t pend = 0;
+#pragma unroll
+    for (int b = 0; b < B; b++) pend |= (k[b] != key[b]) ? 1u << b : 0u;
+    if (any_sent || nullm) { // rare: rows that live in the reserved slots
 #pragma unroll
       for (int b = 0; b < B; b++) {
-        if (!((pend >> b) & 1)) continue;
-        KS kb = k[b];
-        if (kb == KE<KS>::v) kb = cas_key(&lkeys[slot[b]], KE<KS>::v, key[b]); // returns EMPTY when the claim won
-        if (kb == key[b] || kb == KE<KS>::v) pend &= ~(1u << b);
-        else slot[b] = (slot[b] + 1) & mask;
-      }
-      if (step >= FP_PROBE_LIMIT && pend) { // table full: the host redoes the query on the general path
-        used[2] = 1;
-#pragma unroll
-        for (int b = 0; b < B; b++) if ((pend >> b) & 1) { slot[b] = trash; live &= ~(1u << b); }
-        pend = 0;
+        if ((nullm >> b) & 1) { slot[b] = lcap + 1; pend &= ~(1u << b); if ((live >> b) & 1) used[1] = 1; }
+        else if (key[b] == KE<KS>::v) { slot[b] = lcap; pend &= ~(1u << b); if ((live >> b) & 1) used[0] = 1; }
       }
     }
+    // the rest (new keys, displaced keys): every trip takes ONE pending row of each lane through the probe
+    // loop, so the trip count is the largest number of such rows any lane of the wave holds
+    while (pend) {
+      const int bsel = __ffs((int)pend) - 1;
+      pend &= pend - 1;
+      KS kk = key[0];
+      uint32_t ss = slot[0];
+#pragma unroll
+      for (int b = 1; b < B; b++) if (bsel == b) { kk = key[b]; ss = slot[b]; }
+      for (int step = 0;; step++) {
+        KS kb = lkeys[ss];
+        if (kb == KE<KS>::v) kb = cas_key(&lkeys[ss], KE<KS>::v, kk); // returns EMPTY when the claim won
+        if (kb == kk || kb == KE<KS>::v) break;
+        ss = (ss + 1) & mask;
+        if (step >= FP_PROBE_LIMIT) { used[2] = 1; ss = trash; break; } // table full: the host redoes the query
+      }
+#pragma unroll
+      for (int b = 0; b < B; b++) if (bsel == b) slot[b] = ss;
+    }
   }
+#pragma unroll
+  for (int b = 0; b < B; b++) slot[b] = ((live >> b) & 1) ? slot[b] : trash;
 
   // ---- accumulators: unconditional LDS atomics, rows that do not count go to the trash slot ----------------
   uint32_t off = al8(lslots * (uint32_t)sizeof(KS));
@@ -561,8 +581,8 @@ __global__ void __launch_bounds__(1024) k_fold_rows(Plan P, FoldRowsArgs A) {
     }
     if (!live) continue;
     // a batch that holds the end of the column is read with scalar loads: its last quad may be cut
-    if (QUAD && live != (1u << ROWS_B) - 1u) fold_batch<KS, ROWS_B, false, ROWS_NPRE, SH>(P, fsm, A.lbits, sh, row, live, A.keymode, P.keys[0].values, A.kxor, false);
-    else fold_batch<KS, ROWS_B, QUAD, ROWS_NPRE, SH>(P, fsm, A.lbits, sh, row, live, A.keymode, P.keys[0].values, A.kxor, false);
+    if (QUAD && live != (1u << ROWS_B) - 1u) fold_batch<KS, ROWS_B, false, ROWS_NPRE, SH>(P, fsm, A.lbits, sh, row, live, A.keymode, P.keys[0].values, A.kxor, false, 0u);
+    else fold_batch<KS, ROWS_B, QUAD, ROWS_NPRE, SH>(P, fsm, A.lbits, sh, row, live, A.keymode, P.keys[0].values, A.kxor, false, 0u);
   }
   __syncthreads();
   if (sh[2] && threadIdx.x == 0) A.flags[FLAG_OVERFLOW] = 1;
@@ -640,26 +660,19 @@ __global__ void __launch_bounds__(TS_BLOCK) k_tile_sort(Plan P, PartOut O, uint3
   stage_and_store<KS>(fsm, key, pos, live, O.keys + (size_t)r0 * sizeof(KS), nt);
   for (int v = 0; v < P.n_vals; v++) {
     const ValSpec V = P.vals[v];
-    const uint32_t w = wbytes(V.dtype);
-    uint64_t raw[TS_R];
-    load_raw<TS_R, false>(V.values, w, row, raw);
-    if (w == 8) {
-      stage_and_store<uint64_t>(fsm, raw, pos, live, O.vals[v] + (size_t)r0 * 8, nt);
-    } else if (w == 4) {
-      uint32_t x[TS_R];
-#pragma unroll
-      for (int r = 0; r < TS_R; r++) x[r] = (uint32_t)raw[r];
-      stage_and_store<uint32_t>(fsm, x, pos, live, O.vals[v] + (size_t)r0 * 4, nt);
-    } else if (w == 2) {
-      uint16_t x[TS_R];
-#pragma unroll
-      for (int r = 0; r < TS_R; r++) x[r] = (uint16_t)raw[r];
-      stage_and_store<uint16_t>(fsm, x, pos, live, O.vals[v] + (size_t)r0 * 2, nt);
-    } else {
-      uint8_t x[TS_R];
-#pragma unroll
-      for (int r = 0; r < TS_R; r++) x[r] = (uint8_t)raw[r];
-      stage_and_store<uint8_t>(fsm, x, pos, live, O.vals[v] + (size_t)r0, nt);
+    switch (wbytes(V.dtype)) { // typed loads: a 4-byte column costs TS_R registers, not 2 * TS_R
+#define SORT_COL(T)                                                                                     \
+  {                                                                                                     \
+    T x[TS_R];                                                                                          \
+    _Pragma("unroll") for (int r = 0; r < TS_R; r++) x[r] = ((const T *)V.values)[row[r]];              \
+    stage_and_store<T>(fsm, x, pos, live, O.vals[v] + (size_t)r0 * sizeof(T), nt);                      \
+  }                                                                                                     \
+  break;
+      case 1: SORT_COL(uint8_t)
+      case 2: SORT_COL(uint16_t)
+      case 4: SORT_COL(uint32_t)
+      default: SORT_COL(uint64_t)
+#undef SORT_COL
     }
     if (O.valid[v]) {
       uint8_t x[TS_R];
@@ -684,7 +697,15 @@ __global__ void __launch_bounds__(1024) k_fold_runs(Plan P, FoldRunsArgs A, cons
   if (threadIdx.x < 8) sh[threadIdx.x] = 0;
   ltab_init<KS>(P, fsm, lslots);
   __syncthreads();
-  const uint32_t item = blockIdx.x, pg = item / A.S, seg = item % A.S;
+  // Neighbouring partitions share the cache lines at their run boundaries.  Workgroups b, b + 8, b + 16, ...
+  // are observed to land on one XCD, so they are given neighbouring partitions: the second reader of a line
+  // then hits in that XCD's L2 instead of fetching it over the fabric again (speed only, never correctness).
+  uint32_t item = blockIdx.x;
+  {
+    const uint32_t n8 = gridDim.x & ~7u;
+    if (item < n8) item = (item & 7u) * (n8 >> 3) + (item >> 3);
+  }
+  const uint32_t pg = item / A.S, seg = item % A.S;
   const bool null_pg = A.has_null_pg && pg == A.n_pg - 1;
   const uint32_t p0 = null_pg ? A.np : pg * A.w, p1 = null_pg ? A.np + 1 : p0 + A.w;
   const uint32_t per = (A.n_tiles + A.S - 1) / A.S;
@@ -708,6 +729,13 @@ __global__ void __launch_bounds__(1024) k_fold_runs(Plan P, FoldRunsArgs A, cons
       n_[b] = (uint32_t)__builtin_amdgcn_readlane((int)len, b);
       maxlen = n_[b] > maxlen ? n_[b] : maxlen;
     }
+    // dead lanes still look their (clamped) row's key up: an empty run must not point them at another
+    // partition's rows, so it borrows the start of a run of this batch that has rows
+    uint32_t s_any = s_[0];
+#pragma unroll
+    for (int b = 0; b < RUNS_B; b++) if (n_[b]) s_any = s_[b];
+#pragma unroll
+    for (int b = 0; b < RUNS_B; b++) if (!n_[b]) s_[b] = s_any;
     for (uint32_t i0 = 0; i0 < maxlen; i0 += 64) {
       uint32_t row[RUNS_B];
       uint32_t live = 0;
@@ -717,7 +745,7 @@ __global__ void __launch_bounds__(1024) k_fold_runs(Plan P, FoldRunsArgs A, cons
         if (i < n_[b]) live |= 1u << b;
         row[b] = s_[b] + (i < n_[b] ? i : 0); // dead lanes read the run's first row (or the padded row behind the data)
       }
-      fold_batch<KS, RUNS_B, false, RUNS_NPRE, SH>(P, fsm, A.lbits, sh, row, live, keymode, A.pkeys, 0ull, null_pg);
+      fold_batch<KS, RUNS_B, false, RUNS_NPRE, SH>(P, fsm, A.lbits, sh, row, live, keymode, A.pkeys, 0ull, null_pg, A.pbits);
     }
     t = tn; st = stn; len = lenn;
   }
@@ -788,7 +816,7 @@ __global__ void __launch_bounds__(1024) k_merge_emit(Plan P, MergeArgs A, const 
     for (int u = 0; u < MG_U; u++) {
       slot[u] = 0;
       if (!lv[u]) continue;
-      slot[u] = ltab_slot<KS>(lkeys, A.lbits, sh, key[u]);
+      slot[u] = ltab_slot<KS>(lkeys, A.lbits, A.pshift, sh, key[u]);
       if (slot[u] == ~0u) { lv[u] = false; slot[u] = 0; }
     }
     uint64_t goff = koff;
