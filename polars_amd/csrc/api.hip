@@ -705,10 +705,12 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
   uint64_t g_est;
   if (groups_hint > 0) g_est = (uint64_t)std::min<int64_t>(groups_hint, n);
   else {
-    const int64_t ns = std::min<int64_t>(n, 1 << 18);
-    const uint32_t est_wgs = ns <= (1 << 14) ? 1u : 16u; // 16 LDS sets of 32K slots hold any 256K-key sample
+    const int64_t ns = n <= (1 << 17) ? n : (1 << 17); // whole 256-row blocks when sampling
+    const uint32_t set_bits = (uint32_t)std::max(10, ceil_log2((uint64_t)ns * 4));
+    HIP_TRY(c.table.reserve((size_t)4 << set_bits));
+    HIP_TRY(hipMemsetAsync(c.table.p, 0xFF, (size_t)4 << set_bits, c.stream));
     HIP_TRY(hipMemsetAsync(dflags, 0, 64, c.stream));
-    launch_estimate(P, ns, n / ns, est_wgs, dflags, c.stream);
+    launch_estimate(P, ns, ns == n ? 256 : n / (ns >> 8), (uint32_t *)c.table.p, set_bits, dflags, c.stream);
     HIP_TRY(hipGetLastError());
     TableRef t{nullptr, 0, dflags};
     uint32_t f[16];
@@ -754,9 +756,9 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
     // pre-instantiated shapes need < 64 VGPRs (8 waves per SIMD), the run-time shape ~112 (4 waves per SIMD)
     const bool st = fast_shape_id(P) >= 0;
     int wg_per_cu;
-    if (tb <= 18 * 1024 && st) { block = 256; wg_per_cu = 8; }
-    else if (tb <= 36 * 1024) { block = st ? 512 : 256; wg_per_cu = 4; }
-    else if (tb <= 72 * 1024) { block = st ? 1024 : 512; wg_per_cu = 2; }
+    // few, large workgroups: every workgroup initialises and dumps a table of its own
+    if (tb <= 72 * 1024 && st) { block = 1024; wg_per_cu = 2; }
+    else if (tb <= 72 * 1024) { block = 512; wg_per_cu = 2; }
     else { block = 1024; wg_per_cu = 1; }
     const int64_t step = (int64_t)block * (st ? 8 : 4); // rows one workgroup folds per loop trip
     int64_t items = std::max<int64_t>(1, std::min<int64_t>((int64_t)cus * wg_per_cu, (n + step - 1) / step));

@@ -85,4 +85,5 @@ void launch_tile_sort(const Plan &p, const PartOut &o, uint32_t pbits, uint32_t 
 void launch_fold_runs(const Plan &p2, const FoldRunsArgs &a, const OutPlan *o_dev, int key_bytes, uint32_t block, hipStream_t s);
 void launch_merge_emit(const Plan &p, const MergeArgs &a, const OutPlan *o_dev, int key_bytes, uint32_t n_pg, uint32_t block, hipStream_t s);
 // distinct keys among `n_sample` rows taken every `stride` rows -> flags[FLAG_NGROUPS]
-void launch_estimate(const Plan &p, int64_t n_sample, int64_t stride, uint32_t n_wgs, uint32_t *flags, hipStream_t s);
+// `set`: scratch of 1 << set_bits u32 filled with 0xFF bytes (at least 4x the sample)
+void launch_estimate(const Plan &p, int64_t n_sample, int64_t stride, uint32_t *set, uint32_t set_bits, uint32_t *flags, hipStream_t s);

@@ -18,6 +18,10 @@ template <typename KS> struct KE;
 template <> struct KE<uint32_t> { static constexpr uint32_t v = 0xFFFFFFFFu; };
 template <> struct KE<uint64_t> { static constexpr uint64_t v = 0xFFFFFFFFFFFFFFFFull; };
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global load
+// and store of the wave (s_waitcnt vmcnt(0)), which serialises a kernel that streams through LDS.
+DEVINL void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 DEVINL uint32_t al8(uint32_t x) { return (x + 7u) & ~7u; }
 DEVINL uint64_t al16(uint64_t x) { return (x + 15ull) & ~15ull; }
 
@@ -550,6 +554,33 @@ DEVINL uint32_t block_scan_excl(uint32_t x, uint32_t *tmp /* [16] */) {
   return tmp[wave] + inc - x;
 }
 
+// the same with LDS-only barriers (tile sort: global loads / stores stay in flight)
+// exclusive scan of one value per thread over the workgroup (blockDim.x a multiple of 64, <= 1024)
+DEVINL uint32_t block_scan_excl_lds(uint32_t x, uint32_t *tmp /* [16] */) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  uint32_t inc = x;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(inc, off);
+    if (lane >= (uint32_t)off) inc += t;
+  }
+  lds_barrier(); // tmp may still be read from a previous call
+  if (lane == 63) tmp[wave] = inc;
+  lds_barrier();
+  if (wave == 0) {
+    const uint32_t wv = lane < nw ? tmp[lane] : 0;
+    uint32_t winc = wv;
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {
+      const uint32_t t = __shfl_up(winc, off);
+      if (lane >= (uint32_t)off) winc += t;
+    }
+    if (lane < nw) tmp[lane] = winc - wv;
+  }
+  lds_barrier();
+  return tmp[wave] + inc - x;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // few groups: row slices of the input columns
 // ---------------------------------------------------------------------------------------------------------
@@ -598,12 +629,13 @@ template <typename T>
 DEVINL void stage_and_store(uint8_t *stage, const T (&x)[TS_R], const uint32_t (&pos)[TS_R], uint32_t live, uint8_t *dst, uint32_t nt) {
 #pragma unroll
   for (int r = 0; r < TS_R; r++) if ((live >> r) & 1) ((T *)stage)[pos[r]] = x[r];
-  __syncthreads();
+  lds_barrier();
   const uint32_t nchunk = (nt * (uint32_t)sizeof(T) + 15u) >> 4; // the destination is padded to 16 bytes
   for (uint32_t c = threadIdx.x; c < nchunk; c += TS_BLOCK) ((uint4 *)dst)[c] = ((const uint4 *)stage)[c];
-  __syncthreads();
+  lds_barrier();
 }
 
+#define TS_NPRE 2 // value columns requested together with the keys
 template <typename KS>
 __global__ void __launch_bounds__(TS_BLOCK) k_tile_sort(Plan P, PartOut O, uint32_t pbits, uint32_t n_tiles, uint32_t *__restrict__ offs,
                                                         int keymode, uint64_t kxor) {
@@ -612,7 +644,7 @@ __global__ void __launch_bounds__(TS_BLOCK) k_tile_sort(Plan P, PartOut O, uint3
   const uint32_t np = 1u << pbits, nh = np + 1; // partition np holds the rows with a null key
   const uint32_t tid = threadIdx.x, tile = blockIdx.x;
   for (uint32_t p = tid; p < nh; p += TS_BLOCK) hist[p] = 0;
-  __syncthreads();
+  lds_barrier();
   const int64_t r0 = (int64_t)tile * TS_TILE;
   const uint32_t nt = (uint32_t)((P.n_rows - r0) < TS_TILE ? (P.n_rows - r0) : TS_TILE);
   uint32_t row[TS_R], pos[TS_R];
@@ -638,29 +670,57 @@ __global__ void __launch_bounds__(TS_BLOCK) k_tile_sort(Plan P, PartOut O, uint3
 #pragma unroll
     for (int r = 0; r < TS_R; r++) key[r] = (KS)(raw[r] ^ kxor);
   }
+  // the first value columns are requested now and land under the histogram / scan / key phases
+  uint64_t pre[TS_NPRE][TS_R];
+#pragma unroll
+  for (int c = 0; c < TS_NPRE; c++)
+    if (c < P.n_vals) load_raw<TS_R, false>(P.vals[c].values, wbytes(P.vals[c].dtype), row, pre[c]);
 #pragma unroll
   for (int r = 0; r < TS_R; r++) {
     pos[r] = 0;
     if (!((live >> r) & 1)) continue;
-    const uint32_t p = ((nullm >> r) & 1) ? np : part_of(mix_a((uint64_t)key[r]), pbits);
+    const uint32_t p = ((nullm >> r) & 1) ? np : part_of(mix_key(key[r]), pbits);
     pos[r] = p | (atomicAdd(&hist[p], 1u) << 12);
   }
-  __syncthreads();
+  lds_barrier();
   const uint32_t mine = tid < nh ? hist[tid] : 0;
-  const uint32_t excl = block_scan_excl(mine, tmp);
+  const uint32_t excl = block_scan_excl_lds(mine, tmp);
   if (tid < nh) {
     hist[tid] = excl;
     offs[(uint64_t)tid * n_tiles + tile] = excl;
   }
   if (tid == 0) offs[(uint64_t)(np + 1) * n_tiles + tile] = nt;
-  __syncthreads();
+  lds_barrier();
 #pragma unroll
   for (int r = 0; r < TS_R; r++) if ((live >> r) & 1) pos[r] = hist[pos[r] & 0xFFFu] + (pos[r] >> 12);
 
   stage_and_store<KS>(fsm, key, pos, live, O.keys + (size_t)r0 * sizeof(KS), nt);
   for (int v = 0; v < P.n_vals; v++) {
     const ValSpec V = P.vals[v];
-    switch (wbytes(V.dtype)) { // typed loads: a 4-byte column costs TS_R registers, not 2 * TS_R
+    if (v < TS_NPRE) {
+      uint64_t raw[TS_R];
+#pragma unroll
+      for (int c = 0; c < TS_NPRE; c++)
+        if (v == c) {
+#pragma unroll
+          for (int r = 0; r < TS_R; r++) raw[r] = pre[c][r];
+        }
+      switch (wbytes(V.dtype)) {
+#define SORT_PRE(T)                                                                                     \
+  {                                                                                                     \
+    T x[TS_R];                                                                                          \
+    _Pragma("unroll") for (int r = 0; r < TS_R; r++) x[r] = (T)raw[r];                                  \
+    stage_and_store<T>(fsm, x, pos, live, O.vals[v] + (size_t)r0 * sizeof(T), nt);                      \
+  }                                                                                                     \
+  break;
+        case 1: SORT_PRE(uint8_t)
+        case 2: SORT_PRE(uint16_t)
+        case 4: SORT_PRE(uint32_t)
+        default: SORT_PRE(uint64_t)
+#undef SORT_PRE
+      }
+    } else {
+      switch (wbytes(V.dtype)) {
 #define SORT_COL(T)                                                                                     \
   {                                                                                                     \
     T x[TS_R];                                                                                          \
@@ -668,11 +728,12 @@ __global__ void __launch_bounds__(TS_BLOCK) k_tile_sort(Plan P, PartOut O, uint3
     stage_and_store<T>(fsm, x, pos, live, O.vals[v] + (size_t)r0 * sizeof(T), nt);                      \
   }                                                                                                     \
   break;
-      case 1: SORT_COL(uint8_t)
-      case 2: SORT_COL(uint16_t)
-      case 4: SORT_COL(uint32_t)
-      default: SORT_COL(uint64_t)
+        case 1: SORT_COL(uint8_t)
+        case 2: SORT_COL(uint16_t)
+        case 4: SORT_COL(uint32_t)
+        default: SORT_COL(uint64_t)
 #undef SORT_COL
+      }
     }
     if (O.valid[v]) {
       uint8_t x[TS_R];
@@ -882,51 +943,30 @@ __global__ void __launch_bounds__(1024) k_merge_emit(Plan P, MergeArgs A, const 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// sampled cardinality (the analogue of estimate_unique_count, group_by_partitioned.rs:115-157): workgroup j
-// of EST_WGS walks the same strided sample and keeps the keys whose hash falls into its share in an LDS set
-// of 32-bit fingerprints; the distinct counts add up to the sample's exact distinct count.
+// sampled cardinality (the analogue of estimate_unique_count, group_by_partitioned.rs:115-157): one key per
+// thread from 256-row blocks spread evenly over the column; 32-bit fingerprints go into a scratch set in HBM
+// (one CAS per key: ~1e5 global atomics, a few microseconds) and the new ones are counted.
 // ---------------------------------------------------------------------------------------------------------
-#define EST_BITS 15
-#define EST_U 8
-__global__ void __launch_bounds__(1024) k_estimate(Plan P, int64_t n_sample, int64_t stride, uint32_t *flags) {
-  __shared__ uint32_t set[1 << EST_BITS];
-  __shared__ uint32_t cnt;
-  for (uint32_t i = threadIdx.x; i < (1u << EST_BITS); i += blockDim.x) set[i] = 0xFFFFFFFFu;
-  if (threadIdx.x == 0) cnt = 0;
-  __syncthreads();
-  uint32_t mine = 0;
-  for (int64_t i0 = 0; i0 < n_sample; i0 += (int64_t)blockDim.x * EST_U) {
-    uint64_t h[EST_U];
-    bool lv[EST_U];
-#pragma unroll
-    for (int u = 0; u < EST_U; u++) { // the loads of one batch are independent: they are in flight together
-      const int64_t i = i0 + (int64_t)u * blockDim.x + threadIdx.x;
-      lv[u] = i < n_sample;
-      bool isn;
-      const uint64_t key = row_packed_key(P, (lv[u] ? i : 0) * stride, isn);
-      h[u] = isn ? 0x9E3779B97F4A7C15ull : hash_key(key);
-    }
-#pragma unroll
-    for (int u = 0; u < EST_U; u++) {
-      if (!lv[u] || (uint32_t)(h[u] >> 20) % gridDim.x != blockIdx.x) continue;
-      uint32_t f = (uint32_t)(h[u] >> 32);
-      if (f == 0xFFFFFFFFu) f = 0x7FFFFFFFu;
-      uint32_t s = f & ((1u << EST_BITS) - 1);
-      for (int it = 0; it < (1 << EST_BITS); it++) {
-        uint32_t k = set[s];
-        if (k == f) break;
-        if (k == 0xFFFFFFFFu) {
-          k = atomicCAS(&set[s], 0xFFFFFFFFu, f);
-          if (k == 0xFFFFFFFFu) { mine++; break; }
-          if (k == f) break;
-        }
-        s = (s + 1) & ((1u << EST_BITS) - 1);
-      }
+__global__ void __launch_bounds__(256) k_estimate(Plan P, int64_t n_sample, int64_t stride, uint32_t *set, uint32_t set_bits, uint32_t *flags) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  bool fresh = false;
+  if (i < n_sample) {
+    bool isn;
+    const uint64_t key = row_packed_key(P, (i >> 8) * stride + (i & 255), isn);
+    const uint64_t h = isn ? 0x9E3779B97F4A7C15ull : hash_key(key);
+    uint32_t f = (uint32_t)(h >> 32);
+    if (f == 0xFFFFFFFFu) f = 0x7FFFFFFFu;
+    const uint32_t mask = (1u << set_bits) - 1;
+    uint32_t s = (uint32_t)h & mask;
+    for (uint32_t it = 0; it <= mask; it++) {
+      const uint32_t k = atomicCAS(&set[s], 0xFFFFFFFFu, f);
+      if (k == 0xFFFFFFFFu) { fresh = true; break; }
+      if (k == f) break;
+      s = (s + 1) & mask;
     }
   }
-  if (mine) atomicAdd(&cnt, mine);
-  __syncthreads();
-  if (threadIdx.x == 0 && cnt) atomicAdd(&flags[FLAG_NGROUPS], cnt);
+  const unsigned long long m = __ballot(fresh);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&flags[FLAG_NGROUPS], (uint32_t)__popcll(m));
 }
 
 // ---- pre-instantiated shapes (accumulators in lowered order: sorted by source column, counters first) ------
@@ -1059,6 +1099,6 @@ void launch_merge_emit(const Plan &p, const MergeArgs &a, const OutPlan *o_dev, 
   else hipLaunchKernelGGL(k_merge_emit<uint64_t>, dim3(grid), dim3(block), bytes, s, p, a, o_dev);
 }
 
-void launch_estimate(const Plan &p, int64_t n_sample, int64_t stride, uint32_t n_wgs, uint32_t *flags, hipStream_t s) {
-  hipLaunchKernelGGL(k_estimate, dim3(n_wgs), dim3(1024), 0, s, p, n_sample, stride, flags);
+void launch_estimate(const Plan &p, int64_t n_sample, int64_t stride, uint32_t *set, uint32_t set_bits, uint32_t *flags, hipStream_t s) {
+  hipLaunchKernelGGL(k_estimate, dim3((unsigned)((n_sample + 255) / 256)), dim3(256), 0, s, p, n_sample, stride, set, set_bits, flags);
 }
