@@ -838,9 +838,7 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
     o.validity = col.validity;
     OP.outs[i] = o;
   }
-  hipError_t e = c.plans.reserve(sizeof(OutPlan));
-  if (e == hipSuccess) e = hipMemcpyAsync(c.plans.p, &OP, sizeof(OutPlan), hipMemcpyHostToDevice, c.stream);
-  if (e != hipSuccess) { delete R; return fail_hip(e, "output plan"); }
+  hipError_t e = hipSuccess;
 
   // ---- launches --------------------------------------------------------------------------------------------
   hipEventRecord(c.ev[1], c.stream);
@@ -867,7 +865,7 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
     A.pkeys = O.keys; A.out_cap = out_cap;
     A.D = D; A.flags = dflags; A.offs = (const uint32_t *)c.offs.p; A.lbits = lbits; A.np = np; A.w = w; A.n_pg = n_pg;
     A.has_null_pg = has_null_pg; A.S = S; A.n_tiles = n_tiles; A.pbits = pbits;
-    launch_fold_runs(P2, A, (const OutPlan *)c.plans.p, key_bytes, block, c.stream);
+    launch_fold_runs(P2, A, OP, key_bytes, block, c.stream);
     if ((e = hipGetLastError()) != hipSuccess) { delete R; return fail_hip(e, "k_fold_runs launch"); }
     c.strategy = "tilesort";
   }
@@ -875,7 +873,7 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
   MergeArgs M{};
   M.D = D; M.flags = dflags; M.out_cap = out_cap; M.lbits = lbits; M.S = S; M.mbits = mbits; M.pshift = direct ? 0u : pbits;
   if (direct || S > 1) {
-    launch_merge_emit(P, M, (const OutPlan *)c.plans.p, key_bytes, direct ? 1u : n_pg, 1024, c.stream);
+    launch_merge_emit(P, M, OP, key_bytes, direct ? 1u : n_pg, 1024, c.stream);
     if ((e = hipGetLastError()) != hipSuccess) { delete R; return fail_hip(e, "k_merge_emit launch"); }
   }
   hipEventRecord(c.ev[2], c.stream);

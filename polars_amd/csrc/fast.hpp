@@ -82,8 +82,8 @@ uint64_t fast_dump_stride(const Plan &p, uint32_t cap, int key_bytes);
 void launch_fold_rows(const Plan &p, const FoldRowsArgs &a, int key_bytes, bool quad, uint32_t n_items, uint32_t block, hipStream_t s);
 void launch_tile_sort(const Plan &p, const PartOut &o, uint32_t pbits, uint32_t n_tiles, uint32_t *offs, int keymode, uint64_t kxor,
                       int key_bytes, hipStream_t s);
-void launch_fold_runs(const Plan &p2, const FoldRunsArgs &a, const OutPlan *o_dev, int key_bytes, uint32_t block, hipStream_t s);
-void launch_merge_emit(const Plan &p, const MergeArgs &a, const OutPlan *o_dev, int key_bytes, uint32_t n_pg, uint32_t block, hipStream_t s);
+void launch_fold_runs(const Plan &p2, const FoldRunsArgs &a, const OutPlan &o, int key_bytes, uint32_t block, hipStream_t s);
+void launch_merge_emit(const Plan &p, const MergeArgs &a, const OutPlan &o, int key_bytes, uint32_t n_pg, uint32_t block, hipStream_t s);
 // distinct keys among `n_sample` rows taken every `stride` rows -> flags[FLAG_NGROUPS]
 // `set`: scratch of 1 << set_bits u32 filled with 0xFF bytes (at least 4x the sample)
 void launch_estimate(const Plan &p, int64_t n_sample, int64_t stride, uint32_t *set, uint32_t set_bits, uint32_t *flags, hipStream_t s);

@@ -472,7 +472,7 @@ DEVINL uint32_t table_lds_bytes(const Plan &P, uint32_t lslots, uint32_t key_byt
 // into a zeroed bitmap.
 template <typename KS>
 DEVINL void emit_table(const Plan &P, uint8_t *sm, uint32_t lbits, uint32_t *used, uint32_t *bk, uint16_t *list,
-                       const OutPlan *__restrict__ Op, uint32_t *flags, uint64_t out_cap) {
+                       const OutPlan &O, uint32_t *flags, uint64_t out_cap) {
   __shared__ uint32_t e_loff[PLHIP_MAX_ACCS];
   __shared__ uint32_t e_base;
   const uint32_t lcap = 1u << lbits, lslots = lcap + FP_EXTRA_SLOTS;
@@ -494,7 +494,6 @@ DEVINL void emit_table(const Plan &P, uint8_t *sm, uint32_t lbits, uint32_t *use
     if (threadIdx.x == 0) flags[FLAG_OVERFLOW] = 1;
     return;
   }
-  const OutPlan &O = *Op;
   for (uint32_t k0 = 0; k0 < n; k0 += blockDim.x) { // a wave covers 64 consecutive output rows
     const uint32_t k = k0 + threadIdx.x;
     const bool livek = k < n;
@@ -751,7 +750,7 @@ __global__ void __launch_bounds__(TS_BLOCK) k_tile_sort(Plan P, PartOut O, uint3
 // ---------------------------------------------------------------------------------------------------------
 #define RUNS_NPRE 3
 template <typename KS, typename SH>
-__global__ void __launch_bounds__(1024) k_fold_runs(Plan P, FoldRunsArgs A, const OutPlan *__restrict__ Op) {
+__global__ void __launch_bounds__(1024) k_fold_runs(Plan P, FoldRunsArgs A, OutPlan O) { // ~3.7 KB of kernel arguments: no plan upload per query
   __shared__ __align__(16) uint32_t sh[8];
   __shared__ __align__(16) uint32_t bk[136];
   const uint32_t lslots = lslots_of(A.lbits);
@@ -813,7 +812,7 @@ __global__ void __launch_bounds__(1024) k_fold_runs(Plan P, FoldRunsArgs A, cons
   __syncthreads();
   if (sh[2] && threadIdx.x == 0) A.flags[FLAG_OVERFLOW] = 1;
   uint16_t *list = (uint16_t *)(fsm + table_lds_bytes(P, lslots, sizeof(KS)));
-  if (A.S == 1) emit_table<KS>(P, fsm, A.lbits, sh, bk, list, Op, A.flags, A.out_cap);
+  if (A.S == 1) emit_table<KS>(P, fsm, A.lbits, sh, bk, list, O, A.flags, A.out_cap);
   else dump_table<KS>(P, fsm, A.lbits, 0, sh, bk, list, A.D, item);
 }
 
@@ -823,7 +822,7 @@ __global__ void __launch_bounds__(1024) k_fold_runs(Plan P, FoldRunsArgs A, cons
 #define MG_MAX_S 2048
 #define MG_U 4
 template <typename KS>
-__global__ void __launch_bounds__(1024) k_merge_emit(Plan P, MergeArgs A, const OutPlan *__restrict__ Op) {
+__global__ void __launch_bounds__(1024) k_merge_emit(Plan P, MergeArgs A, OutPlan O) {
   __shared__ __align__(16) uint32_t sh[8];
   __shared__ __align__(16) uint32_t bk[136];
   __shared__ __align__(16) uint32_t tmp[16];
@@ -939,7 +938,7 @@ __global__ void __launch_bounds__(1024) k_merge_emit(Plan P, MergeArgs A, const 
   __syncthreads();
   if (sh[2] && threadIdx.x == 0) A.flags[FLAG_OVERFLOW] = 1;
   uint16_t *list = (uint16_t *)(fsm + table_lds_bytes(P, lslots, sizeof(KS)));
-  emit_table<KS>(P, fsm, A.lbits, sh, bk, list, Op, A.flags, A.out_cap);
+  emit_table<KS>(P, fsm, A.lbits, sh, bk, list, O, A.flags, A.out_cap);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1068,35 +1067,35 @@ void launch_tile_sort(const Plan &p, const PartOut &o, uint32_t pbits, uint32_t 
 }
 
 template <typename KS, typename SH>
-void launch_fold_runs_t(const Plan &p2, const FoldRunsArgs &a, const OutPlan *o_dev, size_t bytes, uint32_t block, hipStream_t s) {
+void launch_fold_runs_t(const Plan &p2, const FoldRunsArgs &a, const OutPlan &o, size_t bytes, uint32_t block, hipStream_t s) {
   static bool once = false;
   if (!once) { allow_big_lds(k_fold_runs<KS, SH>); once = true; }
-  hipLaunchKernelGGL((k_fold_runs<KS, SH>), dim3(a.n_pg * a.S), dim3(block), bytes, s, p2, a, o_dev);
+  hipLaunchKernelGGL((k_fold_runs<KS, SH>), dim3(a.n_pg * a.S), dim3(block), bytes, s, p2, a, o);
 }
 
-void launch_fold_runs(const Plan &p2, const FoldRunsArgs &a, const OutPlan *o_dev, int key_bytes, uint32_t block, hipStream_t s) {
+void launch_fold_runs(const Plan &p2, const FoldRunsArgs &a, const OutPlan &o, int key_bytes, uint32_t block, hipStream_t s) {
   const size_t bytes = fast_table_bytes(p2, a.lbits, key_bytes);
   switch (find_shape(p2)) {
 #define X(i, SH)                                                                              \
   case i:                                                                                     \
-    if (key_bytes == 4) launch_fold_runs_t<uint32_t, SH>(p2, a, o_dev, bytes, block, s);      \
-    else launch_fold_runs_t<uint64_t, SH>(p2, a, o_dev, bytes, block, s);                     \
+    if (key_bytes == 4) launch_fold_runs_t<uint32_t, SH>(p2, a, o, bytes, block, s);      \
+    else launch_fold_runs_t<uint64_t, SH>(p2, a, o, bytes, block, s);                     \
     return;
     FP_SHAPES(X)
 #undef X
     default: break;
   }
-  if (key_bytes == 4) launch_fold_runs_t<uint32_t, RtShape>(p2, a, o_dev, bytes, block, s);
-  else launch_fold_runs_t<uint64_t, RtShape>(p2, a, o_dev, bytes, block, s);
+  if (key_bytes == 4) launch_fold_runs_t<uint32_t, RtShape>(p2, a, o, bytes, block, s);
+  else launch_fold_runs_t<uint64_t, RtShape>(p2, a, o, bytes, block, s);
 }
 
-void launch_merge_emit(const Plan &p, const MergeArgs &a, const OutPlan *o_dev, int key_bytes, uint32_t n_pg, uint32_t block, hipStream_t s) {
+void launch_merge_emit(const Plan &p, const MergeArgs &a, const OutPlan &o, int key_bytes, uint32_t n_pg, uint32_t block, hipStream_t s) {
   static bool once = false;
   if (!once) { allow_big_lds(k_merge_emit<uint32_t>); allow_big_lds(k_merge_emit<uint64_t>); once = true; }
   const size_t bytes = fast_table_bytes(p, a.lbits, key_bytes);
   const uint32_t grid = n_pg << a.mbits;
-  if (key_bytes == 4) hipLaunchKernelGGL(k_merge_emit<uint32_t>, dim3(grid), dim3(block), bytes, s, p, a, o_dev);
-  else hipLaunchKernelGGL(k_merge_emit<uint64_t>, dim3(grid), dim3(block), bytes, s, p, a, o_dev);
+  if (key_bytes == 4) hipLaunchKernelGGL(k_merge_emit<uint32_t>, dim3(grid), dim3(block), bytes, s, p, a, o);
+  else hipLaunchKernelGGL(k_merge_emit<uint64_t>, dim3(grid), dim3(block), bytes, s, p, a, o);
 }
 
 void launch_estimate(const Plan &p, int64_t n_sample, int64_t stride, uint32_t *set, uint32_t set_bits, uint32_t *flags, hipStream_t s) {

@@ -124,6 +124,8 @@ struct OutPlan {
   int32_t pad;
   OutSpec outs[PLHIP_MAX_OUTS];
 };
+// the fast path passes Plan + OutPlan + its own arguments by value: the kernel-argument segment is 4 KB
+static_assert(sizeof(Plan) + sizeof(OutPlan) <= 3800, "Plan + OutPlan must fit the kernel-argument segment");
 
 // Wide key tuples (more than 64 bits after range compression) are reduced to dense ids first; their
 // output key columns are then gathered from the ORIGINAL columns at each group's first row, exactly as
