@@ -5,7 +5,8 @@ this package is the thin host-side mirror of the reference API.  There is no CPU
 """
 from ._ffi import ComputeError, PlHipError, ShapeMismatch  # noqa: F401
 from .column import Column, column_from_list  # noqa: F401
-from .frame import (DataFrame, Expr, GroupBy, LazyFrame, col, count, group_by_agg_raw,  # noqa: F401
+from .frame import (DataFrame, Expr, GroupBy, Groups, LazyFrame, agg_groups, col, count, group_by_agg_raw,  # noqa: F401
+                    group_tuples,
                     last_kernel_breakdown, last_kernel_ms, last_strategy, set_strategy)
 from .frame import max_ as max, mean_ as mean, min_ as min, sum_ as sum  # noqa: F401,A001
 

@@ -1201,11 +1201,161 @@ int32_t plhip_groups_buffers(const plhip_groups_t *g, const uint32_t **first, co
 }
 void plhip_groups_free(plhip_groups_t *g) { delete g; }
 
-int32_t plhip_group_tuples(const plhip_column_t *, int32_t, int32_t, int32_t, plhip_groups_t **) {
-  return fail(PLHIP_ERR_COMPUTE, "plhip_group_tuples: not built yet");
+// IntoGroupsProxy::group_tuples / group_by_threaded_multiple_keys_flat -> GroupsProxy::Idx as CSR.
+// Dense group ids come from the HBM key table (one find-or-insert per row), the index lists from a stable
+// radix sort of (group id, row): rows of a group stay in ascending order, as the reference builds them.
+int32_t plhip_group_tuples(const plhip_column_t *keys, int32_t n_keys, int32_t sorted, int32_t out_location,
+                           plhip_groups_t **out) {
+  if (!out) return fail(PLHIP_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  if (n_keys < 1 || !keys) return fail(PLHIP_ERR_COMPUTE, "at least one key is required in a group_by operation");
+  if (n_keys > PLHIP_MAX_KEYS) return fail(PLHIP_ERR_INVALID, "too many key columns (max 16)");
+  if (out_location != PLHIP_HOST && out_location != PLHIP_DEVICE) return fail(PLHIP_ERR_INVALID, "bad out_location");
+  const int64_t n = keys[0].length;
+  for (int i = 0; i < n_keys; i++)
+    if (keys[i].length != n) return fail(PLHIP_ERR_SHAPE_MISMATCH, "series used as keys should have the same length as the dataframe");
+  if (n > 0xFFFFFFFFll) return fail(PLHIP_ERR_COMPUTE, "more than u32::MAX rows (IdxSize is u32)");
+  int rc = ensure_ctx();
+  if (rc) return rc;
+  Ctx &c = g_ctx;
+  plhip_groups *Gp = new (std::nothrow) plhip_groups();
+  if (!Gp) return fail(PLHIP_ERR_OOM, "host allocation failed");
+  Gp->n_rows = n;
+  Gp->on_device = true;
+  uint64_t G = 0;
+  auto dev_alloc = [&](uint32_t **p, size_t count) { return hipMalloc((void **)p, (count ? count : 1) * 4); };
+  if (n > 0) {
+    Staging st;
+    std::vector<DevCol> dk(n_keys);
+    for (int i = 0; i < n_keys; i++) if ((rc = stage_column(keys[i], dk[i], st, c.stream))) { delete Gp; return rc; }
+    Lowered L{};
+    L.P.n_rows = n;
+    if ((rc = build_keys(L.P, dk, st, L.KG))) { delete Gp; return rc; }
+    Plan &P = L.P;
+    const int first_acc = add_acc(P, ACC_FIRST_ROW, CONV_NONE, -1, 4, 0xFFFFFFFFull);
+    const uint64_t cap = next_pow2(std::max<uint64_t>(2 * (uint64_t)n, 1024));
+    const uint64_t n_slots = cap + 2;
+    plan_layout(P, n_slots);
+    hipError_t e = c.table.reserve(table_bytes(P, n_slots));
+    if (e == hipSuccess) e = c.flags.reserve(64);
+    if (e == hipSuccess) e = c.slots.reserve(n_slots * 8);
+    if (e == hipSuccess) e = c.rank.reserve(n_slots * 4);
+    if (e != hipSuccess) { delete Gp; return fail_hip(e, "group_tuples scratch"); }
+    TableRef T{(uint8_t *)c.table.p, cap, (uint32_t *)c.flags.p};
+    uint64_t *slots = (uint64_t *)c.slots.p;
+    launch_table_init(P, T, c.stream);
+    launch_agg_global(P, T, c.stream);
+    launch_compact(P, T, slots, c.stream);
+    uint32_t fl[16];
+    if ((rc = read_flags(T, fl))) { delete Gp; return rc; }
+    if (fl[FLAG_OVERFLOW]) { delete Gp; return fail(PLHIP_ERR_COMPUTE, "hash table overflow at load factor <= 0.5"); }
+    G = fl[FLAG_NGROUPS];
+    if (sorted && G > 1) { // groups ordered by their first row (hashing.rs:32-79)
+      if ((e = c.sortkeys.reserve(G * 8)) != hipSuccess) { delete Gp; return fail_hip(e, "group_tuples scratch"); }
+      launch_gather_sort_keys(P, T, slots, G, first_acc, (uint64_t *)c.sortkeys.p, c.stream);
+      if ((e = sort_pairs_u64((uint64_t *)c.sortkeys.p, slots, G, 32, c.stream)) != hipSuccess) { delete Gp; return fail_hip(e, "sort"); }
+    }
+    uint32_t *ids = nullptr;
+    e = dev_alloc(&ids, (size_t)n);
+    if (e == hipSuccess) e = dev_alloc(&Gp->indices, (size_t)n);
+    if (e == hipSuccess) e = dev_alloc(&Gp->offsets, (size_t)G + 1);
+    if (e == hipSuccess) e = dev_alloc(&Gp->first, (size_t)G);
+    if (e == hipSuccess) {
+      launch_rank_scatter(slots, G, (uint32_t *)c.rank.p, c.stream);
+      launch_encode_rows(P, T, (const uint32_t *)c.rank.p, ids, c.stream);
+      launch_iota_u32(Gp->indices, (uint64_t)n, c.stream);
+      e = sort_pairs_u32(ids, Gp->indices, (uint64_t)n, std::max(1, bit_length(G ? G - 1 : 0)), c.stream);
+    }
+    if (e == hipSuccess) {
+      launch_csr(ids, Gp->indices, (uint64_t)n, G, Gp->offsets, Gp->first, c.stream);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
+    if (ids) hipFree(ids);
+    if (e != hipSuccess) { delete Gp; return fail_hip(e, "group_tuples"); }
+  } else {
+    hipError_t e = dev_alloc(&Gp->indices, 0);
+    if (e == hipSuccess) e = dev_alloc(&Gp->offsets, 1);
+    if (e == hipSuccess) e = dev_alloc(&Gp->first, 0);
+    if (e == hipSuccess) e = hipMemset(Gp->offsets, 0, 4);
+    if (e != hipSuccess) { delete Gp; return fail_hip(e, "group_tuples"); }
+  }
+  Gp->n_groups = (int64_t)G;
+  if (out_location == PLHIP_HOST) {
+    plhip_groups *H = new (std::nothrow) plhip_groups();
+    if (!H) { delete Gp; return fail(PLHIP_ERR_OOM, "host allocation failed"); }
+    H->n_groups = Gp->n_groups; H->n_rows = n; H->on_device = false;
+    rc = copy_out(Gp->first, (size_t)G * 4, (void **)&H->first);
+    if (!rc) rc = copy_out(Gp->offsets, ((size_t)G + 1) * 4, (void **)&H->offsets);
+    if (!rc) rc = copy_out(Gp->indices, (size_t)n * 4, (void **)&H->indices);
+    delete Gp;
+    if (rc) { delete H; return rc; }
+    Gp = H;
+  }
+  *out = Gp;
+  return PLHIP_OK;
 }
-int32_t plhip_agg_groups(const plhip_column_t *, int32_t, const plhip_groups_t *, uint32_t, plhip_result_t **) {
-  return fail(PLHIP_ERR_COMPUTE, "plhip_agg_groups: not built yet");
+
+// Series::agg_sum / agg_mean / agg_min / agg_max and GroupsProxy::group_count over the CSR groups.
+int32_t plhip_agg_groups(const plhip_column_t *values, int32_t kind, const plhip_groups_t *groups, uint32_t flags,
+                         plhip_result_t **out) {
+  if (!out) return fail(PLHIP_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  if (!groups) return fail(PLHIP_ERR_INVALID, "groups handle is NULL");
+  if (kind < 0 || kind > PLHIP_AGG_COUNT) return fail(PLHIP_ERR_INVALID, "bad aggregation kind");
+  if (kind != PLHIP_AGG_COUNT && !values) return fail(PLHIP_ERR_INVALID, "values is NULL");
+  if (values && kind != PLHIP_AGG_COUNT && values->length != groups->n_rows)
+    return fail(PLHIP_ERR_SHAPE_MISMATCH, "the column and the groups differ in length");
+  int rc = ensure_ctx();
+  if (rc) return rc;
+  Ctx &c = g_ctx;
+  const uint64_t G = (uint64_t)groups->n_groups;
+  const int64_t n = groups->n_rows;
+  Staging st;
+  std::vector<DevCol> dv;
+  if (kind != PLHIP_AGG_COUNT) {
+    dv.resize(1);
+    if ((rc = stage_column(*values, dv[0], st, c.stream))) return rc;
+  }
+  Lowered L{};
+  L.P.n_rows = n;
+  L.n_out_keys = 0;
+  plhip_agg_t a{0, kind};
+  if ((rc = build_aggs(L, dv, &a, 1, 0))) return rc;
+  if (L.P.n_accs > 4 || L.outs.size() != 1) return fail(PLHIP_ERR_INVALID, "unexpected accumulator layout");
+  const uint32_t *offsets = groups->offsets, *indices = groups->indices;
+  if (!groups->on_device) { // host-side handle: the lists travel to HBM for the call
+    void *d_off = nullptr, *d_idx = nullptr;
+    HIP_TRY(hipMalloc(&d_off, (G + 1) * 4));
+    st.owned.push_back(d_off);
+    HIP_TRY(hipMalloc(&d_idx, (size_t)std::max<int64_t>(n, 1) * 4));
+    st.owned.push_back(d_idx);
+    HIP_TRY(hipMemcpyAsync(d_off, groups->offsets, (G + 1) * 4, hipMemcpyHostToDevice, c.stream));
+    if (n) HIP_TRY(hipMemcpyAsync(d_idx, groups->indices, (size_t)n * 4, hipMemcpyHostToDevice, c.stream));
+    offsets = (const uint32_t *)d_off; indices = (const uint32_t *)d_idx;
+  }
+  plhip_result *R = new (std::nothrow) plhip_result();
+  if (!R) return fail(PLHIP_ERR_OOM, "host allocation failed");
+  R->n_rows = (int64_t)G; R->on_device = true; R->device = c.device;
+  OutPlan OP{};
+  OP.n_outs = 1;
+  OutSpec o = L.outs[0];
+  ResultCol col;
+  col.dtype = (int)o.dtype;
+  hipError_t e = hipMalloc(&col.values, (size_t)std::max<uint64_t>(G, 1) * dtype_width((int)o.dtype));
+  if (e == hipSuccess && o.validity) {
+    e = hipMalloc((void **)&col.validity, (G / 64 + 1) * 8);
+    if (e == hipSuccess) e = hipMemsetAsync(col.validity, 0, (G / 64 + 1) * 8, c.stream);
+  }
+  R->cols.push_back(col);
+  if (e != hipSuccess) { delete R; return fail_hip(e, "hipMalloc(output)"); }
+  o.values = (uint8_t *)col.values; o.validity = col.validity;
+  OP.outs[0] = o;
+  launch_agg_groups(L.P, OP, offsets, indices, G, G > 0 && (uint64_t)n / G >= 64, c.stream);
+  e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
+  if (e != hipSuccess) { delete R; return fail_hip(e, "agg_groups"); }
+  return finish_result(R, G, flags & PLHIP_FLAG_OUTPUT_DEVICE, out);
 }
 
 } // extern "C"

@@ -304,3 +304,112 @@ void launch_vec_hash(const Plan &p, uint64_t null_hash, uint64_t *out, hipStream
   int grid = (int)(blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks));
   hipLaunchKernelGGL(k_vec_hash, dim3(grid), dim3(256), 0, s, p, null_hash, out);
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// two-step API: GroupsProxy::Idx as CSR, and Series::agg_* over it
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_iota_u32(uint32_t *out, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (uint32_t)i;
+}
+
+// ids_sorted[] ascending: offsets[g] = first position of id g (every id in [0, G) occurs), offsets[G] = n
+__global__ void __launch_bounds__(256) k_csr_offsets(const uint32_t *__restrict__ ids_sorted, uint64_t n, uint64_t G,
+                                                     uint32_t *__restrict__ offsets) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && (i == 0 || ids_sorted[i] != ids_sorted[i - 1])) offsets[ids_sorted[i]] = (uint32_t)i;
+  if (i == 0) offsets[G] = (uint32_t)n;
+}
+
+__global__ void __launch_bounds__(256) k_csr_first(const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ indices, uint64_t G,
+                                                   uint32_t *__restrict__ first) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < G) first[g] = indices[offsets[g]];
+}
+
+hipError_t sort_pairs_u32(uint32_t *keys, uint32_t *vals, uint64_t n, int end_bit, hipStream_t s) {
+  if (n < 2) return hipSuccess;
+  uint32_t *kout = nullptr, *vout = nullptr;
+  void *tmp = nullptr;
+  size_t tmp_bytes = 0;
+  hipError_t e = hipMalloc(&kout, n * 4);
+  if (e != hipSuccess) return e;
+  e = hipMalloc(&vout, n * 4);
+  if (e != hipSuccess) { hipFree(kout); return e; }
+  e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, kout, vals, vout, n, 0, end_bit, s);
+  if (e == hipSuccess) e = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8);
+  if (e == hipSuccess) e = rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, kout, vals, vout, n, 0, end_bit, s); // stable
+  if (e == hipSuccess) e = hipMemcpyAsync(keys, kout, n * 4, hipMemcpyDeviceToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(vals, vout, n * 4, hipMemcpyDeviceToDevice, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  hipFree(kout); hipFree(vout); hipFree(tmp);
+  return e;
+}
+
+void launch_iota_u32(uint32_t *out, uint64_t n, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(k_iota_u32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, n);
+}
+void launch_csr(const uint32_t *ids_sorted, const uint32_t *indices, uint64_t n, uint64_t G, uint32_t *offsets, uint32_t *first, hipStream_t s) {
+  hipLaunchKernelGGL(k_csr_offsets, dim3((unsigned)((n + 255) / 256 > 0 ? (n + 255) / 256 : 1)), dim3(256), 0, s, ids_sorted, n, G, offsets);
+  if (G) hipLaunchKernelGGL(k_csr_first, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, s, offsets, indices, G, first);
+}
+
+// One accumulator state folded sequentially (registers, no atomics): the same AccSpec semantics as the hash
+// tables, applied in the order the rows are visited.
+DEVINL void acc_fold_local(const AccSpec &a, uint64_t &state, uint64_t operand) {
+  switch (a.op) {
+    case ACC_ADD_U64: state += operand; break;
+    case ACC_ADD_F64: state = (uint64_t)__double_as_longlong(__longlong_as_double((long long)state) + __longlong_as_double((long long)operand)); break;
+    case ACC_MIN_I64: state = (long long)operand < (long long)state ? operand : state; break;
+    case ACC_MAX_I64: state = (long long)operand > (long long)state ? operand : state; break;
+    case ACC_MIN_U64: state = operand < state ? operand : state; break;
+    case ACC_MAX_U64: state = operand > state ? operand : state; break;
+    case ACC_CNT_ALL: case ACC_CNT_VALID: state += operand; break;
+    case ACC_FIRST_ROW: state = operand < state ? operand : state; break;
+  }
+}
+
+// Series::agg_{sum,mean,min,max} / group_count on GroupsProxy::Idx (aggregations/mod.rs:459-779,941-1016;
+// take_agg/mod.rs:17-109): WAVE = false: one thread walks a group's index list front to back, the
+// reference's left fold; WAVE = true (long groups): a wave walks it 64 rows at a time and combines the
+// lane partials in a fixed butterfly order.
+template <bool WAVE>
+__global__ void __launch_bounds__(256) k_agg_groups(Plan P, OutPlan O, const uint32_t *__restrict__ offsets,
+                                                    const uint32_t *__restrict__ indices, uint64_t G) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t g = WAVE ? t >> 6 : t;
+  const uint32_t lane = threadIdx.x & 63;
+  const bool live = g < G;
+  uint64_t st[4];
+  for (int a = 0; a < 4; a++) st[a] = a < P.n_accs ? P.accs[a].init : 0;
+  if (live) {
+    const uint32_t b = offsets[g], e = offsets[g + 1];
+    for (uint32_t i = b + (WAVE ? lane : 0); i < e; i += (WAVE ? 64 : 1)) {
+      const int64_t row = indices[i];
+      for (int a = 0; a < P.n_accs && a < 4; a++) {
+        uint64_t operand;
+        if (acc_operand(P, P.accs[a], row, operand)) acc_fold_local(P.accs[a], st[a], operand);
+      }
+    }
+  }
+  if (WAVE) {
+    for (int off = 32; off > 0; off >>= 1)
+      for (int a = 0; a < P.n_accs && a < 4; a++) {
+        const uint64_t other = ((uint64_t)(uint32_t)__shfl_xor((int)(st[a] >> 32), off) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)st[a], off);
+        acc_fold_local(P.accs[a], st[a], other);
+      }
+    if (lane != 0) return;
+  }
+  if (!live) return; // WAVE = false: a wave covers an aligned span of 64 groups below
+  const OutSpec &S = O.outs[0];
+  const uint32_t cnt_all = S.cnt_all >= 0 ? (uint32_t)st[S.cnt_all] : 0;
+  const uint32_t cnt_valid = S.cnt_valid >= 0 ? (uint32_t)st[S.cnt_valid] : cnt_all;
+  const bool valid = finalize_value(S, S.acc >= 0 ? st[S.acc] : 0, cnt_all, cnt_valid, g);
+  if (S.validity) atomicOr((unsigned int *)S.validity + (g >> 5), valid ? 1u << (g & 31) : 0u);
+}
+
+void launch_agg_groups(const Plan &p, const OutPlan &o, const uint32_t *offsets, const uint32_t *indices, uint64_t G, bool wave, hipStream_t s) {
+  if (!G) return;
+  if (wave) hipLaunchKernelGGL(k_agg_groups<true>, dim3((unsigned)((G * 64 + 255) / 256)), dim3(256), 0, s, p, o, offsets, indices, G);
+  else hipLaunchKernelGGL(k_agg_groups<false>, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, s, p, o, offsets, indices, G);
+}

@@ -65,3 +65,10 @@ void launch_sample_keys(const Plan &p, TableRef t, int64_t n_sample, int64_t str
 void launch_key_minmax(const Plan &p, uint64_t *minmax /* [n_keys][2], pre-set to {~0, 0} */, hipStream_t s);
 void launch_vec_hash(const Plan &p, uint64_t null_hash, uint64_t *out, hipStream_t s);
 hipError_t sort_pairs_u64(uint64_t *keys, uint64_t *vals, uint64_t n, int end_bit, hipStream_t s);
+
+// two-step API
+hipError_t sort_pairs_u32(uint32_t *keys, uint32_t *vals, uint64_t n, int end_bit, hipStream_t s); // stable
+void launch_iota_u32(uint32_t *out, uint64_t n, hipStream_t s);
+void launch_csr(const uint32_t *ids_sorted, const uint32_t *indices, uint64_t n, uint64_t G, uint32_t *offsets, uint32_t *first, hipStream_t s);
+// `o.outs[0]` is the one output column; at most 4 accumulators; o.outs[0].validity must be zeroed
+void launch_agg_groups(const Plan &p, const OutPlan &o, const uint32_t *offsets, const uint32_t *indices, uint64_t G, bool wave, hipStream_t s);

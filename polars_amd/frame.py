@@ -191,6 +191,10 @@ class GroupBy:
             exprs.extend(a if isinstance(a, (list, tuple)) else [a])
         return _execute(self.df, self.by, exprs, self.maintain_order)
 
+    def groups(self) -> "Groups":
+        """GroupBy::get_groups: the GroupsProxy of the key columns (group_by/mod.rs:182-189)."""
+        return group_tuples([self.df.get_column(n) for n in self.by], self.maintain_order)
+
     def _eager(self, kind: str) -> DataFrame:
         # GroupBy::sum()/mean()/... aggregate every non-key column (or the selection) and name the
         # outputs `{name}_{agg}` (fmt_group_by_column, group_by/mod.rs:889-909)
@@ -330,3 +334,66 @@ def _execute(df: DataFrame, by: list[str], exprs: list[Expr], maintain_order: bo
     finally:
         _ffi.lib().plhip_result_free(handle)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# two-step API: GroupsProxy + Series.agg_* (the seams a Rust host layer would rebind)
+# ---------------------------------------------------------------------------------------------------
+class Groups:
+    """GroupsProxy::Idx (crates/polars-core/src/frame/group_by/proxy.rs:16-20) as CSR: `first[G]`,
+    `offsets[G + 1]`, `indices[N]` (u32 = IdxSize).  Wraps a plhip_groups_t handle."""
+
+    def __init__(self, handle):
+        self._h = handle
+        L = _ffi.lib()
+        self.n_groups = L.plhip_groups_num_groups(handle)
+        self.n_rows = L.plhip_groups_num_rows(handle)
+
+    def buffers(self):
+        """(first, offsets, indices) as numpy arrays (host handles) or raw device pointers (device handles)."""
+        L = _ffi.lib()
+        f, o, i, loc = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int32()
+        _ffi.check(L.plhip_groups_buffers(self._h, C.byref(f), C.byref(o), C.byref(i), C.byref(loc)))
+        if loc.value == _ffi.DEVICE:
+            return f.value, o.value, i.value
+        as_np = lambda p, n: np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(max(n, 1),))[:n].copy()
+        return as_np(f, self.n_groups), as_np(o, self.n_groups + 1), as_np(i, self.n_rows)
+
+    def lists(self) -> list[list[int]]:
+        _, off, idx = self.buffers()
+        return [idx[off[g]:off[g + 1]].tolist() for g in range(self.n_groups)]
+
+    def close(self):
+        if self._h is not None:
+            _ffi.lib().plhip_groups_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def group_tuples(keys: Sequence[Column], sorted_: bool = False, location: int = _ffi.HOST) -> Groups:
+    """IntoGroupsProxy::group_tuples (into_groups.rs:12-19) / group_by_threaded_multiple_keys_flat
+    (hashing.rs:380-468) through plhip_group_tuples."""
+    karr = (_ffi.ColumnStruct * max(1, len(keys)))(*[k.struct() for k in keys])
+    h = C.c_void_p()
+    _ffi.check(_ffi.lib().plhip_group_tuples(karr, len(keys), int(sorted_), location, C.byref(h)))
+    return Groups(h)
+
+
+def agg_groups(values: Column | None, kind: str, groups: Groups) -> Column:
+    """Series::agg_sum/mean/min/max on GroupsProxy::Idx and GroupsProxy::group_count (kind='count')
+    through plhip_agg_groups.  Returns the one output column (host)."""
+    L = _ffi.lib()
+    h = C.c_void_p()
+    vs = C.byref(values.struct()) if values is not None else None
+    _ffi.check(L.plhip_agg_groups(vs, _ffi.AGG_NAMES[kind], groups._h, 0, C.byref(h)))
+    try:
+        cs = _ffi.ColumnStruct()
+        _ffi.check(L.plhip_result_column(h, 0, C.byref(cs)))
+        return _host_column(f"{values.name if values is not None else 'count'}_{kind}", cs)
+    finally:
+        L.plhip_result_free(h)

@@ -294,3 +294,86 @@ def test_vec_hash_parity(oracle):
 def test_error_kinds():
     with pytest.raises(pa.ComputeError):
         pa.DataFrame({"a": np.zeros(3, np.int32)}).group_by().agg(pa.count())
+
+
+# ---------------------------------------------------------------------------------------------------
+# two-step API: plhip_group_tuples (GroupsProxy::Idx as CSR) + plhip_agg_groups (Series::agg_*)
+# ---------------------------------------------------------------------------------------------------
+def _canon(lists):
+    return sorted(lists, key=lambda l: l[0])
+
+
+@pytest.mark.parametrize("sorted_", [False, True])
+@pytest.mark.parametrize("case", ["one_key", "nullable_key", "multi_key", "all_unique", "one_group"])
+def test_group_tuples(oracle, case, sorted_):
+    rng = np.random.default_rng(41)
+    n = 30000
+    if case == "one_key":
+        keys = [rand_col(rng, "k", np.int32, n, card=700)]
+    elif case == "nullable_key":
+        keys = [rand_col(rng, "k", np.float64, n, card=50, null_frac=0.1)]
+    elif case == "multi_key":
+        keys = [rand_col(rng, "a", np.uint32, n, lo=1, hi=30), rand_col(rng, "b", np.int64, n, lo=-5, hi=5, null_frac=0.05),
+                rand_col(rng, "c", np.int8, n, card=4)]
+    elif case == "all_unique":
+        keys = [Column("k", rng.permutation(n).astype(np.int64) * 7919)]
+    else:
+        keys = [Column("k", np.full(n, 7, dtype=np.uint16))]
+    want = oracle.Groups(keys, sorted_)
+    got = pa.group_tuples(keys, sorted_)
+    assert got.n_groups == want.n_groups and got.n_rows == n
+    first, off, idx = got.buffers()
+    lists = [idx[off[g]:off[g + 1]].tolist() for g in range(got.n_groups)]
+    for g, l in enumerate(lists):  # GroupsIdx invariants (proxy.rs:16-20)
+        assert l == sorted(l) and first[g] == l[0]
+    if sorted_:  # groups ordered by first row (hashing.rs:32-79): the order itself is part of the contract
+        assert lists == want.lists()
+    else:
+        assert _canon(lists) == _canon(want.lists())
+
+
+@pytest.mark.parametrize("vdt", [np.int16, np.int32, np.uint32, np.int64, np.float32, np.float64], ids=lambda d: np.dtype(d).name)
+@pytest.mark.parametrize("card", [40, 5000])
+def test_agg_groups(oracle, vdt, card):
+    # card 40: long groups -> the wave-per-group kernel; card 5000: the one-thread-per-group left fold
+    rng = np.random.default_rng(43)
+    n = 30000
+    keys = [rand_col(rng, "k", np.int32, n, card=card)]
+    dt = np.dtype(vdt)
+    if dt.kind == "f":
+        v = rand_col(rng, "v", vdt, n, null_frac=0.15, nan_frac=0.02)
+    else:
+        lo = None if dt.itemsize <= 2 else (0 if dt.kind == "u" else -(1 << 20))
+        v = rand_col(rng, "v", vdt, n, null_frac=0.15, lo=lo, hi=(1 << 20) if dt.itemsize > 2 else None)
+    want_g = oracle.Groups(keys, True)
+    got_g = pa.group_tuples(keys, True)
+    for kind in ALL_AGGS:
+        wv, wm = oracle.agg(None if kind == "count" else v, kind, want_g)
+        col = pa.agg_groups(None if kind == "count" else v, kind, got_g)
+        gv, gm = col.to_numpy(), col.valid_mask()
+        gm = np.ones(len(gv), bool) if gm is None else gm
+        assert np.array_equal(gm, wm), f"{kind}: validity"
+        rel = 1e-5 if dt == np.float32 else 1e-12
+        assert gv.dtype == wv.dtype, f"{kind}: dtype {gv.dtype} vs {wv.dtype}"
+        for i in np.nonzero(wm)[0]:
+            assert util.values_equal(gv[i].item(), wv[i].item(), rel), f"{kind} group {i}: {gv[i]!r} vs {wv[i]!r}"
+
+
+def test_agg_groups_left_fold_is_bit_exact(oracle):
+    # short groups take the sequential kernel: same fold order as the reference's Idx path -> identical f64 bits
+    rng = np.random.default_rng(47)
+    n = 20000
+    keys = [rand_col(rng, "k", np.int64, n, card=3000)]
+    v = rand_col(rng, "v", np.float64, n)
+    g_o, g_p = oracle.Groups(keys, True), pa.group_tuples(keys, True)
+    for kind in ("sum", "mean"):
+        wv, _ = oracle.agg(v, kind, g_o)
+        gv = pa.agg_groups(v, kind, g_p).to_numpy()
+        assert np.array_equal(gv.view(np.uint64), wv.view(np.uint64)), kind
+
+
+def test_group_tuples_empty_and_errors():
+    g = pa.group_tuples([Column("k", np.empty(0, np.int32))])
+    assert g.n_groups == 0 and g.n_rows == 0
+    with pytest.raises(pa.ShapeMismatch):
+        pa.group_tuples([Column("a", np.zeros(3, np.int32)), Column("b", np.zeros(4, np.int32))])
