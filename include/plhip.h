@@ -150,6 +150,11 @@ const char *plhip_last_strategy(void);
  * part of it spent in the dominant kernel.  Used by bench.py for `roofline.achieved`. */
 int32_t plhip_last_kernel_ms(float *total_ms, float *dominant_ms, const char **dominant_kernel);
 
+/* Blocking copy between buffers of result frames / groups handles and caller memory, on the library's own
+ * HIP runtime (what a host layer uses to move a device-resident result into its own buffers).  No
+ * counterpart in the reference: there results never leave host memory. */
+int32_t plhip_memcpy(void *dst, int32_t dst_location, const void *src, int32_t src_location, size_t bytes);
+
 /* Per-kernel device time of the last call when it ran the LDS-only pipeline (strategy "direct" /
  * "tilesort"): k_tile_sort (0 for "direct"), k_fold_rows / k_fold_runs, k_merge_emit. */
 int32_t plhip_last_kernel_breakdown(float *tile_sort_ms, float *fold_ms, float *merge_emit_ms);

@@ -141,6 +141,8 @@ def lib():
     L.plhip_last_strategy.restype = C.c_char_p
     L.plhip_last_kernel_ms.argtypes = [P(C.c_float), P(C.c_float), P(C.c_char_p)]
     L.plhip_last_kernel_ms.restype = i32
+    L.plhip_memcpy.argtypes = [vp, i32, vp, i32, C.c_size_t]
+    L.plhip_memcpy.restype = i32
     L.plhip_last_kernel_breakdown.argtypes = [P(C.c_float), P(C.c_float), P(C.c_float)]
     L.plhip_last_kernel_breakdown.restype = i32
     L.plhip_vec_hash.argtypes = [P(ColumnStruct), i32, u64, vp, i32]
@@ -184,7 +186,7 @@ def check(status: int) -> None:
 
 EXPORTED_SYMBOLS = [
     "plhip_abi_version", "plhip_init", "plhip_last_error", "plhip_set_strategy", "plhip_last_strategy",
-    "plhip_last_kernel_ms", "plhip_last_kernel_breakdown", "plhip_vec_hash", "plhip_group_by_agg", "plhip_group_by_agg_opts", "plhip_result_num_rows",
+    "plhip_last_kernel_ms", "plhip_memcpy", "plhip_last_kernel_breakdown", "plhip_vec_hash", "plhip_group_by_agg", "plhip_group_by_agg_opts", "plhip_result_num_rows",
     "plhip_result_num_columns", "plhip_result_column", "plhip_result_free", "plhip_group_tuples",
     "plhip_groups_num_groups", "plhip_groups_num_rows", "plhip_groups_buffers", "plhip_groups_free",
     "plhip_agg_groups",

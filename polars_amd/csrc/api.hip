@@ -939,6 +939,17 @@ int32_t plhip_last_kernel_ms(float *total_ms, float *dominant_ms, const char **d
   return PLHIP_OK;
 }
 
+int32_t plhip_memcpy(void *dst, int32_t dst_location, const void *src, int32_t src_location, size_t bytes) {
+  if (!bytes) return PLHIP_OK;
+  if (!dst || !src) return fail(PLHIP_ERR_INVALID, "NULL pointer");
+  int rc = ensure_ctx();
+  if (rc) return rc;
+  const hipMemcpyKind kind = dst_location == PLHIP_DEVICE ? (src_location == PLHIP_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice)
+                                                          : (src_location == PLHIP_DEVICE ? hipMemcpyDeviceToHost : hipMemcpyHostToHost);
+  HIP_TRY(hipMemcpy(dst, src, bytes, kind));
+  return PLHIP_OK;
+}
+
 int32_t plhip_last_kernel_breakdown(float *tile_sort_ms, float *fold_ms, float *merge_emit_ms) {
   if (tile_sort_ms) *tile_sort_ms = g_ctx.k_ms[0];
   if (fold_ms) *fold_ms = g_ctx.k_ms[1];

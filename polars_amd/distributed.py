@@ -1,0 +1,305 @@
+"""Row-sharded group-by over several GPUs: one process per GPU, one exchange step.
+
+The reference already does this across threads (PartitionGroupByExec::run_partitions,
+crates/polars-lazy/src/physical_plan/executors/group_by_partitioned.rs:66-113, 320-360): contiguous row
+split -> local group-by with mergeable partials (AggregationExpr::evaluate_partitioned,
+expressions/aggregation.rs:283-365: mean = (sum, valid count)) -> concat -> regroup -> finalize
+(aggregation.rs:367-483: sum of sums / counts, min of mins, mean = sum / count).  Here the "concat" is ONE
+all-to-all (RCCL over xGMI; torch.distributed backend "nccl") of partial records bucketed by
+owner(key) = high bits of the key hash % world, so every rank regroups a disjoint share of the keys and the
+final result is the concatenation of the ranks' frames.  A heavy key costs one record per rank, whatever its
+row count, so the exchange stays balanced under skew.
+
+torch is plumbing here (device buffers, sort / gather of the partial records, the collective); both
+group-by passes run in libplhip.so.  `engine` exists so that the CPU tests can drive the same protocol over
+gloo with a stand-in for the two passes.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _ffi
+from .column import Column
+
+NULL_HASH = 0x9E3779B97F4A7C15  # any constant: null keys only need to agree on an owner
+
+
+@dataclass
+class Col:
+    """One column of a (partial) frame: `t` holds the bits (u32/u64 data sit in int32/int64 tensors),
+    `code` the plhip dtype, `mask` a bool tensor (True = valid) or None."""
+    name: str
+    t: object
+    code: int
+    mask: object = None
+
+
+_TORCH_OF_CODE = None
+
+
+def _torch_dtype(code: int):
+    global _TORCH_OF_CODE
+    import torch
+
+    if _TORCH_OF_CODE is None:
+        _TORCH_OF_CODE = {_ffi.I8: torch.int8, _ffi.I16: torch.int16, _ffi.I32: torch.int32, _ffi.I64: torch.int64,
+                          _ffi.U8: torch.uint8, _ffi.U16: torch.int16, _ffi.U32: torch.int32, _ffi.U64: torch.int64,
+                          _ffi.F32: torch.float32, _ffi.F64: torch.float64}
+    return _TORCH_OF_CODE[code]
+
+
+def sum_out_code(code: int) -> int:
+    """Output dtype of SUM (series/implementations/mod.rs:167-174): narrow ints widen to i64."""
+    return _ffi.I64 if code in (_ffi.I8, _ffi.I16, _ffi.U8, _ffi.U16) else code
+
+
+def mean_out_code(code: int) -> int:
+    return _ffi.F32 if code == _ffi.F32 else _ffi.F64
+
+
+# ---------------------------------------------------------------------------------------------------
+# the two local passes on libplhip.so
+# ---------------------------------------------------------------------------------------------------
+class HipEngine:
+    """Local passes through the C ABI with device-resident inputs and outputs."""
+
+    def __init__(self, device):
+        self.device = device
+
+    def _frame(self, handle, cols, names) -> list[Col]:
+        """Copies a device-resident result frame into torch tensors (device-to-device) and frees it."""
+        import torch
+
+        L = _ffi.lib()
+        out = []
+        try:
+            for name, cs in zip(names, cols):
+                n = cs.length
+                dt = _torch_dtype(cs.dtype)
+                t = torch.empty(n, dtype=dt, device=self.device)
+                nbytes = n * t.element_size()
+                if nbytes:
+                    _hip_memcpy_dtod(t.data_ptr(), cs.values, nbytes)
+                mask = None
+                if cs.validity:
+                    nb = (n + 7) // 8
+                    bits = torch.empty(max(nb, 1), dtype=torch.uint8, device=self.device)
+                    if nb:
+                        _hip_memcpy_dtod(bits.data_ptr(), cs.validity, nb)
+                    mask = _unpack_bits(bits, n)
+                out.append(Col(name, t, cs.dtype, mask))
+        finally:
+            L.plhip_result_free(handle)
+        return out
+
+    def _columns(self, cols: list[Col]) -> list[Column]:
+        out = []
+        for c in cols:
+            v = None if c.mask is None else _pack_bits(c.mask)
+            out.append(Column(c.name, c.t, v, dtype=c.code, packed=True))
+        return out
+
+    def _sync_torch(self):
+        # libplhip.so runs on its own stream: what torch queued on its stream (gathers, the collective) must
+        # have landed before the library reads it
+        import torch
+
+        if torch.cuda.is_available():
+            torch.cuda.current_stream(self.device).synchronize()
+
+    def group_by(self, keys: list[Column], vals: list[Column], aggs, flags: int, names, hint: int = 0) -> list[Col]:
+        from .frame import group_by_agg_raw
+
+        self._sync_torch()
+        handle, cols = group_by_agg_raw(keys, vals, aggs, flags | _ffi.FLAG_OUTPUT_DEVICE, hint)
+        return self._frame(handle, cols, names)
+
+    def partial(self, keys, vals, aggs, hint: int = 0) -> list[Col]:
+        codes = [(ci, _ffi.AGG_NAMES[k]) for ci, k in aggs]
+        return self.group_by(keys, vals, codes, _ffi.FLAG_PARTIAL, partial_names(keys, aggs), hint)
+
+    def merge(self, keys: list[Col], parts: list[Col], ops: list[str]) -> list[Col]:
+        kc, pc = self._columns(keys), self._columns(parts)
+        aggs = [(i, _ffi.AGG_NAMES[op]) for i, op in enumerate(ops)]
+        names = [k.name for k in keys] + [p.name for p in parts]
+        return self.group_by(kc, pc, aggs, 0, names)
+
+    def key_hashes(self, keys: list[Col]):
+        import torch
+
+        n = keys[0].t.numel()
+        out = torch.empty(n, dtype=torch.int64, device=self.device)
+        if n:
+            kc = self._columns(keys)
+            self._sync_torch()
+            arr = (_ffi.ColumnStruct * len(kc))(*[k.struct() for k in kc])
+            _ffi.check(_ffi.lib().plhip_vec_hash(arr, len(kc), NULL_HASH, out.data_ptr(), _ffi.DEVICE))
+        return out
+
+
+def _hip_memcpy_dtod(dst: int, src: int, nbytes: int) -> None:
+    _ffi.check(_ffi.lib().plhip_memcpy(dst, _ffi.DEVICE, src, _ffi.DEVICE, nbytes))
+
+
+def _unpack_bits(bits, n: int):
+    import torch
+
+    sh = torch.arange(8, device=bits.device, dtype=torch.uint8)
+    return ((bits.unsqueeze(1) >> sh) & 1).reshape(-1)[:n].to(torch.bool)
+
+
+def _pack_bits(mask):
+    import torch
+
+    n = mask.numel()
+    pad = (-n) % 8
+    m = mask.to(torch.uint8)
+    if pad:
+        m = torch.cat([m, torch.zeros(pad, dtype=torch.uint8, device=m.device)])
+    w = (1 << torch.arange(8, device=m.device, dtype=torch.int32)).to(torch.uint8)
+    return (m.reshape(-1, 8) * w).sum(dim=1, dtype=torch.int32).to(torch.uint8).contiguous()
+
+
+def partial_names(keys, aggs) -> list[str]:
+    names = [k.name for k in keys]
+    for i, (ci, kind) in enumerate(aggs):
+        if kind == "mean":
+            names += [f"a{i}_sum", f"a{i}_cnt"]
+        else:
+            names.append(f"a{i}_{kind}")
+    return names
+
+
+# ---------------------------------------------------------------------------------------------------
+# the exchange
+# ---------------------------------------------------------------------------------------------------
+def _as_bytes(c: Col):
+    import torch
+
+    n = c.t.numel()
+    if n == 0:
+        return torch.empty((0, c.t.element_size()), dtype=torch.uint8, device=c.t.device)
+    return c.t.contiguous().view(torch.uint8).reshape(n, c.t.element_size())
+
+
+def exchange_by_owner(cols: list[Col], owner, world: int, group=None) -> list[Col]:
+    """Sends every row to rank owner[row]: the rows are sorted by owner, packed into one byte matrix
+    (all columns and masks side by side) and moved with ONE all_to_all_single after the counts."""
+    import torch
+    import torch.distributed as dist
+
+    dev = owner.device
+    n = owner.numel()
+    order = torch.argsort(owner, stable=True)
+    # counts and "this column carries a validity mask here" flags travel together: the record layout must be
+    # the same on every rank, and a rank whose shard happens to hold no nulls may have dropped a mask
+    hdr = torch.zeros((world, 1 + len(cols)), dtype=torch.int64, device=dev)
+    hdr[:, 0] = torch.bincount(owner, minlength=world)
+    for j, c in enumerate(cols):
+        if c.mask is not None:
+            hdr[:, 1 + j] = 1
+    got = torch.empty_like(hdr)
+    dist.all_to_all_single(got, hdr, group=group)
+    sc, got_h = hdr[:, 0].tolist(), got.tolist()  # the one host sync of the exchange
+    rc = [r[0] for r in got_h]
+    masked = [any(r[1 + j] for r in got_h) for j in range(len(cols))]
+    cols = [Col(c.name, c.t, c.code, c.mask if c.mask is not None or not masked[j] else torch.ones(n, dtype=torch.bool, device=dev))
+            for j, c in enumerate(cols)]
+    pieces, layout = [], []
+    for c in cols:
+        pieces.append(_as_bytes(c))
+        layout.append(c.t.element_size())
+        if c.mask is not None:
+            pieces.append(c.mask.to(torch.uint8).reshape(n, 1))
+            layout.append(-1)
+    rec = sum(abs(w) for w in layout)
+    # a rank may send or receive nothing: the buffers still get storage (a collective must not see a NULL pointer)
+    send = torch.cat(pieces, dim=1).index_select(0, order).contiguous() if n else torch.empty((1, rec), dtype=torch.uint8, device=dev)[:0]
+    recv = torch.empty((max(sum(rc), 1), rec), dtype=torch.uint8, device=dev)[:sum(rc)]
+    dist.all_to_all_single(recv, send, output_split_sizes=rc, input_split_sizes=sc, group=group)
+    out, off, it = [], 0, iter(layout)
+    m = recv.shape[0]
+    for c in cols:
+        w = next(it)
+        t = recv[:, off:off + w].contiguous().view(c.t.dtype).reshape(m) if m else torch.empty(0, dtype=c.t.dtype, device=dev)
+        off += w
+        mask = None
+        if c.mask is not None:
+            next(it)
+            mask = recv[:, off].contiguous().to(torch.bool)
+            off += 1
+        out.append(Col(c.name, t, c.code, mask))
+    return out
+
+
+def _merge_ops(aggs) -> list[str]:
+    ops = []
+    for _, kind in aggs:
+        ops += {"sum": ["sum"], "count": ["sum"], "min": ["min"], "max": ["max"], "mean": ["sum", "sum"]}[kind]
+    return ops
+
+
+def _to_f64(c: Col):
+    import torch
+
+    if c.code == _ffi.U64:  # torch has no unsigned 64-bit arithmetic
+        return (c.t >> 1).to(torch.float64) * 2.0 + (c.t & 1).to(torch.float64)
+    return c.t.to(torch.float64)
+
+
+def finalize(keys: list[Col], merged: list[Col], aggs, val_codes: list[int], names: list[str]) -> list[Col]:
+    """AggregationExpr::finalize (aggregation.rs:367-483) on the regrouped partials."""
+    import torch
+
+    out = list(keys)
+    it = iter(merged)
+    for (ci, kind), name in zip(aggs, names):
+        src = val_codes[ci] if kind != "count" else _ffi.U32
+        if kind == "sum":
+            c = next(it)
+            code = sum_out_code(src)
+            out.append(Col(name, c.t.to(_torch_dtype(code)), code))  # 64-bit partial wraps into the column's type
+        elif kind == "count":
+            c = next(it)
+            out.append(Col(name, c.t.to(torch.int32), _ffi.U32))
+        elif kind == "mean":
+            s, cnt = next(it), next(it)
+            code = mean_out_code(src)
+            n = _to_f64(cnt)
+            if src == _ffi.F32:  # the reference folds f32 in f32 before the division (aggregations/mod.rs:701-742)
+                num = s.t.to(torch.float32).to(torch.float64)
+            else:
+                num = _to_f64(s)
+            valid = n > 0
+            v = torch.where(valid, num / torch.where(valid, n, torch.ones_like(n)), torch.zeros_like(n))
+            out.append(Col(name, v.to(_torch_dtype(code)), code, None if bool(valid.all()) else valid))
+        else:
+            c = next(it)
+            out.append(Col(name, c.t, c.code, c.mask))
+    return out
+
+
+def group_by_agg_sharded(keys: list[Column], vals: list[Column], aggs, *, device=None, engine=None, group=None,
+                         names: list[str] | None = None, n_groups_hint: int = 0):
+    """`keys` / `vals` are this rank's row shard; `aggs` = [(value index, 'sum'|'mean'|'min'|'max'|'count')].
+    Returns this rank's share of the result frame (list[Col]: keys then one column per aggregation); the
+    shares of all ranks are disjoint in the keys and together are the result."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    engine = engine or HipEngine(device)
+    names = names or [f"{vals[ci].name if kind != 'count' else 'count'}_{kind}" for ci, kind in aggs]
+    val_codes = [v.dtype for v in vals]
+    part = engine.partial(keys, vals, aggs, n_groups_hint) if isinstance(engine, HipEngine) else engine.partial(keys, vals, aggs)
+    nk = len(keys)
+    pk, pv = part[:nk], part[nk:]
+    if world > 1:
+        h = engine.key_hashes(pk)
+        owner = ((h >> 33) & 0x7FFFFFFF) % world
+        moved = exchange_by_owner(pk + pv, owner, world, group)
+        pk, pv = moved[:nk], moved[nk:]
+        merged = engine.merge(pk, pv, _merge_ops(aggs))
+        pk, pv = merged[:nk], merged[nk:]
+    return finalize(pk, pv, aggs, val_codes, names)

@@ -377,3 +377,55 @@ def test_group_tuples_empty_and_errors():
     assert g.n_groups == 0 and g.n_rows == 0
     with pytest.raises(pa.ShapeMismatch):
         pa.group_tuples([Column("a", np.zeros(3, np.int32)), Column("b", np.zeros(4, np.int32))])
+
+
+def test_sharded_engine_two_shards_one_gpu(oracle):
+    """The two local passes of polars_amd/distributed.py on the GPU (HipEngine.partial / key_hashes / merge)
+    and its finalize step, with the all-to-all replaced by its definition (rows go to owner = hash % world):
+    two row shards, regrouped per owner, must give the single-pass result."""
+    import torch
+
+    from polars_amd import distributed as pd_
+
+    rng = np.random.default_rng(53)
+    n, world = 60000, 2
+    dev = torch.device("cuda:0")
+    k1 = rng.integers(-30, 30, n).astype(np.int32); k1m = rng.random(n) > 0.05
+    k2 = rng.integers(0, 9, n).astype(np.int64)
+    v0 = rng.integers(-1000, 1000, n).astype(np.int32)
+    v1 = np.round(rng.uniform(0, 100, n), 6); v1m = rng.random(n) > 0.1
+    v2 = rng.integers(0, 50, n).astype(np.uint32)
+    aggs = [(0, "sum"), (1, "mean"), (0, "min"), (1, "max"), (0, "count"), (2, "mean"), (2, "sum")]
+    eng = pd_.HipEngine(dev)
+    shards = []
+    for r in range(world):
+        lo, hi = r * n // world, (r + 1) * n // world
+        keys = [Column("k1", k1[lo:hi], k1m[lo:hi]), Column("k2", k2[lo:hi])]
+        vals = [Column("v0", v0[lo:hi]), Column("v1", v1[lo:hi], v1m[lo:hi]), Column("v2", v2[lo:hi])]
+        part = eng.partial(keys, vals, aggs)
+        owner = ((eng.key_hashes(part[:2]) >> 33) & 0x7FFFFFFF) % world
+        shards.append((part, owner))
+    names = ["s", "m", "mn", "mx", "c", "m2", "s2"]
+    outs = []
+    for r in range(world):  # what rank r holds after the exchange
+        cols = []
+        for j in range(len(shards[0][0])):
+            ts, ms = [], []
+            for part, owner in shards:
+                sel = owner == r
+                ts.append(part[j].t[sel])
+                ms.append((part[j].mask if part[j].mask is not None else torch.ones_like(sel))[sel])
+            c0 = shards[0][0][j]
+            has_mask = any(p[j].mask is not None for p, _ in shards)
+            cols.append(pd_.Col(c0.name, torch.cat(ts).contiguous(), c0.code, torch.cat(ms) if has_mask else None))
+        merged = eng.merge(cols[:2], cols[2:], pd_._merge_ops(aggs))
+        outs.append(pd_.finalize(merged[:2], merged[2:], aggs, [_ffi.I32, _ffi.F64, _ffi.U32], names))
+    got = []
+    for j in range(len(outs[0])):
+        v = np.concatenate([o[j].t.cpu().numpy().view(_ffi.code_np_dtype(o[j].code)) for o in outs])
+        m = np.concatenate([(np.ones(o[j].t.numel(), bool) if o[j].mask is None else o[j].mask.cpu().numpy()) for o in outs])
+        got.append((v, m))
+    keys = [Column("k1", k1, k1m), Column("k2", k2)]
+    vals = [Column("v0", v0), Column("v1", v1, v1m), Column("v2", v2)]
+    want, _ = oracle.group_by_agg(keys, vals, aggs)
+    util.assert_frames_match(got, util.oracle_to_np(want), 2, what="two shards, one GPU")
