@@ -107,9 +107,11 @@ typedef enum plhip_strategy {
   PLHIP_STRATEGY_LDS = 2,        /* per-workgroup LDS tables, then one merge into the HBM table */
   PLHIP_STRATEGY_PARTITIONED = 3,/* radix partition on hash bits, then one LDS table per partition */
   PLHIP_STRATEGY_DIRECT = 4,     /* LDS-only: per-workgroup LDS tables over row slices, merged in LDS (few groups) */
-  PLHIP_STRATEGY_TILESORT = 5    /* LDS-only: tiles sorted by hash partition in LDS, per-partition LDS tables, merged
+  PLHIP_STRATEGY_TILESORT = 5,   /* LDS-only: tiles sorted by hash partition in LDS, per-partition LDS tables, merged
                                     in LDS (many groups); AUTO picks DIRECT / TILESORT when the query qualifies and
                                     falls back to the strategies above otherwise */
+  PLHIP_STRATEGY_SORT = 6        /* radix sort of (packed key, row), run boundaries, one fold per run: any number of
+                                    groups up to all-unique keys, immune to skew */
 } plhip_strategy_t;
 
 /* Optional knowledge the caller has about the query.  struct_size = sizeof(plhip_options_t). */

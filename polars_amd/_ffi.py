@@ -32,7 +32,7 @@ FLAG_MAINTAIN_ORDER = 1
 FLAG_OUTPUT_DEVICE = 2
 FLAG_PARTIAL = 4
 
-STRATEGIES = {"auto": 0, "global": 1, "lds": 2, "partitioned": 3, "direct": 4, "tilesort": 5}
+STRATEGIES = {"auto": 0, "global": 1, "lds": 2, "partitioned": 3, "direct": 4, "tilesort": 5, "sort": 6}
 
 STATUS_NAMES = {
     0: "OK", 1: "ComputeError", 2: "ShapeMismatch", 3: "OutOfMemory", 4: "UnsupportedDtype", 5: "HipError",

@@ -478,6 +478,7 @@ int env_strategy() {
   if (!strcmp(e, "partitioned")) return PLHIP_STRATEGY_PARTITIONED;
   if (!strcmp(e, "direct")) return PLHIP_STRATEGY_DIRECT;
   if (!strcmp(e, "tilesort")) return PLHIP_STRATEGY_TILESORT;
+  if (!strcmp(e, "sort")) return PLHIP_STRATEGY_SORT;
   return PLHIP_STRATEGY_AUTO;
 }
 
@@ -672,8 +673,9 @@ int ceil_log2(uint64_t x) { int b = 0; while ((1ull << b) < x) b++; return b; }
 // runs the general path (stable order, wide key tuples, tiny inputs, more groups than one partition level
 // brings into LDS, or a cardinality estimate that turned out too low).
 int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t groups_hint, int strategy,
-             plhip_result_t **out, bool &handled) {
+             plhip_result_t **out, bool &handled, uint64_t &g_seen) {
   handled = false;
+  g_seen = 0;
   Ctx &c = g_ctx;
   Plan &P = L.P;
   const int64_t n = P.n_rows;
@@ -728,6 +730,7 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
     }
   }
   g_est = std::max<uint64_t>(g_est, 1);
+  g_seen = g_est;
 
   // ---- shape of the pipeline -----------------------------------------------------------------------------
   const int cus = plhip_num_cus();
@@ -901,6 +904,101 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
   return finish_result(R, G, flags, out);
 }
 
+
+// The sort strategy (sort_path.hip): any number of groups, any skew; also serves wide key tuples (output keys
+// gathered at the first row of each run).  Declines stable order (the general path sorts groups by first row).
+int run_sorted(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, plhip_result_t **out, bool &handled) {
+  handled = false;
+  Ctx &c = g_ctx;
+  Plan &P = L.P;
+  const int64_t n = P.n_rows;
+  if ((flags & PLHIP_FLAG_MAINTAIN_ORDER) || n < 1 || P.n_accs > 20) return PLHIP_OK;
+  int rc;
+  if (P.single_key && dk[0].validity) { // nulls become code 0 of a range-compressed key
+    std::vector<KeyCol> one(1);
+    one[0].col = dk[0]; one[0].nullable = true;
+    if ((rc = measure_key_columns(one, n))) return rc;
+    if (one[0].bits > 64) return PLHIP_OK;
+    P.single_key = 0;
+    pack_keys(P, one);
+  }
+  int end_bit = 0;
+  if (P.single_key) end_bit = dtype_width(dk[0].dtype) <= 4 ? 32 : 64;
+  else for (int i = 0; i < P.n_keys; i++) end_bit += (int)P.keys[i].bits;
+  end_bit = std::max(1, std::min(64, end_bit));
+  size_t temp_bytes = 0;
+  HIP_TRY(sort_path_temp_bytes((uint64_t)n, end_bit, &temp_bytes));
+  const size_t n8 = ((size_t)n * 8 + 255) & ~(size_t)255, n4 = ((size_t)n * 4 + 255) & ~(size_t)255;
+  HIP_TRY(c.table.reserve(2 * n8));
+  HIP_TRY(c.slots.reserve(2 * n4));
+  HIP_TRY(c.part.reserve(2 * n4));
+  HIP_TRY(c.rank.reserve(n4 + 256));
+  HIP_TRY(c.sortkeys.reserve(temp_bytes));
+  HIP_TRY(c.items.reserve(((size_t)n / 2048 + 2) * 4 + 256));
+  HIP_TRY(c.flags.reserve(64));
+  HIP_TRY(c.plans.reserve(sizeof(KeyGather)));
+  uint32_t *dflags = (uint32_t *)c.flags.p;
+  uint64_t *keys_a = (uint64_t *)c.table.p, *keys_b = (uint64_t *)((uint8_t *)c.table.p + n8);
+  uint32_t *rows_a = (uint32_t *)c.slots.p, *rows_b = (uint32_t *)((uint8_t *)c.slots.p + n4);
+  uint32_t *fl_d = (uint32_t *)c.part.p, *gid = (uint32_t *)((uint8_t *)c.part.p + n4);
+  uint32_t *offsets = (uint32_t *)c.rank.p;
+  uint32_t *long_count = (uint32_t *)c.items.p, *long_list = long_count + 64;
+  HIP_TRY(hipEventRecord(c.ev[0], c.stream));
+  HIP_TRY(hipMemsetAsync(dflags, 0, 64, c.stream));
+  HIP_TRY(hipMemsetAsync(long_count, 0, 256, c.stream));
+  HIP_TRY(hipEventRecord(c.ev[1], c.stream));
+  HIP_TRY(launch_sort_groups(P, keys_a, keys_b, rows_a, rows_b, fl_d, gid, offsets, c.sortkeys.p, temp_bytes, end_bit, dflags, c.stream));
+  HIP_TRY(hipEventRecord(c.ev[4], c.stream));
+  uint32_t fl[16];
+  TableRef t{nullptr, 0, dflags};
+  if ((rc = read_flags(t, fl))) return rc;
+  const uint64_t G = fl[FLAG_NGROUPS];
+  plhip_result *R = new (std::nothrow) plhip_result();
+  if (!R) return fail(PLHIP_ERR_OOM, "host allocation failed");
+  R->on_device = true; R->device = c.device; R->n_rows = (int64_t)G;
+  OutPlan OP{};
+  OP.n_outs = (int)L.outs.size();
+  for (size_t i = 0; i < L.outs.size(); i++) {
+    OutSpec o = L.outs[i];
+    ResultCol col;
+    col.dtype = (int)o.dtype;
+    hipError_t e = g_pool.get((size_t)std::max<uint64_t>(G, 1) * dtype_width((int)o.dtype), &col.values, &col.vcap);
+    if (e == hipSuccess && o.validity) {
+      e = g_pool.get((size_t)(G / 64 + 2) * 8, (void **)&col.validity, &col.bcap);
+      if (e == hipSuccess) e = hipMemsetAsync(col.validity, 0, (size_t)(G / 64 + 2) * 8, c.stream);
+    }
+    R->cols.push_back(col);
+    if (e != hipSuccess) { delete R; return fail_hip(e, "hipMalloc(output)"); }
+    o.values = (uint8_t *)col.values;
+    o.validity = col.validity;
+    OP.outs[i] = o;
+  }
+  const KeyGather *kg_dev = nullptr;
+  hipError_t e = hipSuccess;
+  if (L.KG.enabled) {
+    e = hipMemcpyAsync(c.plans.p, &L.KG, sizeof(KeyGather), hipMemcpyHostToDevice, c.stream);
+    kg_dev = (const KeyGather *)c.plans.p;
+  }
+  if (e == hipSuccess) {
+    launch_fold_sorted(P, OP, kg_dev, keys_b, rows_b, offsets, G, long_list, long_count, c.stream);
+    e = hipGetLastError();
+  }
+  hipEventRecord(c.ev[5], c.stream);
+  hipEventRecord(c.ev[3], c.stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
+  if (e != hipSuccess) { delete R; return fail_hip(e, "sort strategy kernels"); }
+  hipEventElapsedTime(&c.total_ms, c.ev[0], c.ev[3]);
+  c.k_ms[0] = c.k_ms[1] = c.k_ms[2] = 0.f;
+  hipEventElapsedTime(&c.k_ms[0], c.ev[1], c.ev[4]);
+  hipEventElapsedTime(&c.k_ms[1], c.ev[4], c.ev[5]);
+  c.part_ms = c.k_ms[0]; c.agg_ms = c.k_ms[1];
+  c.dom_ms = std::max(c.k_ms[0], c.k_ms[1]);
+  c.dom_kernel = c.k_ms[0] >= c.k_ms[1] ? "k_pack_rows+rocprim radix sort+run scan" : "k_fold_sorted";
+  c.strategy = "sort";
+  handled = true;
+  return finish_result(R, G, flags, out);
+}
+
 } // namespace
 
 // ---------------------------------------------------------------------------------------------------------
@@ -925,7 +1023,7 @@ int32_t plhip_init(int32_t device_id) {
 const char *plhip_last_error(void) { return g_ctx.err.c_str(); }
 
 int32_t plhip_set_strategy(int32_t strategy) {
-  if (strategy < 0 || strategy > PLHIP_STRATEGY_TILESORT) return fail(PLHIP_ERR_INVALID, "bad strategy");
+  if (strategy < 0 || strategy > PLHIP_STRATEGY_SORT) return fail(PLHIP_ERR_INVALID, "bad strategy");
   g_ctx.forced_strategy = strategy;
   return PLHIP_OK;
 }
@@ -1035,7 +1133,15 @@ int32_t plhip_group_by_agg_opts(const plhip_column_t *keys, int32_t n_keys, cons
     int64_t hint = 0;
     if (opts && opts->struct_size >= sizeof(plhip_options_t)) hint = opts->n_groups_hint;
     bool handled = false;
-    if ((rc = run_fast(L, dk, flags, hint, strategy, out, handled))) return rc;
+    uint64_t g_seen = 0;
+    if ((rc = run_fast(L, dk, flags, hint, strategy, out, handled, g_seen))) return rc;
+    if (handled) return PLHIP_OK;
+    // more groups than the LDS pipeline holds (or wide key tuples): sort instead of hammering HBM with atomics
+    strategy = (n >= (1 << 16) && (g_seen > 4096 || L.KG.enabled)) ? PLHIP_STRATEGY_SORT : PLHIP_STRATEGY_AUTO;
+  }
+  if (strategy == PLHIP_STRATEGY_SORT) {
+    bool handled = false;
+    if ((rc = run_sorted(L, dk, flags, out, handled))) return rc;
     if (handled) return PLHIP_OK;
     strategy = PLHIP_STRATEGY_AUTO;
   }

@@ -72,3 +72,10 @@ void launch_iota_u32(uint32_t *out, uint64_t n, hipStream_t s);
 void launch_csr(const uint32_t *ids_sorted, const uint32_t *indices, uint64_t n, uint64_t G, uint32_t *offsets, uint32_t *first, hipStream_t s);
 // `o.outs[0]` is the one output column; at most 4 accumulators; o.outs[0].validity must be zeroed
 void launch_agg_groups(const Plan &p, const OutPlan &o, const uint32_t *offsets, const uint32_t *indices, uint64_t G, bool wave, hipStream_t s);
+
+// sort strategy (sort_path.hip)
+hipError_t sort_path_temp_bytes(uint64_t n, int end_bit, size_t *bytes);
+hipError_t launch_sort_groups(const Plan &p, uint64_t *keys_a, uint64_t *keys_b, uint32_t *rows_a, uint32_t *rows_b, uint32_t *flags,
+                              uint32_t *gid, uint32_t *offsets, void *temp, size_t temp_bytes, int end_bit, uint32_t *dflags, hipStream_t s);
+void launch_fold_sorted(const Plan &p, const OutPlan &o, const KeyGather *kg_dev, const uint64_t *skeys, const uint32_t *rows,
+                        const uint32_t *offsets, uint64_t G, uint32_t *long_list, uint32_t *long_count, hipStream_t s);

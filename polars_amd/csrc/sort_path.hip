@@ -1,0 +1,181 @@
+// sort_path.hip — the strategy for more groups than one partition level brings into LDS (up to all-unique
+// keys, e.g. BASELINE configs 3 and 5), and for any skew: radix sort of (packed key, row) pairs, run
+// boundaries, then one fold per run.
+//
+//   k_pack_rows      packed key of every row (the Plan's range-compressed tuple) + row ids
+//   rocprim          stable LSD radix sort of the pairs on the used key bits (library sort: the pass count, not
+//                    the kernel, is what this tier is about; HBM-bound)
+//   k_run_flags      1 where a new key starts; inclusive scan -> group id; k_run_offsets -> CSR offsets
+//   k_fold_sorted    one thread per run: gathers the value rows (ascending row order = the reference's fold
+//                    order), folds every accumulator in registers, writes the output columns; long runs are
+//                    queued and folded by one workgroup each (k_fold_sorted_long), so a heavy key cannot
+//                    serialise on one lane
+//
+// No hash table, no atomics on the row path; cost independent of the number of groups.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+#include "device.hpp"
+#include "kernels.hpp"
+
+namespace {
+
+#define SP_BLOCK 256
+#define SP_LONG 2048 // runs at least this long go to the per-workgroup kernel
+
+__global__ void __launch_bounds__(256) k_pack_rows(Plan P, uint64_t *__restrict__ keys, uint32_t *__restrict__ rows) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < P.n_rows; r += stride) {
+    bool isn;
+    keys[r] = row_packed_key(P, r, isn);
+    rows[r] = (uint32_t)r;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_run_flags(const uint64_t *__restrict__ keys, uint64_t n, uint32_t *__restrict__ flags) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+
+// gid = inclusive scan of the flags: run g (0-based) starts where flags[i] == 1 and gid[i] == g + 1
+__global__ void __launch_bounds__(256) k_run_offsets(const uint32_t *__restrict__ flags, const uint32_t *__restrict__ gid, uint64_t n,
+                                                     uint32_t *__restrict__ offsets, uint32_t *__restrict__ dflags) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && flags[i]) offsets[gid[i] - 1] = (uint32_t)i;
+  if (i == n - 1) { offsets[gid[i]] = (uint32_t)n; dflags[FLAG_NGROUPS] = gid[i]; }
+}
+
+DEVINL void fold_local(const AccSpec &a, uint64_t &state, uint64_t operand) {
+  switch (a.op) {
+    case ACC_ADD_U64: state += operand; break;
+    case ACC_ADD_F64: state = (uint64_t)__double_as_longlong(__longlong_as_double((long long)state) + __longlong_as_double((long long)operand)); break;
+    case ACC_MIN_I64: state = (long long)operand < (long long)state ? operand : state; break;
+    case ACC_MAX_I64: state = (long long)operand > (long long)state ? operand : state; break;
+    case ACC_MIN_U64: state = operand < state ? operand : state; break;
+    case ACC_MAX_U64: state = operand > state ? operand : state; break;
+    case ACC_CNT_ALL: case ACC_CNT_VALID: state += operand; break;
+    case ACC_FIRST_ROW: state = operand < state ? operand : state; break;
+  }
+}
+
+// accumulators of run g -> output row g (sst[a * SP_BLOCK + lane_slot] holds accumulator a)
+DEVINL void emit_run(const Plan &P, const OutPlan &O, const KeyGather *KG, const uint64_t *sst, uint32_t slot, uint64_t packed,
+                     uint32_t first_row, uint64_t g) {
+  for (int o = 0; o < O.n_outs; o++) {
+    const OutSpec &S = O.outs[o];
+    bool valid;
+    if (S.kind == OUT_KEY) {
+      if (KG && KG->enabled) { // keys_sliced: the original key column at the group's first row
+        const KeySpec &K = KG->okeys[S.acc];
+        valid = bit_valid(K.validity, K.boff, first_row);
+        store_by_dtype_int(S.values, K.dtype, g, valid ? key_denorm(load_key_norm(K.values, K.dtype, first_row), K.dtype) : 0);
+      } else {
+        valid = finalize_key(P, S, packed, false, false, g);
+      }
+    } else {
+      const uint64_t acc = S.acc >= 0 ? sst[S.acc * SP_BLOCK + slot] : 0;
+      const uint32_t cnt_all = S.cnt_all >= 0 ? (uint32_t)sst[S.cnt_all * SP_BLOCK + slot] : 0;
+      const uint32_t cnt_valid = S.cnt_valid >= 0 ? (uint32_t)sst[S.cnt_valid * SP_BLOCK + slot] : cnt_all;
+      valid = finalize_value(S, acc, cnt_all, cnt_valid, g);
+    }
+    if (S.validity && valid) atomicOr((unsigned int *)S.validity + (g >> 5), 1u << (g & 31)); // zeroed bitmap
+  }
+}
+
+__global__ void __launch_bounds__(SP_BLOCK) k_fold_sorted(Plan P, OutPlan O, const KeyGather *__restrict__ KG,
+                                                          const uint64_t *__restrict__ skeys, const uint32_t *__restrict__ rows,
+                                                          const uint32_t *__restrict__ offsets, uint64_t G,
+                                                          uint32_t *__restrict__ long_list, uint32_t *__restrict__ long_count) {
+  extern __shared__ __align__(16) uint64_t sst[]; // [n_accs][SP_BLOCK]
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  const uint32_t b = offsets[g], e = offsets[g + 1];
+  if (e - b >= SP_LONG) {
+    long_list[atomicAdd(long_count, 1u)] = (uint32_t)g;
+    return;
+  }
+  for (int a = 0; a < P.n_accs; a++) { // one accumulator at a time: its state stays in registers
+    const AccSpec A = P.accs[a];
+    uint64_t st = A.init;
+    for (uint32_t i = b; i < e; i++) {
+      uint64_t operand;
+      if (acc_operand(P, A, (int64_t)rows[i], operand)) fold_local(A, st, operand);
+    }
+    sst[a * SP_BLOCK + threadIdx.x] = st;
+  }
+  emit_run(P, O, KG, sst, threadIdx.x, skeys[b], rows[b], g);
+}
+
+// one workgroup per long run: lanes stride the index list, partial states are combined in a fixed tree
+__global__ void __launch_bounds__(SP_BLOCK) k_fold_sorted_long(Plan P, OutPlan O, const KeyGather *__restrict__ KG,
+                                                               const uint64_t *__restrict__ skeys, const uint32_t *__restrict__ rows,
+                                                               const uint32_t *__restrict__ offsets,
+                                                               const uint32_t *__restrict__ long_list, const uint32_t *__restrict__ long_count) {
+  extern __shared__ __align__(16) uint64_t sst[]; // [n_accs][SP_BLOCK]
+  for (uint32_t li = blockIdx.x; li < *long_count; li += gridDim.x) {
+    const uint64_t g = long_list[li];
+    const uint32_t b = offsets[g], e = offsets[g + 1];
+    for (int a = 0; a < P.n_accs; a++) {
+      const AccSpec A = P.accs[a];
+      uint64_t st = A.init;
+      for (uint32_t i = b + threadIdx.x; i < e; i += SP_BLOCK) {
+        uint64_t operand;
+        if (acc_operand(P, A, (int64_t)rows[i], operand)) fold_local(A, st, operand);
+      }
+      uint64_t *col = sst + a * SP_BLOCK;
+      col[threadIdx.x] = st;
+      __syncthreads();
+      for (uint32_t off = SP_BLOCK / 2; off > 0; off >>= 1) {
+        if (threadIdx.x < off) {
+          uint64_t mine = col[threadIdx.x];
+          fold_local(A, mine, col[threadIdx.x + off]);
+          col[threadIdx.x] = mine;
+        }
+        __syncthreads();
+      }
+    }
+    if (threadIdx.x == 0) emit_run(P, O, KG, sst, 0, skeys[b], rows[b], g);
+    __syncthreads();
+  }
+}
+
+} // namespace
+
+// scratch bytes rocprim needs for the sort and the scan of n elements
+hipError_t sort_path_temp_bytes(uint64_t n, int end_bit, size_t *bytes) {
+  size_t a = 0, b = 0;
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, a, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, n, 0, end_bit);
+  if (e != hipSuccess) return e;
+  e = rocprim::inclusive_scan(nullptr, b, (uint32_t *)nullptr, (uint32_t *)nullptr, n, rocprim::plus<uint32_t>());
+  *bytes = (a > b ? a : b) + 256;
+  return e;
+}
+
+// keys_a/rows_a receive the packed rows; the sorted pairs end in keys_b/rows_b.  offsets: n + 1 u32.
+// flags / gid: n u32 each.  On return dflags[FLAG_NGROUPS] = number of runs (read it after the stream).
+hipError_t launch_sort_groups(const Plan &p, uint64_t *keys_a, uint64_t *keys_b, uint32_t *rows_a, uint32_t *rows_b, uint32_t *flags,
+                              uint32_t *gid, uint32_t *offsets, void *temp, size_t temp_bytes, int end_bit, uint32_t *dflags, hipStream_t s) {
+  const uint64_t n = (uint64_t)p.n_rows;
+  int64_t blocks = (p.n_rows + 255) / 256;
+  hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0, s, p, keys_a, rows_a);
+  hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_a, keys_b, rows_a, rows_b, n, 0, end_bit, s); // stable
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_run_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, keys_b, n, flags);
+  e = rocprim::inclusive_scan(temp, temp_bytes, flags, gid, n, rocprim::plus<uint32_t>(), s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_run_offsets, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, flags, gid, n, offsets, dflags);
+  return hipGetLastError();
+}
+
+void launch_fold_sorted(const Plan &p, const OutPlan &o, const KeyGather *kg_dev, const uint64_t *skeys, const uint32_t *rows,
+                        const uint32_t *offsets, uint64_t G, uint32_t *long_list, uint32_t *long_count, hipStream_t s) {
+  if (!G) return;
+  const size_t lds = (size_t)(p.n_accs ? p.n_accs : 1) * SP_BLOCK * 8;
+  hipLaunchKernelGGL(k_fold_sorted, dim3((unsigned)((G + SP_BLOCK - 1) / SP_BLOCK)), dim3(SP_BLOCK), lds, s, p, o, kg_dev, skeys, rows, offsets, G,
+                     long_list, long_count);
+  const uint64_t max_long = (uint64_t)p.n_rows / SP_LONG + 1;
+  hipLaunchKernelGGL(k_fold_sorted_long, dim3((unsigned)(max_long < 4096 ? max_long : 4096)), dim3(SP_BLOCK), lds, s, p, o, kg_dev, skeys, rows,
+                     offsets, long_list, long_count);
+}

@@ -12,7 +12,7 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 KA = util.load_known_answers()
-STRATEGIES = ["auto", "global", "lds", "partitioned", "direct", "tilesort"]
+STRATEGIES = ["auto", "global", "lds", "partitioned", "direct", "tilesort", "sort"]
 
 
 @pytest.fixture(autouse=True)
@@ -92,7 +92,7 @@ def check_parity(oracle, keys, values, aggs, strategy="auto", maintain_order=Fal
     want, _ = oracle.group_by_agg(keys, values, aggs, maintain_order=maintain_order)
     got = run_product(keys, values, aggs, maintain_order, strategy)
     ran = pa.last_strategy()
-    if strategy in ("direct", "tilesort") and ran != strategy:
+    if strategy in ("direct", "tilesort", "sort") and ran != strategy:
         FELL_BACK.append((what, strategy, ran))
     g, w = util.frame_to_np(got), util.oracle_to_np(want)
     if maintain_order:  # row order itself is part of the contract
@@ -109,9 +109,9 @@ FELL_BACK: list = []  # (case, forced strategy, strategy that ran): the LDS-only
 def test_zz_fast_path_coverage():
     """The forced LDS-only strategies may decline (stable order, wide key tuples, more groups than fit);
     they must not decline the plain cases."""
-    declined = {w for w, _, _ in FELL_BACK}
-    allowed = ("multi-key", "stable", "card=None", "n=0")
-    bad = [d for d in declined if not any(d.startswith(a) or a in d for a in allowed)]
+    allowed = {"direct": ("multi-key", "stable", "card=None", "n=0"), "tilesort": ("multi-key", "stable", "card=None", "n=0"),
+               "sort": ("stable", "n=0")}
+    bad = [w for w, s, _ in FELL_BACK if not any(w.startswith(a) or a in w for a in allowed[s])]
     assert not bad, f"fast path declined: {sorted(bad)}"
 
 
