@@ -748,7 +748,7 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
   }
   if (strategy == PLHIP_STRATEGY_TILESORT) direct = false;
   if (strategy == PLHIP_STRATEGY_DIRECT && !direct) return PLHIP_OK;
-  const uint32_t pbits = 8, np = 1u << pbits;
+  uint32_t pbits = 8, np = 1u << pbits; // 9 when that is what brings the groups of a partition into LDS
   uint32_t w = 1, S = 1, n_pg = 1, has_null_pg = 0, n_items = 0, mbits = 0;
   int64_t rows_per_item = 0;
   const uint32_t n_tiles = (uint32_t)((n + TS_TILE - 1) / TS_TILE);
@@ -772,12 +772,17 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
     while (mbits < FP_MAX_MBITS && (entries >> mbits) > 4096) mbits++;
   } else {
     // groups per hash partition, with head-room for the sampling error and uneven partitions
-    const double gf = (double)g_est / np * 1.3 + 8;
+    const double slack = groups_hint > 0 ? 1.12 : 1.3; // a hint is a bound: only the partitions' unevenness is left
+    double gf = (double)g_est / np * slack + 8;
     uint32_t lb_max = 15;
     while (lb_max > 6 && fast_table_bytes(P, lb_max, key_bytes) > LDS_MAX) lb_max--;
-    if (gf > 0.45 * (double)(1u << lb_max)) return PLHIP_OK; // needs a second partition level: general path
+    if (gf > 0.45 * (double)(1u << lb_max) && n >= (1 << 22)) { // shorter runs (16 rows per tile), twice the partitions
+      pbits = TS_MAX_PBITS; np = 1u << pbits;
+      gf = (double)g_est / np * slack + 8;
+    }
+    if (gf > 0.62 * (double)(1u << lb_max)) return PLHIP_OK; // needs a second partition level: the sort strategy
     lbits = 6;
-    while (gf * w > 0.45 * (double)(1u << lbits)) lbits++;
+    while (lbits < lb_max && gf * w > 0.45 * (double)(1u << lbits)) lbits++;
     while (lbits < lb_max && gf * w > 0.125 * (double)(1u << lbits) && fast_table_bytes(P, lbits + 1, key_bytes) <= 100 * 1024) lbits++;
     has_null_pg = (P.single_key && dk[0].validity) ? 1 : 0;
     n_pg = np / w + has_null_pg;

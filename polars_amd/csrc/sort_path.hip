@@ -99,7 +99,18 @@ __global__ void __launch_bounds__(SP_BLOCK) k_fold_sorted(Plan P, OutPlan O, con
   for (int a = 0; a < P.n_accs; a++) { // one accumulator at a time: its state stays in registers
     const AccSpec A = P.accs[a];
     uint64_t st = A.init;
-    for (uint32_t i = b; i < e; i++) {
+    uint32_t i = b;
+    for (; i + 4 <= e; i += 4) { // four gathers in flight; folded in index order (the reference's order)
+      const uint32_t r0 = rows[i], r1 = rows[i + 1], r2 = rows[i + 2], r3 = rows[i + 3];
+      uint64_t o0, o1, o2, o3;
+      const bool v0 = acc_operand(P, A, (int64_t)r0, o0), v1 = acc_operand(P, A, (int64_t)r1, o1);
+      const bool v2 = acc_operand(P, A, (int64_t)r2, o2), v3 = acc_operand(P, A, (int64_t)r3, o3);
+      if (v0) fold_local(A, st, o0);
+      if (v1) fold_local(A, st, o1);
+      if (v2) fold_local(A, st, o2);
+      if (v3) fold_local(A, st, o3);
+    }
+    for (; i < e; i++) {
       uint64_t operand;
       if (acc_operand(P, A, (int64_t)rows[i], operand)) fold_local(A, st, operand);
     }
