@@ -62,6 +62,25 @@ def mean_out_code(code: int) -> int:
 # ---------------------------------------------------------------------------------------------------
 # the two local passes on libplhip.so
 # ---------------------------------------------------------------------------------------------------
+class _FrameOwner:
+    """Keeps a plhip_result_t alive for the tensors that alias its buffers."""
+
+    def __init__(self, handle):
+        self.handle = handle
+
+    def __del__(self):
+        try:
+            _ffi.lib().plhip_result_free(self.handle)
+        except Exception:
+            pass
+
+
+class _DevBuf:
+    def __init__(self, ptr: int, nbytes: int, owner):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+        self._owner = owner
+
+
 class HipEngine:
     """Local passes through the C ABI with device-resident inputs and outputs."""
 
@@ -69,30 +88,43 @@ class HipEngine:
         self.device = device
 
     def _frame(self, handle, cols, names) -> list[Col]:
-        """Copies a device-resident result frame into torch tensors (device-to-device) and frees it."""
+        """Wraps a device-resident result frame as torch tensors.  Zero-copy through __cuda_array_interface__
+        (the frame is freed when the last tensor over it dies); if this torch build cannot alias foreign
+        device memory the columns are copied device-to-device instead."""
         import torch
 
-        L = _ffi.lib()
+        owner = _FrameOwner(handle)
         out = []
-        try:
-            for name, cs in zip(names, cols):
-                n = cs.length
-                dt = _torch_dtype(cs.dtype)
-                t = torch.empty(n, dtype=dt, device=self.device)
-                nbytes = n * t.element_size()
-                if nbytes:
-                    _hip_memcpy_dtod(t.data_ptr(), cs.values, nbytes)
-                mask = None
-                if cs.validity:
-                    nb = (n + 7) // 8
-                    bits = torch.empty(max(nb, 1), dtype=torch.uint8, device=self.device)
-                    if nb:
-                        _hip_memcpy_dtod(bits.data_ptr(), cs.validity, nb)
-                    mask = _unpack_bits(bits, n)
-                out.append(Col(name, t, cs.dtype, mask))
-        finally:
-            L.plhip_result_free(handle)
+        for name, cs in zip(names, cols):
+            n = cs.length
+            dt = _torch_dtype(cs.dtype)
+            t = self._alias(cs.values, n * torch.empty(0, dtype=dt).element_size(), owner).view(dt) if n else torch.empty(0, dtype=dt, device=self.device)
+            mask = None
+            if cs.validity:
+                nb = (n + 7) // 8
+                bits = self._alias(cs.validity, nb, owner) if nb else torch.empty(0, dtype=torch.uint8, device=self.device)
+                mask = _unpack_bits(bits, n)
+            out.append(Col(name, t, cs.dtype, mask))
         return out
+
+    def _alias(self, ptr: int, nbytes: int, owner):
+        import torch
+
+        if HipEngine._can_alias is not False:
+            try:
+                t = torch.as_tensor(_DevBuf(ptr, nbytes, owner), device=self.device)
+                t._plhip_owner = owner
+                HipEngine._can_alias = True
+                return t
+            except Exception:
+                if HipEngine._can_alias:
+                    raise
+                HipEngine._can_alias = False
+        t = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        _hip_memcpy_dtod(t.data_ptr(), ptr, nbytes)
+        return t
+
+    _can_alias = None
 
     def _columns(self, cols: list[Col]) -> list[Column]:
         out = []
@@ -124,7 +156,7 @@ class HipEngine:
         kc, pc = self._columns(keys), self._columns(parts)
         aggs = [(i, _ffi.AGG_NAMES[op]) for i, op in enumerate(ops)]
         names = [k.name for k in keys] + [p.name for p in parts]
-        return self.group_by(kc, pc, aggs, 0, names)
+        return self.group_by(kc, pc, aggs, 0, names, hint=max(int(keys[0].t.numel()), 1))  # every row may be a group
 
     def key_hashes(self, keys: list[Col]):
         import torch
@@ -193,20 +225,13 @@ def exchange_by_owner(cols: list[Col], owner, world: int, group=None) -> list[Co
     dev = owner.device
     n = owner.numel()
     order = torch.argsort(owner, stable=True)
-    # counts and "this column carries a validity mask here" flags travel together: the record layout must be
-    # the same on every rank, and a rank whose shard happens to hold no nulls may have dropped a mask
-    hdr = torch.zeros((world, 1 + len(cols)), dtype=torch.int64, device=dev)
-    hdr[:, 0] = torch.bincount(owner, minlength=world)
-    for j, c in enumerate(cols):
-        if c.mask is not None:
-            hdr[:, 1 + j] = 1
-    got = torch.empty_like(hdr)
-    dist.all_to_all_single(got, hdr, group=group)
-    sc, got_h = hdr[:, 0].tolist(), got.tolist()  # the one host sync of the exchange
-    rc = [r[0] for r in got_h]
-    masked = [any(r[1 + j] for r in got_h) for j in range(len(cols))]
-    cols = [Col(c.name, c.t, c.code, c.mask if c.mask is not None or not masked[j] else torch.ones(n, dtype=torch.bool, device=dev))
-            for j, c in enumerate(cols)]
+    # The record layout must be the same on every rank: an engine attaches a mask to a partial column exactly
+    # when the SOURCE column has a validity bitmap (a property of the schema, not of the shard's contents).
+    send_counts = torch.bincount(owner, minlength=world)
+    recv_counts = torch.empty_like(send_counts)
+    dist.all_to_all_single(recv_counts, send_counts, group=group)
+    both = torch.stack([send_counts, recv_counts]).tolist()  # the one host sync of the exchange
+    sc, rc = both[0], both[1]
     pieces, layout = [], []
     for c in cols:
         pieces.append(_as_bytes(c))
@@ -249,7 +274,8 @@ def _to_f64(c: Col):
     return c.t.to(torch.float64)
 
 
-def finalize(keys: list[Col], merged: list[Col], aggs, val_codes: list[int], names: list[str]) -> list[Col]:
+def finalize(keys: list[Col], merged: list[Col], aggs, val_codes: list[int], names: list[str],
+             val_nullable: list[bool] | None = None) -> list[Col]:
     """AggregationExpr::finalize (aggregation.rs:367-483) on the regrouped partials."""
     import torch
 
@@ -274,7 +300,10 @@ def finalize(keys: list[Col], merged: list[Col], aggs, val_codes: list[int], nam
                 num = _to_f64(s)
             valid = n > 0
             v = torch.where(valid, num / torch.where(valid, n, torch.ones_like(n)), torch.zeros_like(n))
-            out.append(Col(name, v.to(_torch_dtype(code)), code, None if bool(valid.all()) else valid))
+            # a mean is null only for an all-null group: without a validity bitmap on the source there is none
+            # (and no host sync to find out)
+            nullable = True if val_nullable is None else val_nullable[ci]
+            out.append(Col(name, v.to(_torch_dtype(code)), code, valid if nullable else None))
         else:
             c = next(it)
             out.append(Col(name, c.t, c.code, c.mask))
@@ -282,7 +311,7 @@ def finalize(keys: list[Col], merged: list[Col], aggs, val_codes: list[int], nam
 
 
 def group_by_agg_sharded(keys: list[Column], vals: list[Column], aggs, *, device=None, engine=None, group=None,
-                         names: list[str] | None = None, n_groups_hint: int = 0):
+                         names: list[str] | None = None, n_groups_hint: int = 0, force_exchange: bool = False):
     """`keys` / `vals` are this rank's row shard; `aggs` = [(value index, 'sum'|'mean'|'min'|'max'|'count')].
     Returns this rank's share of the result frame (list[Col]: keys then one column per aggregation); the
     shares of all ranks are disjoint in the keys and together are the result."""
@@ -295,11 +324,11 @@ def group_by_agg_sharded(keys: list[Column], vals: list[Column], aggs, *, device
     part = engine.partial(keys, vals, aggs, n_groups_hint) if isinstance(engine, HipEngine) else engine.partial(keys, vals, aggs)
     nk = len(keys)
     pk, pv = part[:nk], part[nk:]
-    if world > 1:
+    if world > 1 or (force_exchange and dist.is_initialized()):  # force_exchange: rehearse the collective on one rank
         h = engine.key_hashes(pk)
         owner = ((h >> 33) & 0x7FFFFFFF) % world
         moved = exchange_by_owner(pk + pv, owner, world, group)
         pk, pv = moved[:nk], moved[nk:]
         merged = engine.merge(pk, pv, _merge_ops(aggs))
         pk, pv = merged[:nk], merged[nk:]
-    return finalize(pk, pv, aggs, val_codes, names)
+    return finalize(pk, pv, aggs, val_codes, names, [v.validity is not None for v in vals])

@@ -40,7 +40,7 @@ def columns(data, lo, hi):
 class OracleEngine:
     """Stand-in for HipEngine: same partial-frame layout, computed by the CPU oracle."""
 
-    def _col(self, name, arr, valid=None):
+    def _col(self, name, arr, valid=None, nullable=None):
         import torch
 
         from polars_amd import _ffi
@@ -49,7 +49,10 @@ class OracleEngine:
         code = _ffi.np_dtype_code(arr.dtype)
         view = {np.dtype(np.uint32): np.int32, np.dtype(np.uint64): np.int64, np.dtype(np.uint16): np.int16}.get(arr.dtype)
         t = torch.from_numpy(np.ascontiguousarray(arr.view(view) if view else arr))
-        mask = None if valid is None or valid.all() else torch.from_numpy(valid.copy())
+        # a mask goes with the column exactly when the source is nullable (schema property, same on all ranks)
+        if nullable is None:
+            nullable = valid is not None and not valid.all()
+        mask = torch.from_numpy((valid if valid is not None else np.ones(len(arr), bool)).copy()) if nullable else None
         return Col(name, t, code, mask)
 
     def _np_column(self, c):
@@ -67,7 +70,7 @@ class OracleEngine:
         out = []
         for kc in keys:
             v, m = orc.take_keys(kc, g)
-            out.append(self._col(kc.name, v, m))
+            out.append(self._col(kc.name, v, m, nullable=kc.validity is not None))
         for i, (ci, kind) in enumerate(aggs):
             src = vals[ci]
             a = src.to_numpy()
@@ -85,7 +88,7 @@ class OracleEngine:
                 out.append(self._col(f"a{i}_count", v.astype(np.uint64)))
             else:
                 v, ok = orc.agg(src, kind, g)
-                out.append(self._col(f"a{i}_{kind}", v, ok))
+                out.append(self._col(f"a{i}_{kind}", v, ok, nullable=src.validity is not None))
         return out
 
     def key_hashes(self, keys):
@@ -104,7 +107,7 @@ class OracleEngine:
         kc, pc = [self._np_column(k) for k in keys], [self._np_column(p) for p in parts]
         out, _ = orc.group_by_agg(kc, pc, [(i, op) for i, op in enumerate(ops)])
         names = [k.name for k in keys] + [p.name for p in parts]
-        return [self._col(nm, v, m) for nm, (_, v, m) in zip(names, out)]
+        return [self._col(nm, v, m, nullable=c.mask is not None) for nm, (_, v, m), c in zip(names, out, list(keys) + list(parts))]
 
 
 def _worker(rank, world, port, n, seed, outdir):

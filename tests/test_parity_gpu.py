@@ -429,3 +429,86 @@ def test_sharded_engine_two_shards_one_gpu(oracle):
     vals = [Column("v0", v0), Column("v1", v1, v1m), Column("v2", v2)]
     want, _ = oracle.group_by_agg(keys, vals, aggs)
     util.assert_frames_match(got, util.oracle_to_np(want), 2, what="two shards, one GPU")
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE.json's full sizes: whole-frame parity where the oracle finishes in seconds, size-independent
+# properties (checksum of checksums, counts add up to N, distinct keys) beyond that
+# ---------------------------------------------------------------------------------------------------
+def _bench_frame(workload, n, hint=True):
+    import torch
+
+    import bench
+    from polars_amd import h2oai
+
+    keys_n, vals_n, aggs, wide = bench.WORKLOADS[workload]
+    dev = torch.device("cuda:0")
+    tensors = h2oai.generate(n, seed=108, device=dev, wide=wide, columns=keys_n + vals_n)
+    cols = h2oai.to_columns(tensors, wide)
+    keys, vals = [cols[k] for k in keys_n], [cols[v] for v in vals_n]
+    h = 0
+    if hint and not wide and all(k in ("id1", "id2", "id3") for k in keys_n):
+        h = 1
+        for k in keys_n:
+            h *= 100 if k in ("id1", "id2") else max(n // 100, 1)
+    return tensors, keys, vals, aggs, min(h, n)
+
+
+def _run_raw(keys, vals, aggs, hint):
+    from polars_amd.frame import _host_column
+
+    codes = [(ci, _ffi.AGG_NAMES[k]) for ci, k in aggs]
+    handle, cols = pa.group_by_agg_raw(keys, vals, codes, 0, hint)
+    try:
+        got = [_host_column(str(i), cs) for i, cs in enumerate(cols)]
+    finally:
+        _ffi.lib().plhip_result_free(handle)
+    return [(c.to_numpy(), c.valid_mask() if c.valid_mask() is not None else np.ones(len(c), bool)) for c in got]
+
+
+@pytest.mark.parametrize("workload,expect", [("q1", "direct"), ("q3", "tilesort"), ("q5", "tilesort")])
+@pytest.mark.parametrize("hint", [True, False])
+def test_db_benchmark_full_size_vs_oracle(oracle, workload, expect, hint):
+    n = 10_000_000
+    tensors, keys, vals, aggs, h = _bench_frame(workload, n, hint)
+    got = _run_raw(keys, vals, aggs, h)
+    assert pa.last_strategy() == expect
+    host = {k: v.cpu().numpy() for k, v in tensors.items()}
+    hk = [Column(c.name, host[c.name].view(np.uint32) if c.dtype == _ffi.U32 else host[c.name]) for c in keys]
+    hv = [Column(c.name, host[c.name]) for c in vals]
+    want, _ = oracle.group_by_agg(hk, hv, aggs, n_threads=8)
+    util.assert_frames_match(got, util.oracle_to_np(want), len(keys), what=f"{workload} 1e7 rows")
+
+
+def test_wrong_hints_cost_time_not_correctness(oracle):
+    n = 2_000_000
+    tensors, keys, vals, aggs, _ = _bench_frame("q3", n)
+    host = {k: v.cpu().numpy() for k, v in tensors.items()}
+    want, _ = oracle.group_by_agg([Column("id3", host["id3"].view(np.uint32))], [Column(c.name, host[c.name]) for c in vals], aggs, n_threads=8)
+    for h in (7, 500, n):  # far too low (tables overflow -> the query is redone), low, far too high
+        got = _run_raw(keys, vals, aggs, h)
+        util.assert_frames_match(got, util.oracle_to_np(want), 1, what=f"hint {h} via {pa.last_strategy()}")
+
+
+def test_high_cardinality_properties():
+    """BASELINE config 3 shape at 2e7 rows (three i64 keys, nearly all-unique tuples): properties that do not
+    need a second implementation at this size."""
+    import torch
+
+    n = 20_000_000
+    tensors, keys, vals, aggs, _ = _bench_frame("c3", n)
+    got = _run_raw(keys, vals, aggs, 0)
+    assert pa.last_strategy() == "sort"
+    k1, k2, k3 = (got[i][0] for i in range(3))
+    s1, mn, mx, s3, mean3, cnt = (got[3 + i][0] for i in range(6))
+    assert int(cnt.astype(np.int64).sum()) == n                                        # counts add up to N
+    assert int(s1.sum()) == int(tensors["v1"].sum().item())                            # checksum of integer sums: exact
+    tot3 = float(tensors["v3"].sum().item())
+    assert abs(float(s3.sum()) - tot3) <= 1e-9 * abs(tot3)                             # f64 checksum of sums
+    packed = (tensors["id1"] * 101 + tensors["id2"]) * (n // 100 + 1) + tensors["id3"]  # injective for this data
+    assert len(k1) == int(torch.unique(packed).numel())                                # one row per distinct key tuple
+    gp = (k1.astype(np.int64) * 101 + k2) * (n // 100 + 1) + k3
+    assert len(np.unique(gp)) == len(gp)                                               # and no tuple twice
+    assert (mn <= mx).all() and np.allclose(mean3 * cnt, s3, rtol=1e-12)
+    one = cnt == 1                                                                     # single-row groups: sum = min = max
+    assert (s1[one] == mn[one]).all() and (mn[one] == mx[one]).all()
