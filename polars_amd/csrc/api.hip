@@ -50,6 +50,7 @@ struct Ctx {
   int forced_strategy = -1; // -1: not set by the API (env / auto)
   Scratch table, slots, sortkeys, flags, misc, rank, plans, items, part, dump, hdr, offs;
   float k_ms[3] = {0.f, 0.f, 0.f}; // fast path: tile sort, fold, merge+emit
+  bool flags_clean = false;        // the 64-byte flag block is zero (re-zeroed behind every read, off the next query's critical path)
   uint32_t *host_flags = nullptr; // pinned, 64 bytes
 };
 
@@ -497,6 +498,7 @@ namespace {
 
 int read_flags(TableRef t, uint32_t *out8) {
   Ctx &c = g_ctx;
+  c.flags_clean = false; // whoever reads the flags has used them
   HIP_TRY(hipMemcpyAsync(c.host_flags, t.flags, 32, hipMemcpyDeviceToHost, c.stream));
   HIP_TRY(hipStreamSynchronize(c.stream));
   memcpy(out8, c.host_flags, 32); // the first 8 flags are the ones the host reads
@@ -712,6 +714,7 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
     HIP_TRY(c.table.reserve((size_t)4 << set_bits));
     HIP_TRY(hipMemsetAsync(c.table.p, 0xFF, (size_t)4 << set_bits, c.stream));
     HIP_TRY(hipMemsetAsync(dflags, 0, 64, c.stream));
+    c.flags_clean = false;
     launch_estimate(P, ns, ns == n ? 256 : n / (ns >> 8), (uint32_t *)c.table.p, set_bits, dflags, c.stream);
     HIP_TRY(hipGetLastError());
     TableRef t{nullptr, 0, dflags};
@@ -829,8 +832,8 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
   R->device = c.device;
   OutPlan OP{};
   OP.n_outs = (int)L.outs.size();
-  HIP_TRY(hipEventRecord(c.ev[0], c.stream));
-  HIP_TRY(hipMemsetAsync(dflags, 0, 64, c.stream));
+  if (!c.flags_clean) HIP_TRY(hipMemsetAsync(dflags, 0, 64, c.stream));
+  c.flags_clean = false;
   for (size_t i = 0; i < L.outs.size(); i++) {
     OutSpec o = L.outs[i];
     ResultCol col;
@@ -848,7 +851,7 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
   }
   hipError_t e = hipSuccess;
 
-  // ---- launches --------------------------------------------------------------------------------------------
+  // ---- launches (events: [1] start, [4] tile sort done, [5] fold done, [2] merge done) ------------------------
   hipEventRecord(c.ev[1], c.stream);
   if (direct) {
     bool quad = true;
@@ -857,7 +860,6 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
     for (int v = 0; v < P.n_vals; v++) if (!aligned(P.vals[v].values, dtype_width((int)P.vals[v].dtype))) quad = false;
     FoldRowsArgs A{};
     A.D = D; A.flags = dflags; A.rows_per_item = rows_per_item; A.kxor = kxor; A.lbits = lbits; A.keymode = keymode; A.mbits = mbits;
-    hipEventRecord(c.ev[4], c.stream);
     launch_fold_rows(P, A, key_bytes, quad, n_items, block, c.stream);
     if ((e = hipGetLastError()) != hipSuccess) { delete R; return fail_hip(e, "k_fold_rows launch"); }
     c.strategy = "direct";
@@ -880,24 +882,25 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
   hipEventRecord(c.ev[5], c.stream);
   MergeArgs M{};
   M.D = D; M.flags = dflags; M.out_cap = out_cap; M.lbits = lbits; M.S = S; M.mbits = mbits; M.pshift = direct ? 0u : pbits;
-  if (direct || S > 1) {
+  const bool merged = direct || S > 1;
+  if (merged) {
     launch_merge_emit(P, M, OP, key_bytes, direct ? 1u : n_pg, 1024, c.stream);
     if ((e = hipGetLastError()) != hipSuccess) { delete R; return fail_hip(e, "k_merge_emit launch"); }
+    hipEventRecord(c.ev[2], c.stream);
   }
-  hipEventRecord(c.ev[2], c.stream);
-  hipEventRecord(c.ev[3], c.stream);
   e = hipGetLastError();
   uint32_t fl[16] = {0};
   if (e == hipSuccess) {
     TableRef t{nullptr, 0, dflags};
     int rc = read_flags(t, fl);
     if (rc) { delete R; return rc; }
+    if (hipMemsetAsync(dflags, 0, 64, c.stream) == hipSuccess) c.flags_clean = true; // for the next query
   } else { delete R; return fail_hip(e, "group-by kernels"); }
-  hipEventElapsedTime(&c.total_ms, c.ev[0], c.ev[3]);
-  c.k_ms[0] = 0.f;
+  hipEventElapsedTime(&c.total_ms, c.ev[1], merged ? c.ev[2] : c.ev[5]);
+  c.k_ms[0] = c.k_ms[2] = 0.f;
   if (!direct) hipEventElapsedTime(&c.k_ms[0], c.ev[1], c.ev[4]);
-  hipEventElapsedTime(&c.k_ms[1], c.ev[4], c.ev[5]);
-  hipEventElapsedTime(&c.k_ms[2], c.ev[5], c.ev[2]);
+  hipEventElapsedTime(&c.k_ms[1], direct ? c.ev[1] : c.ev[4], c.ev[5]);
+  if (merged) hipEventElapsedTime(&c.k_ms[2], c.ev[5], c.ev[2]);
   const char *names[3] = {"k_tile_sort", direct ? "k_fold_rows" : "k_fold_runs", "k_merge_emit"};
   int dom = 0;
   for (int i = 1; i < 3; i++) if (c.k_ms[i] > c.k_ms[dom]) dom = i;
@@ -950,6 +953,7 @@ int run_sorted(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, plhip_result
   uint32_t *long_count = (uint32_t *)c.items.p, *long_list = long_count + 64;
   HIP_TRY(hipEventRecord(c.ev[0], c.stream));
   HIP_TRY(hipMemsetAsync(dflags, 0, 64, c.stream));
+  c.flags_clean = false;
   HIP_TRY(hipMemsetAsync(long_count, 0, 256, c.stream));
   HIP_TRY(hipEventRecord(c.ev[1], c.stream));
   HIP_TRY(launch_sort_groups(P, keys_a, keys_b, rows_a, rows_b, fl_d, gid, offsets, c.sortkeys.p, temp_bytes, end_bit, dflags, c.stream));
