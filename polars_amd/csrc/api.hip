@@ -669,6 +669,22 @@ int finish_result(plhip_result *R, uint64_t G, uint32_t flags, plhip_result_t **
   return PLHIP_OK;
 }
 
+// Orders the accumulators by source column (stable) and renumbers the outputs' references.
+void order_accs_by_source(Lowered &L) {
+  Plan &P = L.P;
+  for (int i = 1; i < P.n_accs; i++)
+    for (int j = i; j > 0 && P.accs[j].src < P.accs[j - 1].src; j--) {
+      std::swap(P.accs[j], P.accs[j - 1]);
+      for (auto &o : L.outs) {
+        auto fix = [&](int32_t &x) { if (x == j) x = j - 1; else if (x == j - 1) x = j; };
+        if (o.kind != OUT_KEY) fix(o.acc);
+        fix(o.cnt_valid); fix(o.cnt_all);
+      }
+      if (L.first_acc == j) L.first_acc = j - 1; else if (L.first_acc == j - 1) L.first_acc = j;
+      if (L.KG.first_acc == j) L.KG.first_acc = j - 1; else if (L.KG.first_acc == j - 1) L.KG.first_acc = j;
+    }
+}
+
 int ceil_log2(uint64_t x) { int b = 0; while ((1ull << b) < x) b++; return b; }
 
 // The LDS-only pipeline (fast_path.hip).  Sets `handled` when it produced the result; otherwise the caller
@@ -684,15 +700,7 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
   if ((flags & PLHIP_FLAG_MAINTAIN_ORDER) || L.KG.enabled || L.first_acc >= 0) return PLHIP_OK;
   const bool forced = strategy == PLHIP_STRATEGY_DIRECT || strategy == PLHIP_STRATEGY_TILESORT;
   if (n < 1 || (!forced && n < (1 << 15))) return PLHIP_OK;
-  for (int i = 1; i < P.n_accs; i++) // fold_batch loads a source column once for consecutive accumulators
-    for (int j = i; j > 0 && P.accs[j].src < P.accs[j - 1].src; j--) {
-      std::swap(P.accs[j], P.accs[j - 1]);
-      for (auto &o : L.outs) {
-        auto fix = [&](int32_t &x) { if (x == j) x = j - 1; else if (x == j - 1) x = j; };
-        if (o.kind != OUT_KEY) fix(o.acc);
-        fix(o.cnt_valid); fix(o.cnt_all);
-      }
-    }
+  order_accs_by_source(L); // a source column is fetched once for consecutive accumulators
   const int key_bytes = packed_key_bytes(P, dk);
   int keymode = 0;
   uint64_t kxor = 0;
@@ -921,6 +929,7 @@ int run_sorted(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, plhip_result
   Plan &P = L.P;
   const int64_t n = P.n_rows;
   if ((flags & PLHIP_FLAG_MAINTAIN_ORDER) || n < 1 || P.n_accs > 20) return PLHIP_OK;
+  order_accs_by_source(L);
   int rc;
   if (P.single_key && dk[0].validity) { // nulls become code 0 of a range-compressed key
     std::vector<KeyCol> one(1);

@@ -25,15 +25,6 @@ DEVINL void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" :::
 DEVINL uint32_t al8(uint32_t x) { return (x + 7u) & ~7u; }
 DEVINL uint64_t al16(uint64_t x) { return (x + 15ull) & ~15ull; }
 
-DEVINL uint32_t wbytes(uint32_t dt) {
-  switch (dt) {
-    case PLHIP_I8: case PLHIP_U8: return 1;
-    case PLHIP_I16: case PLHIP_U16: return 2;
-    case PLHIP_I32: case PLHIP_U32: case PLHIP_F32: return 4;
-    default: return 8;
-  }
-}
-
 DEVINL uint32_t cas_key(uint32_t *p, uint32_t expect, uint32_t val) { return atomicCAS(p, expect, val); }
 DEVINL uint64_t cas_key(uint64_t *p, uint64_t expect, uint64_t val) {
   return atomicCAS((unsigned long long *)p, (unsigned long long)expect, (unsigned long long)val);
@@ -81,94 +72,6 @@ DEVINL void ltab_init(const Plan &P, uint8_t *sm, uint32_t lslots) {
     off += al8(lslots * P.accs[a].width);
   }
 }
-
-// raw column bits of B rows, zero-extended.  QUAD: the B == 4 rows are consecutive, row[0] % 4 == 0 and the
-// column base is aligned to 4 elements, so one (two for 8-byte types) vector load fetches them.
-template <int B, bool QUAD>
-DEVINL void load_raw(const uint8_t *vals, uint32_t w, const uint32_t (&row)[B], uint64_t (&raw)[B]) {
-  if (QUAD) { // every group of four rows is one aligned quad: vector loads
-    static_assert(!QUAD || B % 4 == 0, "quads");
-    switch (w) {
-      case 1:
-#pragma unroll
-        for (int g = 0; g < B / 4; g++) {
-          const uint32_t q = *(const uint32_t *)(vals + (size_t)row[4 * g]);
-#pragma unroll
-          for (int b = 0; b < 4; b++) raw[4 * g + b] = (q >> (8 * b)) & 0xFFu;
-        }
-        break;
-      case 2:
-#pragma unroll
-        for (int g = 0; g < B / 4; g++) {
-          const uint2 q = *(const uint2 *)(vals + (size_t)row[4 * g] * 2);
-          raw[4 * g] = q.x & 0xFFFFu; raw[4 * g + 1] = q.x >> 16; raw[4 * g + 2] = q.y & 0xFFFFu; raw[4 * g + 3] = q.y >> 16;
-        }
-        break;
-      case 4:
-#pragma unroll
-        for (int g = 0; g < B / 4; g++) {
-          const uint4 q = *(const uint4 *)(vals + (size_t)row[4 * g] * 4);
-          raw[4 * g] = q.x; raw[4 * g + 1] = q.y; raw[4 * g + 2] = q.z; raw[4 * g + 3] = q.w;
-        }
-        break;
-      default:
-#pragma unroll
-        for (int g = 0; g < B / 4; g++) {
-          const uint4 q0 = *(const uint4 *)(vals + (size_t)row[4 * g] * 8);
-          const uint4 q1 = *(const uint4 *)(vals + (size_t)row[4 * g] * 8 + 16);
-          raw[4 * g] = (uint64_t)q0.x | ((uint64_t)q0.y << 32); raw[4 * g + 1] = (uint64_t)q0.z | ((uint64_t)q0.w << 32);
-          raw[4 * g + 2] = (uint64_t)q1.x | ((uint64_t)q1.y << 32); raw[4 * g + 3] = (uint64_t)q1.z | ((uint64_t)q1.w << 32);
-        }
-        break;
-    }
-    return;
-  }
-  switch (w) {
-#define LD_RAW(T) _Pragma("unroll") for (int b = 0; b < B; b++) raw[b] = (uint64_t)((const T *)vals)[row[b]]; break;
-    case 1: LD_RAW(uint8_t)
-    case 2: LD_RAW(uint16_t)
-    case 4: LD_RAW(uint32_t)
-    default: LD_RAW(uint64_t)
-#undef LD_RAW
-  }
-}
-
-// raw bits -> accumulator operands.  Sign extension is a pair of uniform shifts (0 for unsigned and 64-bit
-// types), so the integer path has no per-dtype branch at all.
-template <int B>
-DEVINL void raw_to_operands(uint32_t dtype, uint32_t conv, const uint64_t (&raw)[B], uint64_t (&opnd)[B]) {
-  const bool sgn = dtype == PLHIP_I8 || dtype == PLHIP_I16 || dtype == PLHIP_I32;
-  const uint32_t sh = sgn ? 64u - 8u * wbytes(dtype) : 0u;
-  int64_t x[B];
-#pragma unroll
-  for (int b = 0; b < B; b++) x[b] = (int64_t)(raw[b] << sh) >> sh;
-  if (conv == CONV_INT) {
-#pragma unroll
-    for (int b = 0; b < B; b++) opnd[b] = (uint64_t)x[b];
-    return;
-  }
-  double d[B];
-  if (dtype == PLHIP_F64) {
-#pragma unroll
-    for (int b = 0; b < B; b++) d[b] = __longlong_as_double((long long)raw[b]);
-  } else if (dtype == PLHIP_F32) {
-#pragma unroll
-    for (int b = 0; b < B; b++) d[b] = (double)__uint_as_float((uint32_t)raw[b]);
-  } else if (dtype == PLHIP_U64) {
-#pragma unroll
-    for (int b = 0; b < B; b++) d[b] = (double)raw[b];
-  } else {
-#pragma unroll
-    for (int b = 0; b < B; b++) d[b] = (double)x[b];
-  }
-#pragma unroll
-  for (int b = 0; b < B; b++) {
-    if (conv == CONV_F64) opnd[b] = (uint64_t)__double_as_longlong(d[b]);
-    else if (conv == CONV_FMIN) opnd[b] = (d[b] != d[b]) ? ~0ull : f64_ordered(d[b]);
-    else opnd[b] = (d[b] != d[b]) ? 0ull : f64_ordered(d[b]);
-  }
-}
-
 
 // ---- query shapes ---------------------------------------------------------------------------------------
 // The fold code is written once against a "shape" (value dtypes + accumulator list).  RtShape reads it from

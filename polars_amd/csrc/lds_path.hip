@@ -13,8 +13,6 @@
 // Everything here is HBM/LDS-bound integer and f64-atomic work; no MFMA.
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
-
 #include "device.hpp"
 #include "kernels.hpp"
 
@@ -208,7 +206,7 @@ DEVINL void raw_operands(uint32_t dtype, uint32_t conv, const uint64_t (&raw)[A2
 template <typename KS>
 __global__ void __launch_bounds__(A2_BLOCK) // 8 waves per SIMD = two 1024-thread workgroups per CU
 k_lds_agg2(Plan P, TableRef T, const WorkItem *__restrict__ items, const uint32_t *__restrict__ n_items_p,
-           uint32_t *next_item, uint32_t lbits, uint64_t dense_cap, uint64_t *slots, uint32_t diag) {
+           uint32_t *next_item, uint32_t lbits, uint64_t dense_cap, uint64_t *slots) {
   __shared__ uint32_t lused[2];
   __shared__ uint32_t loff[PLHIP_MAX_ACCS];
   __shared__ uint32_t sh_item, sh_count, sh_cursor, sh_base;
@@ -260,14 +258,6 @@ k_lds_agg2(Plan P, TableRef T, const WorkItem *__restrict__ items, const uint32_
       uint32_t slot[A2_R];
 #pragma unroll
       for (int r = 0; r < A2_R; r++) { rows[r] = tbase + (int64_t)r * A2_BLOCK + tid; live[r] = (cur.live >> r) & 1; }
-      if (diag & 2) { // DIAG: loads only
-        uint64_t acc = 0;
-#pragma unroll
-        for (int r = 0; r < A2_R; r++) acc += (uint64_t)cur.key[r] + cur.raw[0][r] + cur.raw[1][r] + cur.raw[2][r];
-        if (acc == 0x123456789abcdefull) lused[0] = 1;
-        cur = nxt;
-        continue;
-      }
 #pragma unroll
       for (int r = 0; r < A2_R; r++) {
         slot[r] = 0;
@@ -286,7 +276,7 @@ k_lds_agg2(Plan P, TableRef T, const WorkItem *__restrict__ items, const uint32_
             }
         }
       }
-      for (int a = 0; a < ((diag & 1) ? 0 : P.n_accs); a++) { // DIAG bit 0: probes only
+      for (int a = 0; a < P.n_accs; a++) {
         const AccSpec A = P.accs[a];
         uint8_t *lb = smem2 + loff[a];
         if (A.op == ACC_CNT_ALL) {
@@ -354,7 +344,6 @@ k_lds_agg2(Plan P, TableRef T, const WorkItem *__restrict__ items, const uint32_
     if (spilled) atomicAdd(&T.flags[FLAG_LDS_SPILL], spilled);
     __syncthreads();
 
-    if (diag & 4) continue; // DIAG: no emit
     if (W.direct) {
       // a whole partition: nobody else holds these keys -> dense result area, plain stores
       uint32_t mine = 0;
@@ -447,12 +436,10 @@ void launch_lds_agg2(const Plan &p, TableRef t, const WorkItem *items, const uin
     (void)hipFuncSetAttribute((const void *)k_lds_agg2<uint64_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
     attr_set = true;
   }
-  static int diag = -1;
-  if (diag < 0) { const char *e = getenv("PLHIP_DIAG"); diag = e ? atoi(e) : 0; }
   if (key_bytes == 4)
-    hipLaunchKernelGGL(k_lds_agg2<uint32_t>, dim3(grid), dim3(A2_BLOCK), bytes, s, p, t, items, n_items_dev, next_item_dev, lbits, dense_cap, slots, (uint32_t)diag);
+    hipLaunchKernelGGL(k_lds_agg2<uint32_t>, dim3(grid), dim3(A2_BLOCK), bytes, s, p, t, items, n_items_dev, next_item_dev, lbits, dense_cap, slots);
   else
-    hipLaunchKernelGGL(k_lds_agg2<uint64_t>, dim3(grid), dim3(A2_BLOCK), bytes, s, p, t, items, n_items_dev, next_item_dev, lbits, dense_cap, slots, (uint32_t)diag);
+    hipLaunchKernelGGL(k_lds_agg2<uint64_t>, dim3(grid), dim3(A2_BLOCK), bytes, s, p, t, items, n_items_dev, next_item_dev, lbits, dense_cap, slots);
 }
 
 // ---------------------------------------------------------------------------------------------------------

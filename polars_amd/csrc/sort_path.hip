@@ -96,25 +96,48 @@ __global__ void __launch_bounds__(SP_BLOCK) k_fold_sorted(Plan P, OutPlan O, con
     long_list[atomicAdd(long_count, 1u)] = (uint32_t)g;
     return;
   }
-  for (int a = 0; a < P.n_accs; a++) { // one accumulator at a time: its state stays in registers
-    const AccSpec A = P.accs[a];
-    uint64_t st = A.init;
-    uint32_t i = b;
-    for (; i + 4 <= e; i += 4) { // four gathers in flight; folded in index order (the reference's order)
-      const uint32_t r0 = rows[i], r1 = rows[i + 1], r2 = rows[i + 2], r3 = rows[i + 3];
-      uint64_t o0, o1, o2, o3;
-      const bool v0 = acc_operand(P, A, (int64_t)r0, o0), v1 = acc_operand(P, A, (int64_t)r1, o1);
-      const bool v2 = acc_operand(P, A, (int64_t)r2, o2), v3 = acc_operand(P, A, (int64_t)r3, o3);
-      if (v0) fold_local(A, st, o0);
-      if (v1) fold_local(A, st, o1);
-      if (v2) fold_local(A, st, o2);
-      if (v3) fold_local(A, st, o3);
+  // accumulators are ordered by source column: every value row is gathered ONCE and serves all of them
+  for (int a = 0; a < P.n_accs; a++) sst[a * SP_BLOCK + threadIdx.x] = P.accs[a].init;
+  for (int a0 = 0; a0 < P.n_accs;) {
+    const int src = P.accs[a0].src;
+    int a1 = a0 + 1;
+    while (a1 < P.n_accs && P.accs[a1].src == src) a1++;
+    for (uint32_t i = b; i < e; i += 4) {
+      uint32_t r[4];
+      uint32_t okm = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (i + k < e) okm |= 1u << k;
+        r[k] = rows[i + k < e ? i + k : b];
+      }
+      uint64_t raw[4] = {0, 0, 0, 0};
+      uint32_t dtype = 0;
+      if (src >= 0) {
+        const ValSpec V = P.vals[src];
+        dtype = V.dtype;
+        load_raw<4, false>(V.values, wbytes(V.dtype), r, raw); // four gathers in flight
+        if (V.validity) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) if (!val_valid(V, (int64_t)r[k])) okm &= ~(1u << k);
+        }
+      }
+      for (int a = a0; a < a1; a++) {
+        const AccSpec A = P.accs[a];
+        uint64_t st = sst[a * SP_BLOCK + threadIdx.x];
+        if (A.op == ACC_CNT_ALL || A.op == ACC_CNT_VALID) st += (uint64_t)__popc(okm);
+        else if (A.op == ACC_FIRST_ROW) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) if ((okm >> k) & 1) st = r[k] < st ? r[k] : st;
+        } else {
+          uint64_t opnd[4];
+          raw_to_operands<4>(dtype, A.conv, raw, opnd);
+#pragma unroll
+          for (int k = 0; k < 4; k++) if ((okm >> k) & 1) fold_local(A, st, opnd[k]); // index order: the reference's fold order
+        }
+        sst[a * SP_BLOCK + threadIdx.x] = st;
+      }
     }
-    for (; i < e; i++) {
-      uint64_t operand;
-      if (acc_operand(P, A, (int64_t)rows[i], operand)) fold_local(A, st, operand);
-    }
-    sst[a * SP_BLOCK + threadIdx.x] = st;
+    a0 = a1;
   }
   emit_run(P, O, KG, sst, threadIdx.x, skeys[b], rows[b], g);
 }
