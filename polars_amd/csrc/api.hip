@@ -1019,6 +1019,8 @@ int run_sorted(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, plhip_result
 
 } // namespace
 
+void plhip_internal_set_error(const char *msg) { g_ctx.err = msg ? msg : ""; } // for plugin.hip
+
 // ---------------------------------------------------------------------------------------------------------
 // library entry points
 // ---------------------------------------------------------------------------------------------------------

@@ -12,8 +12,8 @@ from polars_amd import _ffi
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def _declared_symbols():
-    text = (ROOT / "include" / "plhip.h").read_text()
+def _declared_symbols(header="plhip.h"):
+    text = (ROOT / "include" / header).read_text()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(plhip_[a-z0-9_]+)\s*\(", text)))
 
@@ -29,6 +29,15 @@ def test_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in plhip.h but not exported"
     assert sorted(_ffi.EXPORTED_SYMBOLS) == declared
+
+
+def test_exports_the_reference_plugin_symbols():
+    # include/plhip_plugin.h: the FfiPlugin boundary (crates/polars-plan/src/dsl/function_expr/plugin.rs:33-75)
+    lib = _ffi.lib()
+    declared = _declared_symbols("plhip_plugin.h")
+    assert declared == ["plhip_plugin_group_by", "plhip_plugin_group_by_field"]
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in plhip_plugin.h but not exported"
 
 
 def test_abi_version():

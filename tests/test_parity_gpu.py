@@ -512,3 +512,119 @@ def test_high_cardinality_properties():
     assert (mn <= mx).all() and np.allclose(mean3 * cnt, s3, rtol=1e-12)
     one = cnt == 1                                                                     # single-row groups: sum = min = max
     assert (s1[one] == mn[one]).all() and (mn[one] == mx[one]).all()
+
+
+# ---------------------------------------------------------------------------------------------------
+# the reference's FfiPlugin boundary (include/plhip_plugin.h), driven through the Arrow C Data Interface
+# ---------------------------------------------------------------------------------------------------
+import ctypes as C  # noqa: E402
+
+
+class CArrowSchema(C.Structure):
+    _fields_ = [("format", C.c_char_p), ("name", C.c_char_p), ("metadata", C.c_char_p), ("flags", C.c_int64),
+                ("n_children", C.c_int64), ("children", C.c_void_p), ("dictionary", C.c_void_p), ("release", C.c_void_p),
+                ("private_data", C.c_void_p)]
+
+
+class CArrowArray(C.Structure):
+    _fields_ = [("length", C.c_int64), ("null_count", C.c_int64), ("offset", C.c_int64), ("n_buffers", C.c_int64),
+                ("n_children", C.c_int64), ("buffers", C.c_void_p), ("children", C.c_void_p), ("dictionary", C.c_void_p),
+                ("release", C.c_void_p), ("private_data", C.c_void_p)]
+
+
+class CSeriesExport(C.Structure):
+    pass
+
+
+_SERIES_RELEASE = C.CFUNCTYPE(None, C.POINTER(CSeriesExport))
+CSeriesExport._fields_ = [("field", C.POINTER(CArrowSchema)), ("arrays", C.POINTER(C.POINTER(CArrowArray))), ("len", C.c_size_t),
+                          ("release", _SERIES_RELEASE), ("private_data", C.c_void_p)]
+
+
+def _export_series(name, chunks, keep):
+    """export_series (crates/polars-ffi/src/lib.rs:50-68) with pyarrow as the Arrow implementation."""
+    import pyarrow as pa_
+
+    schema = CArrowSchema()
+    pa_.field(name, chunks[0].type)._export_to_c(C.addressof(schema))
+    arrs = [CArrowArray() for _ in chunks]
+    for a, ch in zip(arrs, chunks):
+        ch._export_to_c(C.addressof(a))
+    ptrs = (C.POINTER(CArrowArray) * len(arrs))(*[C.pointer(a) for a in arrs])
+    released = []
+    rel = _SERIES_RELEASE(lambda p: released.append(1))
+    keep += [schema, arrs, ptrs, rel]
+    e = CSeriesExport(C.pointer(schema), C.cast(ptrs, C.POINTER(C.POINTER(CArrowArray))), len(arrs), rel, None)
+    return e, arrs, released
+
+
+@pytest.mark.parametrize("chunked", [False, True])
+def test_ffi_plugin_boundary(oracle, chunked):
+    import pyarrow as pa_
+
+    L = _ffi.lib()
+    L.plhip_plugin_group_by.argtypes = [C.POINTER(CSeriesExport), C.c_size_t]
+    L.plhip_plugin_group_by.restype = CSeriesExport
+    rng = np.random.default_rng(61)
+    n = 50000
+    k = rng.integers(-40, 40, n).astype(np.int32); km = rng.random(n) > 0.05
+    v0 = rng.integers(-100, 100, n).astype(np.int64)
+    v1 = np.round(rng.uniform(0, 100, n), 6); v1m = rng.random(n) > 0.1
+    split = [0, n] if not chunked else [0, 777, 20001, n]
+
+    def chunks(vals, mask=None):
+        out = []
+        for a, b in zip(split[:-1], split[1:]):
+            out.append(pa_.array(vals[a:b], mask=None if mask is None else ~mask[a:b]))
+        return out
+
+    keep = []
+    spec, spec_arrs, spec_rel = _export_series("plhip:k=1;0:sum,1:mean,1:max,0:count", [pa_.array([0], type=pa_.uint32())], keep)
+    ek, k_arrs, k_rel = _export_series("key", chunks(k, km), keep)
+    e0, a0, r0 = _export_series("v0", chunks(v0), keep)
+    e1, a1, r1 = _export_series("v1", chunks(v1, v1m), keep)
+    inputs = (CSeriesExport * 4)(spec, ek, e0, e1)
+    out = L.plhip_plugin_group_by(inputs, 4)
+    # the plugin owns its inputs (plugin.rs:42-48): every array and every series export was released
+    for arrs in (spec_arrs, k_arrs, a0, a1):
+        assert all(not a.release for a in arrs)
+    assert all(len(r) == 1 for r in (spec_rel, k_rel, r0, r1))
+    assert out.len == 1
+    st = pa_.Array._import_from_c(C.addressof(out.arrays[0].contents), C.addressof(out.field.contents))
+    out.release(C.byref(out))  # frees the boxes; the array contents now belong to pyarrow (polars-ffi lib.rs:36-48)
+    assert isinstance(st, pa_.StructArray)
+    assert [f.name for f in st.type] == ["key", "v0_sum", "v1_mean", "v1_max", "count"]
+    assert [str(f.type) for f in st.type] == ["int32", "int64", "double", "double", "uint32"]
+    got = []
+    for i in range(5):
+        col = st.field(i)
+        valid = ~np.asarray(col.is_null())
+        got.append((np.asarray(col.fill_null(0)), valid))
+    want, _ = oracle.group_by_agg([Column("key", k, km)], [Column("v0", v0), Column("v1", v1, v1m)],
+                                  [(0, "sum"), (1, "mean"), (1, "max"), (0, "count")])
+    util.assert_frames_match(got, util.oracle_to_np(want), 1, what="FfiPlugin boundary")
+
+
+def test_ffi_plugin_field_and_errors():
+    import pyarrow as pa_
+
+    L = _ffi.lib()
+    L.plhip_plugin_group_by_field.argtypes = [C.POINTER(CArrowSchema), C.c_size_t]
+    L.plhip_plugin_group_by_field.restype = CArrowSchema
+    fields = (CArrowSchema * 3)()
+    for i, f in enumerate([pa_.field("plhip:k=1;0:mean,0:sum,0:count", pa_.uint32()), pa_.field("id", pa_.uint32()), pa_.field("x", pa_.int16())]):
+        f._export_to_c(C.addressof(fields[i]))
+    out = L.plhip_plugin_group_by_field(fields, 3)
+    t = pa_.Field._import_from_c(C.addressof(out))
+    assert t.name == "group_by" and [(f.name, str(f.type)) for f in t.type] == [("id", "uint32"), ("x_mean", "double"), ("x_sum", "int64"),
+                                                                                ("count", "uint32")]
+    # no error channel at this ABI version: a bad query comes back as a valid, empty struct + plhip_last_error()
+    L.plhip_plugin_group_by.argtypes = [C.POINTER(CSeriesExport), C.c_size_t]
+    L.plhip_plugin_group_by.restype = CSeriesExport
+    keep = []
+    bad, _, _ = _export_series("not a query", [pa_.array([0], type=pa_.uint32())], keep)
+    col, _, _ = _export_series("a", [pa_.array([1, 2, 3], type=pa_.int32())], keep)
+    out = L.plhip_plugin_group_by((CSeriesExport * 2)(bad, col), 2)
+    st = pa_.Array._import_from_c(C.addressof(out.arrays[0].contents), C.addressof(out.field.contents))
+    out.release(C.byref(out))
+    assert len(st) == 0 and b"plhip:k=" in L.plhip_last_error()
