@@ -628,3 +628,30 @@ def test_ffi_plugin_field_and_errors():
     st = pa_.Array._import_from_c(C.addressof(out.arrays[0].contents), C.addressof(out.field.contents))
     out.release(C.byref(out))
     assert len(st) == 0 and b"plhip:k=" in L.plhip_last_error()
+
+
+@pytest.mark.parametrize("pattern", ["sorted", "constant", "two_values", "stride_256", "blocks", "reverse"])
+def test_adversarial_key_patterns_auto(oracle, pattern):
+    """Inputs that defeat sampling or hashing assumptions (sorted keys make a block sample look low-cardinality,
+    strided keys stress the multiplicative hash): AUTO must stay correct through whatever fallbacks it takes."""
+    n = 1_500_000
+    rng = np.random.default_rng(67)
+    if pattern == "sorted":
+        k = np.sort(rng.integers(0, 200_000, n)).astype(np.int64)
+    elif pattern == "reverse":
+        k = np.sort(rng.integers(0, 3_000, n))[::-1].astype(np.int32).copy()
+    elif pattern == "constant":
+        k = np.full(n, -5, dtype=np.int32)
+    elif pattern == "two_values":
+        k = (np.arange(n) % 2).astype(np.uint32) * 0xFFFFFFFF  # 0 and the u32 table sentinel, alternating
+    elif pattern == "stride_256":
+        k = (rng.integers(0, 50_000, n) * 256).astype(np.int64)
+    else:
+        k = (np.arange(n) // 1000).astype(np.int32)  # 1500 groups, each one contiguous block
+    v = rng.integers(-50, 50, n).astype(np.int32)
+    w = np.round(rng.uniform(0, 10, n), 3)
+    keys, vals = [Column("k", k)], [Column("v", v), Column("w", w)]
+    aggs = [(0, "sum"), (1, "mean"), (0, "min"), (1, "max"), (0, "count")]
+    want, _ = oracle.group_by_agg(keys, vals, aggs, n_threads=8)
+    got = run_product(keys, vals, aggs, False, "auto")
+    util.assert_frames_match(util.frame_to_np(got), util.oracle_to_np(want), 1, what=f"{pattern} via {pa.last_strategy()}")
