@@ -52,6 +52,11 @@ struct Ctx {
   float k_ms[3] = {0.f, 0.f, 0.f}; // fast path: tile sort, fold, merge+emit
   bool flags_clean = false;        // the 64-byte flag block is zero (re-zeroed behind every read, off the next query's critical path)
   uint32_t *host_flags = nullptr; // pinned, 64 bytes
+  // fast path: the last kernel publishes the flag block here (pinned, coherent, device-visible) and the host
+  // spins on its first 64-bit word instead of queueing a device-to-host copy and waiting for the stream
+  uint32_t *host_sig = nullptr, *host_sig_dev = nullptr;
+  uint32_t seq = 0;
+  int timing_pending = 0; // 1: direct, 2: tilesort (S == 1), 3: tilesort + merge -- event times not read yet
 };
 
 thread_local Ctx g_ctx;
@@ -69,10 +74,13 @@ int fail_hip(hipError_t e, const char *what) {
     if (_e != hipSuccess) return fail_hip(_e, #expr);  \
   } while (0)
 
+void resolve_timing();
+
 int ensure_ctx() {
   Ctx &c = g_ctx;
   if (c.device >= 0) {
     HIP_TRY(hipSetDevice(c.device));
+    resolve_timing(); // before this call records the events again
     return PLHIP_OK;
   }
   int n = 0;
@@ -86,6 +94,9 @@ int ensure_ctx() {
   HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
   for (auto &ev : c.ev) HIP_TRY(hipEventCreate(&ev));
   HIP_TRY(hipHostMalloc((void **)&c.host_flags, 64, hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void **)&c.host_sig, 64, hipHostMallocMapped | hipHostMallocCoherent));
+  memset(c.host_sig, 0, 64);
+  HIP_TRY(hipHostGetDevicePointer((void **)&c.host_sig_dev, c.host_sig, 0));
   c.device = dev;
   return PLHIP_OK;
 }
@@ -505,6 +516,53 @@ int read_flags(TableRef t, uint32_t *out8) {
   return PLHIP_OK;
 }
 
+// Waits for publish_done (fast_path.hip) of the query tagged `seq`.  The stream is polled now and then so
+// that a failed launch cannot leave the host spinning; if the stream drained without the signal the flags are
+// fetched the ordinary way.
+int wait_signal(TableRef t, uint32_t seq, uint32_t *out8) {
+  Ctx &c = g_ctx;
+  c.flags_clean = false;
+  const uint64_t *sig = (const uint64_t *)c.host_sig;
+  uint64_t v;
+  for (uint64_t spin = 1;; spin++) {
+    if (((v = __atomic_load_n(sig, __ATOMIC_ACQUIRE)) >> 32) == seq) break;
+    if ((spin & 2047) == 0) {
+      const hipError_t q = hipStreamQuery(c.stream);
+      if (q == hipSuccess) {
+        if (((v = __atomic_load_n(sig, __ATOMIC_ACQUIRE)) >> 32) == seq) break;
+        return read_flags(t, out8);
+      }
+      if (q != hipErrorNotReady) return fail_hip(q, "group-by kernels");
+    }
+    __builtin_ia32_pause();
+  }
+  memset(out8, 0, 32);
+  out8[FLAG_OVERFLOW] = (uint32_t)(v >> 31) & 1u;
+  out8[FLAG_NGROUPS] = (uint32_t)v & 0x7FFFFFFFu;
+  // the values are here; the result buffers may be handed on only once the kernel has retired
+  HIP_TRY(hipStreamSynchronize(c.stream));
+  return PLHIP_OK;
+}
+
+// event times of the last fast-path query (read lazily: the host returns before the stream has retired the
+// trailing event records)
+void resolve_timing() {
+  Ctx &c = g_ctx;
+  if (!c.timing_pending) return;
+  const bool direct = c.timing_pending == 1, merged = c.timing_pending != 2;
+  c.timing_pending = 0;
+  if (hipEventSynchronize(merged ? c.ev[2] : c.ev[5]) != hipSuccess) { (void)hipGetLastError(); return; }
+  hipEventElapsedTime(&c.total_ms, c.ev[1], merged ? c.ev[2] : c.ev[5]);
+  c.k_ms[0] = c.k_ms[2] = 0.f;
+  if (!direct) hipEventElapsedTime(&c.k_ms[0], c.ev[1], c.ev[4]);
+  hipEventElapsedTime(&c.k_ms[1], direct ? c.ev[1] : c.ev[4], c.ev[5]);
+  if (merged) hipEventElapsedTime(&c.k_ms[2], c.ev[5], c.ev[2]);
+  const char *names[3] = {"k_tile_sort", direct ? "k_fold_rows" : "k_fold_runs", "k_merge_emit"};
+  int dom = 0;
+  for (int i = 1; i < 3; i++) if (c.k_ms[i] > c.k_ms[dom]) dom = i;
+  c.dom_ms = c.k_ms[dom]; c.dom_kernel = names[dom]; c.part_ms = c.k_ms[0]; c.agg_ms = c.k_ms[1];
+}
+
 int estimate_groups(const Plan &P, uint64_t &g_est) {
   Ctx &c = g_ctx;
   const int64_t n = P.n_rows;
@@ -750,7 +808,10 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
   uint32_t lbits = 0, block = 1024;
   {
     // sparse tables (<= 1/8 full when LDS allows) keep most probes at the home slot
-    uint32_t lb = (uint32_t)std::max(6, ceil_log2(2 * g_est + 2));
+    // densest table accepted: 3/4 full (one pass at 2 500 groups and load 0.61 measured 0.081 ms against 0.136 ms
+    // for the three-pass tile sort, scripts/sweep_groups.py)
+    const uint64_t min_slots = (4 * g_est + 2) / 3 + 2;
+    uint32_t lb = (uint32_t)std::max(6, ceil_log2(min_slots));
     if (lb <= 15 && fast_table_bytes(P, lb, key_bytes) <= LDS_MAX) {
       direct = true;
       while (lb < 15 && (1ull << lb) < 8 * g_est && fast_table_bytes(P, lb + 1, key_bytes) <= 64 * 1024) lb++;
@@ -860,6 +921,8 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
   hipError_t e = hipSuccess;
 
   // ---- launches (events: [1] start, [4] tile sort done, [5] fold done, [2] merge done) ------------------------
+  if (++c.seq == 0) c.seq = 1;
+  const uint32_t seq = c.seq;
   hipEventRecord(c.ev[1], c.stream);
   if (direct) {
     bool quad = true;
@@ -883,6 +946,7 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
     A.pkeys = O.keys; A.out_cap = out_cap;
     A.D = D; A.flags = dflags; A.offs = (const uint32_t *)c.offs.p; A.lbits = lbits; A.np = np; A.w = w; A.n_pg = n_pg;
     A.has_null_pg = has_null_pg; A.S = S; A.n_tiles = n_tiles; A.pbits = pbits;
+    A.host_sig = c.host_sig_dev; A.seq = seq;
     launch_fold_runs(P2, A, OP, key_bytes, block, c.stream);
     if ((e = hipGetLastError()) != hipSuccess) { delete R; return fail_hip(e, "k_fold_runs launch"); }
     c.strategy = "tilesort";
@@ -890,6 +954,7 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
   hipEventRecord(c.ev[5], c.stream);
   MergeArgs M{};
   M.D = D; M.flags = dflags; M.out_cap = out_cap; M.lbits = lbits; M.S = S; M.mbits = mbits; M.pshift = direct ? 0u : pbits;
+  M.host_sig = c.host_sig_dev; M.seq = seq;
   const bool merged = direct || S > 1;
   if (merged) {
     launch_merge_emit(P, M, OP, key_bytes, direct ? 1u : n_pg, 1024, c.stream);
@@ -900,19 +965,11 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
   uint32_t fl[16] = {0};
   if (e == hipSuccess) {
     TableRef t{nullptr, 0, dflags};
-    int rc = read_flags(t, fl);
+    int rc = wait_signal(t, seq, fl);
     if (rc) { delete R; return rc; }
     if (hipMemsetAsync(dflags, 0, 64, c.stream) == hipSuccess) c.flags_clean = true; // for the next query
   } else { delete R; return fail_hip(e, "group-by kernels"); }
-  hipEventElapsedTime(&c.total_ms, c.ev[1], merged ? c.ev[2] : c.ev[5]);
-  c.k_ms[0] = c.k_ms[2] = 0.f;
-  if (!direct) hipEventElapsedTime(&c.k_ms[0], c.ev[1], c.ev[4]);
-  hipEventElapsedTime(&c.k_ms[1], direct ? c.ev[1] : c.ev[4], c.ev[5]);
-  if (merged) hipEventElapsedTime(&c.k_ms[2], c.ev[5], c.ev[2]);
-  const char *names[3] = {"k_tile_sort", direct ? "k_fold_rows" : "k_fold_runs", "k_merge_emit"};
-  int dom = 0;
-  for (int i = 1; i < 3; i++) if (c.k_ms[i] > c.k_ms[dom]) dom = i;
-  c.dom_ms = c.k_ms[dom]; c.dom_kernel = names[dom]; c.part_ms = c.k_ms[0]; c.agg_ms = c.k_ms[1];
+  c.timing_pending = direct ? 1 : (merged ? 3 : 2);
   if (fl[FLAG_OVERFLOW]) { delete R; return PLHIP_OK; } // estimate too low: the general path redoes the query
   const uint64_t G = fl[FLAG_NGROUPS];
   R->n_rows = (int64_t)G;
@@ -1051,6 +1108,7 @@ int32_t plhip_set_strategy(int32_t strategy) {
 const char *plhip_last_strategy(void) { return g_ctx.strategy.c_str(); }
 
 int32_t plhip_last_kernel_ms(float *total_ms, float *dominant_ms, const char **dominant_kernel) {
+  resolve_timing();
   if (total_ms) *total_ms = g_ctx.total_ms;
   if (dominant_ms) *dominant_ms = g_ctx.dom_ms;
   if (dominant_kernel) *dominant_kernel = g_ctx.dom_kernel.c_str();
@@ -1069,6 +1127,7 @@ int32_t plhip_memcpy(void *dst, int32_t dst_location, const void *src, int32_t s
 }
 
 int32_t plhip_last_kernel_breakdown(float *tile_sort_ms, float *fold_ms, float *merge_emit_ms) {
+  resolve_timing();
   if (tile_sort_ms) *tile_sort_ms = g_ctx.k_ms[0];
   if (fold_ms) *fold_ms = g_ctx.k_ms[1];
   if (merge_emit_ms) *merge_emit_ms = g_ctx.k_ms[2];

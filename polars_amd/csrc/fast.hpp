@@ -64,6 +64,9 @@ struct FoldRunsArgs {
   uint32_t S;        // tile segments per group
   uint32_t n_tiles;
   uint32_t pbits; // log2(np): the hash bits the tile sort consumed
+  uint32_t *host_sig; // pinned host memory (device address): the last workgroup stores seq << 32 | overflow << 31 | groups
+  uint32_t seq;       // there, the word the host spins on (nullptr: no signal)
+  uint32_t pad;
 };
 
 struct MergeArgs {
@@ -74,6 +77,9 @@ struct MergeArgs {
   uint32_t S;     // dumps per partition group
   uint32_t mbits; // merge workgroups per partition group = 1 << mbits (split by key hash)
   uint32_t pshift; // hash bits consumed by the tile sort (0 for row-slice dumps)
+  uint32_t *host_sig; // as in FoldRunsArgs
+  uint32_t seq;
+  uint32_t pad;
 };
 
 int fast_shape_id(const Plan &p); // index of the pre-instantiated shape the plan matches, or -1 (run-time shape)

@@ -394,7 +394,7 @@ DEVINL void emit_table(const Plan &P, uint8_t *sm, uint32_t lbits, uint32_t *use
   __syncthreads();
   const uint64_t gbase = e_base;
   if (gbase + n > out_cap) { // the outputs are sized from the table capacities: only after an overflow elsewhere
-    if (threadIdx.x == 0) flags[FLAG_OVERFLOW] = 1;
+    if (threadIdx.x == 0) { flags[FLAG_OVERFLOW] = 1; used[2] = 1; }
     return;
   }
   for (uint32_t k0 = 0; k0 < n; k0 += blockDim.x) { // a wave covers 64 consecutive output rows
@@ -652,6 +652,27 @@ __global__ void __launch_bounds__(TS_BLOCK) k_tile_sort(Plan P, PartOut O, uint3
 // together.  With one segment per group the workgroup writes the output columns itself.
 // ---------------------------------------------------------------------------------------------------------
 #define RUNS_NPRE 3
+// The group count reaches the host without a device-to-host copy: every workgroup of the query's last kernel
+// counts itself done (bit 16 up: "my table overflowed"); the last one writes the flags the host needs into pinned
+// host memory as ONE 64-bit word (seq << 32 | overflow << 31 | groups) that the host is spinning on.  Only atomics carry the values (they
+// execute memory-side, no fence needed); the host still waits for the kernel's end before it hands the result
+// buffers on, so the output stores need no fence here either.
+DEVINL void publish_done(uint32_t *flags, const uint32_t *sh, uint32_t *host_sig, uint32_t seq) {
+  if (!host_sig) return;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t ovf = sh[2] ? 0x10000u : 0u;
+    const uint32_t old = atomicAdd(&flags[FLAG_DONE], 1u + ovf);
+    if ((old & 0xFFFFu) == gridDim.x - 1) {
+      const uint32_t o = (((old + ovf) >> 16) ? 1u : 0u) | atomicAdd(&flags[FLAG_OVERFLOW], 0u); // earlier kernels' too
+      const uint32_t g = atomicAdd(&flags[FLAG_NGROUPS], 0u);
+      // one 64-bit store carries everything: no ordering between host words to arrange
+      __hip_atomic_store((uint64_t *)host_sig, ((uint64_t)seq << 32) | (o ? 0x80000000u : 0u) | (g & 0x7FFFFFFFu), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 template <typename KS, typename SH>
 __global__ void __launch_bounds__(1024) k_fold_runs(Plan P, FoldRunsArgs A, OutPlan O) { // ~3.7 KB of kernel arguments: no plan upload per query
   __shared__ __align__(16) uint32_t sh[8];
@@ -715,8 +736,10 @@ __global__ void __launch_bounds__(1024) k_fold_runs(Plan P, FoldRunsArgs A, OutP
   __syncthreads();
   if (sh[2] && threadIdx.x == 0) A.flags[FLAG_OVERFLOW] = 1;
   uint16_t *list = (uint16_t *)(fsm + table_lds_bytes(P, lslots, sizeof(KS)));
-  if (A.S == 1) emit_table<KS>(P, fsm, A.lbits, sh, bk, list, O, A.flags, A.out_cap);
-  else dump_table<KS>(P, fsm, A.lbits, 0, sh, bk, list, A.D, item);
+  if (A.S == 1) {
+    emit_table<KS>(P, fsm, A.lbits, sh, bk, list, O, A.flags, A.out_cap);
+    publish_done(A.flags, sh, A.host_sig, A.seq);
+  } else dump_table<KS>(P, fsm, A.lbits, 0, sh, bk, list, A.D, item);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -842,6 +865,7 @@ __global__ void __launch_bounds__(1024) k_merge_emit(Plan P, MergeArgs A, OutPla
   if (sh[2] && threadIdx.x == 0) A.flags[FLAG_OVERFLOW] = 1;
   uint16_t *list = (uint16_t *)(fsm + table_lds_bytes(P, lslots, sizeof(KS)));
   emit_table<KS>(P, fsm, A.lbits, sh, bk, list, O, A.flags, A.out_cap);
+  publish_done(A.flags, sh, A.host_sig, A.seq);
 }
 
 // ---------------------------------------------------------------------------------------------------------

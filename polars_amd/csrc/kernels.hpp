@@ -13,6 +13,7 @@
 #define FLAG_NULL 2
 #define FLAG_NGROUPS 3
 #define FLAG_LDS_SPILL 4
+#define FLAG_DONE 5 // workgroups of the last kernel that have finished (fast path: completion signal)
 
 struct TableRef {
   uint8_t *base;   // keys[slots] u64, then the accumulator arrays (AccSpec::offset)
