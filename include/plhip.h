@@ -228,6 +228,53 @@ void plhip_groups_free(plhip_groups_t *g);
 int32_t plhip_agg_groups(const plhip_column_t *values, int32_t kind, const plhip_groups_t *groups,
                          uint32_t flags, plhip_result_t **out);
 
+/* ---- exchange step of the row-sharded group-by (one process per GPU) ---------------------------- */
+
+/* The reference runs the partitioned group-by between THREADS: local group-by with mergeable partials ->
+ * concat of the partial frames -> regroup -> finalize (PartitionGroupByExec::run_partitions / execute,
+ * crates/polars-lazy/src/physical_plan/executors/group_by_partitioned.rs:66-113, 320-360).  Between GPUs the
+ * concat is ONE all-to-all of row records bucketed by the rank that owns each key; these two entry points
+ * are its device side (polars_amd/distributed.py drives them).
+ *
+ * Record of a frame row = for every column its value bytes followed by one validity byte (0/1) if the column
+ * has a bitmap; plhip_result_record_bytes = the record size of `r`. */
+int64_t plhip_result_record_bytes(const plhip_result_t *r);
+
+/* Packs the rows of the device-resident frame `r` (its first n_keys columns are the keys) into `records`
+ * (device memory, num_rows * record_bytes), bucket after bucket by
+ *     owner(row) = ((vec_hash(keys)[row] >> 33) & 0x7FFFFFFF) % n_parts        (plhip_vec_hash, same null_hash)
+ * and returns the rows per owner in counts[n_parts] (host).  Order inside a bucket is unspecified. */
+int32_t plhip_result_pack_by_owner(const plhip_result_t *r, int32_t n_keys, uint64_t null_hash, int32_t n_parts,
+                                   void *records, int64_t *counts);
+
+/* The receiving side: n_rows records (device memory) of the schema dtypes[n_cols] / nullable[n_cols] become a
+ * device-resident frame (free it with plhip_result_free). */
+int32_t plhip_records_to_frame(const void *records, int64_t n_rows, const int32_t *dtypes, const uint8_t *nullable,
+                               int32_t n_cols, plhip_result_t **out);
+
+/* plhip_records_to_frame followed by the regroup of the partials (PartitionGroupByExec::execute,
+ * group_by_partitioned.rs:340-360; AggregationExpr::finalize's per-kind merge, aggregation.rs:367-483: sum of
+ * sums and counts, min of mins, max of maxs): the first n_keys columns are the keys, merge_kinds[n_cols -
+ * n_keys] (PLHIP_AGG_SUM / _MIN / _MAX) says how each partial column merges.  flags / opts as in
+ * plhip_group_by_agg_opts.  One call, no host round trip between the unpacking and the regroup. */
+int32_t plhip_merge_records(const void *records, int64_t n_rows, const int32_t *dtypes, const uint8_t *nullable,
+                            int32_t n_cols, int32_t n_keys, const int32_t *merge_kinds, uint32_t flags,
+                            const plhip_options_t *opts, plhip_result_t **out);
+
+/* AggregationExpr::finalize (crates/polars-lazy/src/physical_plan/expressions/aggregation.rs:367-483) on a
+ * regrouped PARTIAL frame: sum partials wrap into the column's own sum type, counts become IdxSize (u32),
+ * mean = sum / count (f32 sources round through f32 first; count 0 -> null), keys / min / max pass through.
+ * `merged` = n_keys key columns, then per final one partial column (two for MEAN: sum, count).  out_cols[n_keys +
+ * n_finals] are caller-allocated DEVICE buffers of num_rows elements of the final dtype (as plhip_group_by_agg
+ * would produce); `validity` there = a bitmap of (num_rows / 64 + 1) * 8 bytes, required where the merged column
+ * has one, optional for MEAN (NULL: not wanted), ignored elsewhere. */
+typedef struct plhip_final {
+  int32_t kind;      /* plhip_agg_kind_t */
+  int32_t src_dtype; /* dtype of the aggregated source column (ignored for COUNT) */
+} plhip_final_t;
+int32_t plhip_finalize_partial(const plhip_result_t *merged, int32_t n_keys, const plhip_final_t *finals, int32_t n_finals,
+                               const plhip_column_t *out_cols);
+
 #ifdef __cplusplus
 }
 #endif

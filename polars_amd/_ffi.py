@@ -78,6 +78,12 @@ class AggStruct(C.Structure):
     _fields_ = [("column", C.c_int32), ("kind", C.c_int32)]
 
 
+class FinalStruct(C.Structure):
+    """plhip_final_t"""
+
+    _fields_ = [("kind", C.c_int32), ("src_dtype", C.c_int32)]
+
+
 class OptionsStruct(C.Structure):
     """plhip_options_t"""
 
@@ -172,6 +178,16 @@ def lib():
     L.plhip_groups_free.restype = None
     L.plhip_agg_groups.argtypes = [P(ColumnStruct), i32, vp, u32, P(vp)]
     L.plhip_agg_groups.restype = i32
+    L.plhip_result_record_bytes.argtypes = [vp]
+    L.plhip_result_record_bytes.restype = i64
+    L.plhip_result_pack_by_owner.argtypes = [vp, i32, u64, i32, vp, P(i64)]
+    L.plhip_result_pack_by_owner.restype = i32
+    L.plhip_records_to_frame.argtypes = [vp, i64, P(i32), P(C.c_uint8), i32, P(vp)]
+    L.plhip_records_to_frame.restype = i32
+    L.plhip_merge_records.argtypes = [vp, i64, P(i32), P(C.c_uint8), i32, i32, P(i32), u32, P(OptionsStruct), P(vp)]
+    L.plhip_merge_records.restype = i32
+    L.plhip_finalize_partial.argtypes = [vp, i32, P(FinalStruct), i32, P(ColumnStruct)]
+    L.plhip_finalize_partial.restype = i32
     if L.plhip_abi_version() != 1:
         raise OSError("libplhip.so ABI version mismatch")
     _lib = L
@@ -189,5 +205,5 @@ EXPORTED_SYMBOLS = [
     "plhip_last_kernel_ms", "plhip_memcpy", "plhip_last_kernel_breakdown", "plhip_vec_hash", "plhip_group_by_agg", "plhip_group_by_agg_opts", "plhip_result_num_rows",
     "plhip_result_num_columns", "plhip_result_column", "plhip_result_free", "plhip_group_tuples",
     "plhip_groups_num_groups", "plhip_groups_num_rows", "plhip_groups_buffers", "plhip_groups_free",
-    "plhip_agg_groups",
+    "plhip_agg_groups", "plhip_result_record_bytes", "plhip_result_pack_by_owner", "plhip_records_to_frame", "plhip_merge_records", "plhip_finalize_partial",
 ]

@@ -1554,4 +1554,199 @@ int32_t plhip_agg_groups(const plhip_column_t *values, int32_t kind, const plhip
   return finish_result(R, G, flags & PLHIP_FLAG_OUTPUT_DEVICE, out);
 }
 
+// ---- exchange step of the row-sharded group-by (exchange.hip) ----------------------------------------------
+namespace {
+// record layout of a frame: per column the value bytes, then one validity byte if the column has a bitmap
+int rec_layout(RecPlan &R, const int32_t *dtypes, const uint8_t *nullable, int n_cols) {
+  if (n_cols < 1 || n_cols > PLHIP_MAX_OUTS) return fail(PLHIP_ERR_INVALID, "bad column count");
+  uint32_t off = 0;
+  for (int i = 0; i < n_cols; i++) {
+    const int w = dtype_width(dtypes[i]);
+    if (!w) return fail(PLHIP_ERR_UNSUPPORTED_DTYPE, "unsupported dtype code " + std::to_string(dtypes[i]));
+    R.dtype[i] = (uint32_t)dtypes[i]; R.width[i] = (uint32_t)w; R.off[i] = off; R.has_valid[i] = nullable[i] ? 1 : 0;
+    off += (uint32_t)w + (nullable[i] ? 1u : 0u);
+  }
+  R.n_cols = n_cols; R.rec_bytes = off;
+  return PLHIP_OK;
+}
+int frame_layout(RecPlan &R, const plhip_result_t *r) {
+  int32_t dt[PLHIP_MAX_OUTS];
+  uint8_t nu[PLHIP_MAX_OUTS];
+  if (!r || r->cols.size() > PLHIP_MAX_OUTS) return fail(PLHIP_ERR_INVALID, "bad frame");
+  for (size_t i = 0; i < r->cols.size(); i++) { dt[i] = r->cols[i].dtype; nu[i] = r->cols[i].validity ? 1 : 0; }
+  int rc = rec_layout(R, dt, nu, (int)r->cols.size());
+  if (rc) return rc;
+  for (size_t i = 0; i < r->cols.size(); i++) {
+    R.values[i] = (const uint8_t *)r->cols[i].values; R.validity[i] = r->cols[i].validity; R.boff[i] = 0;
+  }
+  R.n_rows = r->n_rows;
+  return PLHIP_OK;
+}
+} // namespace
+
+int64_t plhip_result_record_bytes(const plhip_result_t *r) {
+  RecPlan R{};
+  return frame_layout(R, r) ? -1 : (int64_t)R.rec_bytes;
+}
+
+int32_t plhip_result_pack_by_owner(const plhip_result_t *r, int32_t n_keys, uint64_t null_hash, int32_t n_parts, void *records,
+                                   int64_t *counts) {
+  if (!r || !counts) return fail(PLHIP_ERR_INVALID, "NULL pointer");
+  if (!r->on_device) return fail(PLHIP_ERR_INVALID, "the frame must be device-resident (PLHIP_FLAG_OUTPUT_DEVICE)");
+  if (n_parts < 1 || n_parts > EX_MAX_PARTS) return fail(PLHIP_ERR_INVALID, "owner count out of range");
+  if (n_keys < 1 || n_keys > (int)r->cols.size() || n_keys > PLHIP_MAX_KEYS) return fail(PLHIP_ERR_INVALID, "bad key count");
+  int rc = ensure_ctx();
+  if (rc) return rc;
+  Ctx &c = g_ctx;
+  RecPlan R{};
+  if ((rc = frame_layout(R, r))) return rc;
+  R.n_keys = n_keys; R.n_parts = (uint32_t)n_parts;
+  for (int p = 0; p < n_parts; p++) counts[p] = 0;
+  const int64_t n = r->n_rows;
+  if (n == 0) return PLHIP_OK;
+  if (!records) return fail(PLHIP_ERR_INVALID, "records buffer is NULL");
+  if (n > 0xFFFFFFFFll) return fail(PLHIP_ERR_INVALID, "too many rows for one exchange");
+  // scratch: counts[n_parts] | cursor[n_parts] | owner[n] (u16)
+  const size_t head = (size_t)2 * n_parts * 4;
+  HIP_TRY(c.misc.reserve(head + (size_t)n * 2 + 64));
+  uint32_t *d_counts = (uint32_t *)c.misc.p, *d_cursor = d_counts + n_parts;
+  uint16_t *d_owner = (uint16_t *)((uint8_t *)c.misc.p + head);
+  HIP_TRY(hipMemsetAsync(d_counts, 0, head, c.stream));
+  launch_owner_count(R, null_hash, d_owner, d_counts, c.stream);
+  HIP_TRY(hipGetLastError());
+  launch_pack_records(R, d_owner, d_counts, d_cursor, (uint8_t *)records, c.stream);
+  HIP_TRY(hipGetLastError());
+  std::vector<uint32_t> h(n_parts);
+  HIP_TRY(hipMemcpyAsync(h.data(), d_counts, (size_t)n_parts * 4, hipMemcpyDeviceToHost, c.stream));
+  HIP_TRY(hipStreamSynchronize(c.stream));
+  for (int p = 0; p < n_parts; p++) counts[p] = h[p];
+  return PLHIP_OK;
+}
+
+namespace {
+int records_to_frame_impl(const void *records, int64_t n_rows, const int32_t *dtypes, const uint8_t *nullable, int32_t n_cols, bool sync,
+                          plhip_result **out) {
+  *out = nullptr;
+  if (!dtypes || !nullable || n_rows < 0 || (n_rows > 0 && !records)) return fail(PLHIP_ERR_INVALID, "bad arguments");
+  int rc = ensure_ctx();
+  if (rc) return rc;
+  Ctx &c = g_ctx;
+  RecPlan R{};
+  if ((rc = rec_layout(R, dtypes, nullable, n_cols))) return rc;
+  R.n_rows = n_rows;
+  plhip_result *F = new (std::nothrow) plhip_result();
+  if (!F) return fail(PLHIP_ERR_OOM, "host allocation failed");
+  F->on_device = true; F->device = c.device; F->n_rows = n_rows;
+  for (int i = 0; i < n_cols; i++) {
+    ResultCol col;
+    col.dtype = dtypes[i];
+    hipError_t e = g_pool.get((size_t)std::max<int64_t>(n_rows, 1) * R.width[i], &col.values, &col.vcap);
+    if (e == hipSuccess && nullable[i]) e = g_pool.get((size_t)(n_rows / 64 + 2) * 8, (void **)&col.validity, &col.bcap);
+    F->cols.push_back(col);
+    if (e != hipSuccess) { delete F; return fail_hip(e, "hipMalloc(frame)"); }
+    R.values[i] = (const uint8_t *)col.values; R.validity[i] = col.validity; R.boff[i] = 0;
+  }
+  if (n_rows > 0) {
+    launch_unpack_records(R, (const uint8_t *)records, c.stream);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && sync) e = hipStreamSynchronize(c.stream);
+    if (e != hipSuccess) { delete F; return fail_hip(e, "k_unpack"); }
+  }
+  *out = F;
+  return PLHIP_OK;
+}
+} // namespace
+
+int32_t plhip_records_to_frame(const void *records, int64_t n_rows, const int32_t *dtypes, const uint8_t *nullable, int32_t n_cols,
+                               plhip_result_t **out) {
+  if (!out) return fail(PLHIP_ERR_INVALID, "out is NULL");
+  return records_to_frame_impl(records, n_rows, dtypes, nullable, n_cols, true, out);
+}
+
+int32_t plhip_merge_records(const void *records, int64_t n_rows, const int32_t *dtypes, const uint8_t *nullable, int32_t n_cols,
+                            int32_t n_keys, const int32_t *merge_kinds, uint32_t flags, const plhip_options_t *opts, plhip_result_t **out) {
+  if (!out) return fail(PLHIP_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  if (n_keys < 1 || n_keys > n_cols || !merge_kinds) return fail(PLHIP_ERR_INVALID, "bad key count / merge kinds");
+  plhip_result *F = nullptr;
+  int rc = records_to_frame_impl(records, n_rows, dtypes, nullable, n_cols, false, &F); // same stream: no sync in between
+  if (rc) return rc;
+  std::vector<plhip_column_t> cols(n_cols);
+  for (int i = 0; i < n_cols; i++) {
+    cols[i].values = F->cols[i].values; cols[i].validity = F->cols[i].validity; cols[i].offset = 0; cols[i].length = n_rows;
+    cols[i].dtype = F->cols[i].dtype; cols[i].location = PLHIP_DEVICE;
+  }
+  const int nv = n_cols - n_keys;
+  std::vector<plhip_agg_t> aggs(nv);
+  for (int i = 0; i < nv; i++) {
+    if (merge_kinds[i] != PLHIP_AGG_SUM && merge_kinds[i] != PLHIP_AGG_MIN && merge_kinds[i] != PLHIP_AGG_MAX) {
+      delete F;
+      return fail(PLHIP_ERR_INVALID, "partials merge by sum, min or max");
+    }
+    aggs[i].column = i; aggs[i].kind = merge_kinds[i];
+  }
+  rc = plhip_group_by_agg_opts(cols.data(), n_keys, cols.data() + n_keys, nv, aggs.data(), nv, flags, opts, out);
+  delete F; // the group-by has synchronised the stream
+  return rc;
+}
+
+int32_t plhip_finalize_partial(const plhip_result_t *merged, int32_t n_keys, const plhip_final_t *finals, int32_t n_finals,
+                               const plhip_column_t *out_cols) {
+  if (!merged || !finals || !out_cols) return fail(PLHIP_ERR_INVALID, "NULL pointer");
+  if (!merged->on_device) return fail(PLHIP_ERR_INVALID, "the frame must be device-resident (PLHIP_FLAG_OUTPUT_DEVICE)");
+  if (n_keys < 1 || n_finals < 0 || n_keys + n_finals > PLHIP_MAX_OUTS) return fail(PLHIP_ERR_INVALID, "bad column counts");
+  int rc = ensure_ctx();
+  if (rc) return rc;
+  Ctx &c = g_ctx;
+  const int64_t G = merged->n_rows;
+  FinPlan F{};
+  F.n_rows = G; F.n_outs = n_keys + n_finals;
+  size_t src = 0;
+  auto next_col = [&](const ResultCol *&col) -> bool { if (src >= merged->cols.size()) return false; col = &merged->cols[src++]; return true; };
+  for (int o = 0; o < F.n_outs; o++) {
+    FinOut &X = F.outs[o];
+    const plhip_column_t &out = out_cols[o];
+    if (out.location != PLHIP_DEVICE || out.length != G || out.offset != 0 || (G > 0 && !out.values))
+      return fail(PLHIP_ERR_INVALID, "output columns must be device buffers of the frame's row count");
+    const ResultCol *a = nullptr;
+    if (!next_col(a)) return fail(PLHIP_ERR_SHAPE_MISMATCH, "the frame has fewer columns than the query describes");
+    X.a = (const uint8_t *)a->values; X.a_valid = nullptr; X.cnt = nullptr;
+    X.spec = OutSpec{};
+    X.spec.values = (uint8_t *)out.values; X.spec.validity = (uint8_t *)out.validity; X.spec.acc = -1; X.spec.cnt_valid = 0; X.spec.cnt_all = 0;
+    const int kind = o < n_keys ? -1 : finals[o - n_keys].kind;
+    const int sdt = o < n_keys ? a->dtype : finals[o - n_keys].src_dtype;
+    int want = a->dtype;
+    if (kind == -1 || kind == PLHIP_AGG_MIN || kind == PLHIP_AGG_MAX) {
+      X.mode = FIN_COPY; X.width = (uint32_t)dtype_width(a->dtype); X.a_valid = a->validity;
+      if (a->validity && !out.validity) return fail(PLHIP_ERR_INVALID, "a nullable column needs an output bitmap");
+    } else {
+      X.mode = FIN_VALUE;
+      if (dtype_width(a->dtype) != 8) return fail(PLHIP_ERR_SHAPE_MISMATCH, "partial sums and counts are 64-bit columns");
+      if (kind == PLHIP_AGG_COUNT) { X.spec.kind = OUT_COUNT; want = PLHIP_U32; }
+      else {
+        if (!dtype_width(sdt)) return fail(PLHIP_ERR_UNSUPPORTED_DTYPE, "unsupported source dtype");
+        const bool is_f = dt_is_float(sdt);
+        if (kind == PLHIP_AGG_SUM) {
+          X.spec.kind = is_f ? OUT_SUM_F64 : OUT_SUM_INT;
+          want = is_f ? sdt : (dtype_width(sdt) < 4 ? PLHIP_I64 : sdt);
+        } else if (kind == PLHIP_AGG_MEAN) {
+          X.spec.kind = a->dtype == PLHIP_F64 ? OUT_MEAN_F64 : (a->dtype == PLHIP_I64 ? OUT_MEAN_INT : OUT_MEAN_UINT);
+          want = sdt == PLHIP_F32 ? PLHIP_F32 : PLHIP_F64;
+          const ResultCol *cnt = nullptr;
+          if (!next_col(cnt) || dtype_width(cnt->dtype) != 8) return fail(PLHIP_ERR_SHAPE_MISMATCH, "mean needs a (sum, count) pair of columns");
+          X.cnt = (const uint8_t *)cnt->values;
+        } else return fail(PLHIP_ERR_INVALID, "bad aggregation kind");
+      }
+    }
+    if (out.dtype != want) return fail(PLHIP_ERR_SHAPE_MISMATCH, "output column " + std::to_string(o) + " has the wrong dtype");
+    X.spec.dtype = (uint32_t)want;
+  }
+  if (src != merged->cols.size()) return fail(PLHIP_ERR_SHAPE_MISMATCH, "the frame has more columns than the query describes");
+  if (G == 0) return PLHIP_OK;
+  launch_finalize_partial(F, c.stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c.stream));
+  return PLHIP_OK;
+}
+
 } // extern "C"

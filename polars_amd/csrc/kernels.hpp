@@ -80,3 +80,37 @@ hipError_t launch_sort_groups(const Plan &p, uint64_t *keys_a, uint64_t *keys_b,
                               uint32_t *gid, uint32_t *offsets, void *temp, size_t temp_bytes, int end_bit, uint32_t *dflags, hipStream_t s);
 void launch_fold_sorted(const Plan &p, const OutPlan &o, const KeyGather *kg_dev, const uint64_t *skeys, const uint32_t *rows,
                         const uint32_t *offsets, uint64_t G, uint32_t *long_list, uint32_t *long_count, hipStream_t s);
+
+// exchange step of the row-sharded group-by (exchange.hip): frame <-> row records
+#define EX_MAX_PARTS 1024 // owner ranks
+struct RecPlan {
+  int64_t n_rows;
+  int32_t n_cols, n_keys; // the first n_keys columns are the keys the owner is hashed from
+  uint32_t n_parts, rec_bytes;
+  const uint8_t *values[PLHIP_MAX_OUTS]; // column buffers (written by the unpack kernel)
+  const uint8_t *validity[PLHIP_MAX_OUTS]; // LSB-first bitmaps or nullptr
+  int64_t boff[PLHIP_MAX_OUTS];
+  uint32_t dtype[PLHIP_MAX_OUTS], width[PLHIP_MAX_OUTS];
+  uint32_t off[PLHIP_MAX_OUTS];      // field offset inside a record: value bytes, then one validity byte if has_valid
+  uint8_t has_valid[PLHIP_MAX_OUTS];
+};
+void launch_owner_count(const RecPlan &r, uint64_t null_hash, uint16_t *owner, uint32_t *counts, hipStream_t s);
+void launch_pack_records(const RecPlan &r, const uint16_t *owner, const uint32_t *counts, uint32_t *cursor, uint8_t *records, hipStream_t s);
+void launch_unpack_records(const RecPlan &r, const uint8_t *records, hipStream_t s);
+
+// AggregationExpr::finalize on a regrouped partial frame (exchange.hip)
+#define FIN_COPY 0  // keys, min, max: value and validity bit as they are
+#define FIN_VALUE 1 // sum / count / mean through finalize_value (device.hpp)
+struct FinOut {
+  const uint8_t *a;       // partial column (FIN_VALUE: 8-byte sums / counts)
+  const uint8_t *a_valid; // its bitmap (FIN_COPY) or nullptr
+  const uint8_t *cnt;     // mean: the u64 valid-count column
+  uint32_t mode, width;   // FIN_COPY: element width
+  OutSpec spec;           // FIN_VALUE: kind / dtype / values; both: values, validity (may be nullptr)
+};
+struct FinPlan {
+  int64_t n_rows;
+  int32_t n_outs, pad;
+  FinOut outs[PLHIP_MAX_OUTS];
+};
+void launch_finalize_partial(const FinPlan &f, hipStream_t s);

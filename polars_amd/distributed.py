@@ -171,6 +171,139 @@ class HipEngine:
         return out
 
 
+    # ---- the exchange with the bucketing and the unpacking done by the library (exchange.hip) ------------
+    def pack(self, keys, vals, aggs, world: int, hint: int = 0):
+        """Partial pass, then plhip_result_pack_by_owner: returns (records [G x rec] uint8 on the device, bucket
+        after bucket by owner rank; rows per owner as a list)."""
+        import ctypes as C
+
+        import torch
+
+        from .frame import group_by_agg_raw
+
+        L = _ffi.lib()
+        schema = partial_schema(keys, vals, aggs)
+        rec = sum(_ffi.code_np_dtype(code).itemsize + (1 if nullable else 0) for code, nullable in schema)
+        codes = [(ci, _ffi.AGG_NAMES[k]) for ci, k in aggs]
+        self._sync_torch()
+        handle, cols = group_by_agg_raw(keys, vals, codes, _ffi.FLAG_PARTIAL | _ffi.FLAG_OUTPUT_DEVICE, hint)
+        try:
+            g = int(L.plhip_result_num_rows(handle))
+            if g:  # the frame's layout is a property of the schema: every rank computes the same one
+                assert [(cs.dtype, bool(cs.validity)) for cs in cols] == schema, "partial frame does not match the schema"
+                assert L.plhip_result_record_bytes(handle) == rec
+            send = torch.empty((max(g, 1), rec), dtype=torch.uint8, device=self.device)
+            counts = (C.c_int64 * world)()
+            _ffi.check(L.plhip_result_pack_by_owner(handle, len(keys), NULL_HASH, world, send.data_ptr(), counts))
+        finally:
+            L.plhip_result_free(handle)
+        return send[:g], list(counts)
+
+    def merge_records(self, recv, keys, vals, aggs, hint: int = 0, raw: bool = False):
+        """plhip_merge_records on the received records: unpacked into columns and regrouped (sum of sums /
+        counts, min of mins, max of maxs) in one library call; returns the regrouped partial columns (or, with
+        `raw`, the device-resident frame's handle: free it with plhip_result_free)."""
+        import ctypes as C
+
+        L = _ffi.lib()
+        nk = len(keys)
+        schema = partial_schema(keys, vals, aggs)
+        m = int(recv.shape[0])
+        self._sync_torch()
+        dts = (C.c_int32 * len(schema))(*[code for code, _ in schema])
+        nul = (C.c_uint8 * len(schema))(*[1 if nullable else 0 for _, nullable in schema])
+        ops = _merge_ops(aggs)
+        kinds = (C.c_int32 * max(len(ops), 1))(*[_ffi.AGG_NAMES[op] for op in ops])
+        opts = _ffi.OptionsStruct(C.sizeof(_ffi.OptionsStruct), max(min(m, hint) if hint > 0 else m, 1))
+        merged = C.c_void_p()
+        _ffi.check(L.plhip_merge_records(recv.data_ptr() if m else None, m, dts, nul, len(schema), nk, kinds,
+                                         _ffi.FLAG_OUTPUT_DEVICE, C.byref(opts), C.byref(merged)))
+        if raw:
+            return merged
+        mcols = []
+        for i in range(L.plhip_result_num_columns(merged)):
+            cs = _ffi.ColumnStruct()
+            _ffi.check(L.plhip_result_column(merged, i, C.byref(cs)))
+            mcols.append(cs)
+        names = [k.name for k in keys] + [f"p{i}" for i in range(len(schema) - nk)]
+        return self._frame(merged, mcols, names)
+
+    def finalize_frame(self, merged, keys, vals, aggs, names) -> list[Col]:
+        """plhip_finalize_partial: the regrouped partial frame `merged` (handle; freed here) becomes the final
+        columns, written by one kernel straight into torch-allocated tensors."""
+        import ctypes as C
+
+        import torch
+
+        L = _ffi.lib()
+        try:
+            g = int(L.plhip_result_num_rows(merged))
+            spec = [(k.name, k.dtype, k.validity is not None) for k in keys]
+            finals = []
+            for (ci, kind), name in zip(aggs, names):
+                src = vals[ci].dtype if kind != "count" else _ffi.U32
+                nullable = kind in ("mean", "min", "max") and vals[ci].validity is not None
+                code = {"sum": sum_out_code(src), "count": _ffi.U32, "mean": mean_out_code(src)}.get(kind, src)
+                spec.append((name, code, nullable))
+                finals.append(_ffi.FinalStruct(_ffi.AGG_NAMES[kind], src))
+            out, structs, bitmaps = [], [], []
+            for name, code, nullable in spec:
+                t = torch.empty(max(g, 1), dtype=_torch_dtype(code), device=self.device)[:g]
+                bits = torch.empty((g // 64 + 1) * 8, dtype=torch.uint8, device=self.device) if nullable else None
+                structs.append(_ffi.ColumnStruct(t.data_ptr() if g else None, bits.data_ptr() if nullable else None, 0, g, code, _ffi.DEVICE))
+                out.append(Col(name, t, code))
+                bitmaps.append(bits)
+            carr = (_ffi.ColumnStruct * len(structs))(*structs)
+            farr = (_ffi.FinalStruct * max(len(finals), 1))(*finals)
+            _ffi.check(L.plhip_finalize_partial(merged, len(keys), farr, len(finals), carr))
+        finally:
+            L.plhip_result_free(merged)
+        for c, bits in zip(out, bitmaps):
+            if bits is not None:
+                c.mask = _unpack_bits(bits, g)
+        return out
+
+    def sharded(self, keys, vals, aggs, world: int, group, hint: int, names) -> list[Col]:
+        """pack -> counts + ONE all_to_all_single -> merge_records -> finalize_frame.  torch only allocates the
+        buffers and runs the two collectives."""
+        import torch
+        import torch.distributed as dist
+
+        send, sc = self.pack(keys, vals, aggs, world, hint)
+        send_counts = torch.tensor(sc, dtype=torch.int64, device=self.device)
+        recv_counts = torch.empty_like(send_counts)
+        dist.all_to_all_single(recv_counts, send_counts, group=group)
+        rc = recv_counts.tolist()  # the one host sync of the exchange
+        m = sum(rc)
+        rec = send.shape[1]
+        recv = torch.empty((max(m, 1), rec), dtype=torch.uint8, device=self.device)[:m]
+        dist.all_to_all_single(recv, send, output_split_sizes=rc, input_split_sizes=sc, group=group)
+        return self.finalize_frame(self.merge_records(recv, keys, vals, aggs, hint, raw=True), keys, vals, aggs, names)
+
+
+def partial_schema(keys, vals, aggs) -> list[tuple[int, bool]]:
+    """(dtype code, has a validity bitmap) of every column of a PLHIP_FLAG_PARTIAL frame (api.hip build_aggs):
+    determined by the query's schema alone, hence identical on every rank whatever its shard holds."""
+    signed = (_ffi.I8, _ffi.I16, _ffi.I32, _ffi.I64)
+    out = [(k.dtype, k.validity is not None) for k in keys]
+    for ci, kind in aggs:
+        if kind == "count":
+            out.append((_ffi.U64, False))
+            continue
+        src = vals[ci].dtype
+        w = _ffi.code_np_dtype(src).itemsize
+        is_f = src in (_ffi.F32, _ffi.F64)
+        int_sum = _ffi.I64 if (src in signed or w < 4) else _ffi.U64
+        if kind == "sum":
+            out.append((_ffi.F64 if is_f else int_sum, False))
+        elif kind == "mean":
+            out.append((_ffi.F64 if (is_f or w > 4) else (_ffi.I64 if src in signed else _ffi.U64), False))
+            out.append((_ffi.U64, False))
+        else:
+            out.append((src, vals[ci].validity is not None))
+    return out
+
+
 def _hip_memcpy_dtod(dst: int, src: int, nbytes: int) -> None:
     _ffi.check(_ffi.lib().plhip_memcpy(dst, _ffi.DEVICE, src, _ffi.DEVICE, nbytes))
 
@@ -293,17 +426,20 @@ def finalize(keys: list[Col], merged: list[Col], aggs, val_codes: list[int], nam
         elif kind == "mean":
             s, cnt = next(it), next(it)
             code = mean_out_code(src)
-            n = _to_f64(cnt)
+            n = cnt.t.to(torch.float64)  # a row count: far below 2^63, the int64 view of the u64 column is exact
             if src == _ffi.F32:  # the reference folds f32 in f32 before the division (aggregations/mod.rs:701-742)
                 num = s.t.to(torch.float32).to(torch.float64)
             else:
                 num = _to_f64(s)
-            valid = n > 0
-            v = torch.where(valid, num / torch.where(valid, n, torch.ones_like(n)), torch.zeros_like(n))
             # a mean is null only for an all-null group: without a validity bitmap on the source there is none
-            # (and no host sync to find out)
+            # (and no host sync to find out): every group then has at least one counted row
             nullable = True if val_nullable is None else val_nullable[ci]
-            out.append(Col(name, v.to(_torch_dtype(code)), code, valid if nullable else None))
+            if nullable:
+                valid = n > 0
+                v = torch.where(valid, num / torch.where(valid, n, torch.ones_like(n)), torch.zeros_like(n))
+            else:
+                valid, v = None, num / n
+            out.append(Col(name, v.to(_torch_dtype(code)), code, valid))
         else:
             c = next(it)
             out.append(Col(name, c.t, c.code, c.mask))
@@ -311,7 +447,8 @@ def finalize(keys: list[Col], merged: list[Col], aggs, val_codes: list[int], nam
 
 
 def group_by_agg_sharded(keys: list[Column], vals: list[Column], aggs, *, device=None, engine=None, group=None,
-                         names: list[str] | None = None, n_groups_hint: int = 0, force_exchange: bool = False):
+                         names: list[str] | None = None, n_groups_hint: int = 0, force_exchange: bool = False,
+                         python_exchange: bool = False):
     """`keys` / `vals` are this rank's row shard; `aggs` = [(value index, 'sum'|'mean'|'min'|'max'|'count')].
     Returns this rank's share of the result frame (list[Col]: keys then one column per aggregation); the
     shares of all ranks are disjoint in the keys and together are the result."""
@@ -321,10 +458,13 @@ def group_by_agg_sharded(keys: list[Column], vals: list[Column], aggs, *, device
     engine = engine or HipEngine(device)
     names = names or [f"{vals[ci].name if kind != 'count' else 'count'}_{kind}" for ci, kind in aggs]
     val_codes = [v.dtype for v in vals]
+    exchange = world > 1 or (force_exchange and dist.is_initialized())  # force_exchange: rehearse the collective on one rank
+    if exchange and isinstance(engine, HipEngine) and not python_exchange:
+        return engine.sharded(keys, vals, aggs, world, group, n_groups_hint, names)
     part = engine.partial(keys, vals, aggs, n_groups_hint) if isinstance(engine, HipEngine) else engine.partial(keys, vals, aggs)
     nk = len(keys)
     pk, pv = part[:nk], part[nk:]
-    if world > 1 or (force_exchange and dist.is_initialized()):  # force_exchange: rehearse the collective on one rank
+    if exchange:
         h = engine.key_hashes(pk)
         owner = ((h >> 33) & 0x7FFFFFFF) % world
         moved = exchange_by_owner(pk + pv, owner, world, group)

@@ -431,6 +431,143 @@ def test_sharded_engine_two_shards_one_gpu(oracle):
     util.assert_frames_match(got, util.oracle_to_np(want), 2, what="two shards, one GPU")
 
 
+def _shard_inputs(rng, n):
+    k1 = rng.integers(-30, 30, n).astype(np.int32); k1m = rng.random(n) > 0.05
+    k2 = rng.integers(0, 9, n).astype(np.int64)
+    v0 = rng.integers(-1000, 1000, n).astype(np.int32)
+    v1 = np.round(rng.uniform(0, 100, n), 6); v1m = rng.random(n) > 0.1
+    v2 = rng.integers(0, 50, n).astype(np.uint32)
+    return (k1, k1m, k2), (v0, v1, v1m, v2)
+
+
+def _shard_columns(K, V, lo, hi):
+    k1, k1m, k2 = K
+    v0, v1, v1m, v2 = V
+    return ([Column("k1", k1[lo:hi], k1m[lo:hi]), Column("k2", k2[lo:hi])],
+            [Column("v0", v0[lo:hi]), Column("v1", v1[lo:hi], v1m[lo:hi]), Column("v2", v2[lo:hi])])
+
+
+def test_pack_by_owner_matches_its_definition():
+    """plhip_result_pack_by_owner: counts = rows per owner, every record sits in its owner's bucket
+    (owner = ((vec_hash >> 33) & 0x7FFFFFFF) % world, recomputed here from plhip_vec_hash), and the records are
+    exactly the frame's rows; plhip_records_to_frame gives the columns back."""
+    import ctypes as C
+
+    import torch
+
+    from polars_amd import distributed as pd_
+
+    rng = np.random.default_rng(59)
+    n, world = 50000, 5
+    K, V = _shard_inputs(rng, n)
+    keys, vals = _shard_columns(K, V, 0, n)
+    aggs = [(0, "sum"), (1, "mean"), (0, "min"), (1, "max"), (0, "count")]
+    eng = pd_.HipEngine(torch.device("cuda:0"))
+    part = eng.partial(keys, vals, aggs)  # the frame as tensors (python path)
+    owner = (((eng.key_hashes(part[:2]) >> 33) & 0x7FFFFFFF) % world).cpu().numpy()
+    send, counts = eng.pack(keys, vals, aggs, world)
+    g = part[0].t.numel()
+    assert send.shape[0] == g and sum(counts) == g
+    assert counts == np.bincount(owner, minlength=world).tolist()
+    schema = pd_.partial_schema(keys, vals, aggs)
+    # decode the records on the host
+    rec = send.cpu().numpy()
+    off, cols = 0, []
+    for code, nullable in schema:
+        w = _ffi.code_np_dtype(code).itemsize
+        v = np.ascontiguousarray(rec[:, off:off + w]).view(_ffi.code_np_dtype(code)).reshape(-1)
+        off += w
+        m = None
+        if nullable:
+            m = rec[:, off].astype(bool); off += 1
+        cols.append((v, m))
+    assert off == rec.shape[1]
+
+    def by_key(cols_vm):  # rows ordered by the (unique) key tuple; null slots zeroed
+        out = []
+        for v, m in cols_vm:
+            out.append(v if m is None else np.where(m, v, np.zeros_like(v)))
+            if m is not None:
+                out.append(m)
+        order = np.lexsort((out[2], out[0], out[1]))  # k1 mask, k1, k2
+        return [c[order] for c in out]
+
+    want = [(c.t.cpu().numpy().view(_ffi.code_np_dtype(c.code)), None if c.mask is None else c.mask.cpu().numpy()) for c in part]
+    for gc, wc in zip(by_key(cols), by_key(want)):  # two runs of the partial pass: f64 sums differ in the last bits
+        if gc.dtype.kind == "f":
+            np.testing.assert_allclose(gc, wc, rtol=1e-12)
+        else:
+            assert np.array_equal(gc, wc)
+    # every bucket holds only rows of its owner: recompute the owner of the packed rows' keys
+    pk = [pd_.Col("k1", torch.from_numpy(cols[0][0].copy()).cuda(), _ffi.I32, torch.from_numpy(cols[0][1].copy()).cuda()),
+          pd_.Col("k2", torch.from_numpy(cols[1][0].copy()).cuda(), _ffi.I64)]
+    o2 = (((eng.key_hashes(pk) >> 33) & 0x7FFFFFFF) % world).cpu().numpy()
+    assert np.array_equal(o2, np.repeat(np.arange(world), counts))
+    # and back to columns
+    frame = C.c_void_p()
+    dts = (C.c_int32 * len(schema))(*[c for c, _ in schema])
+    nul = (C.c_uint8 * len(schema))(*[int(b) for _, b in schema])
+    L = _ffi.lib()
+    _ffi.check(L.plhip_records_to_frame(send.data_ptr(), g, dts, nul, len(schema), C.byref(frame)))
+    cs_list = []
+    for i in range(len(schema)):
+        cs = _ffi.ColumnStruct()
+        _ffi.check(L.plhip_result_column(frame, i, C.byref(cs)))
+        cs_list.append(cs)
+    back = eng._frame(frame, cs_list, [f"c{i}" for i in range(len(schema))])
+    got = [(c.t.cpu().numpy().view(_ffi.code_np_dtype(c.code)), None if c.mask is None else c.mask.cpu().numpy()) for c in back]
+    for (gv, gm), (wv, wm) in zip(got, cols):
+        assert (gm is None) == (wm is None)
+        if gm is not None:
+            assert np.array_equal(gm, wm)
+            assert np.array_equal(gv[gm], wv[wm])
+        else:
+            assert np.array_equal(gv, wv)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_library_exchange_one_gpu(oracle, world):
+    """HipEngine.pack / merge_records (the library-side bucketing and unpacking of the exchange) with the
+    all-to-all replaced by its definition: rank r receives bucket r of every shard.  One shard is empty."""
+    import torch
+
+    from polars_amd import distributed as pd_
+
+    rng = np.random.default_rng(61)
+    n = 60000
+    K, V = _shard_inputs(rng, n)
+    aggs = [(0, "sum"), (1, "mean"), (0, "min"), (1, "max"), (0, "count"), (2, "mean"), (2, "sum")]
+    eng = pd_.HipEngine(torch.device("cuda:0"))
+    bounds = [0] + [n * (r + 1) // (world - 1) for r in range(world - 1)] + [n]  # the last shard is empty
+    packed, shard_cols = [], []
+    for r in range(world):
+        keys, vals = _shard_columns(K, V, bounds[r], bounds[r + 1])
+        shard_cols.append((keys, vals))
+        packed.append(eng.pack(keys, vals, aggs, world))
+    names = ["s", "m", "mn", "mx", "c", "m2", "s2"]
+    outs = []
+    for r in range(world):
+        pieces = []
+        for send, counts in packed:
+            lo = sum(counts[:r])
+            pieces.append(send[lo:lo + counts[r]])
+        recv = torch.cat(pieces).contiguous()
+        keys, vals = shard_cols[r]
+        if r % 2 == 0:  # both finalize routes: torch on the regrouped columns, and the library's kernel
+            merged = eng.merge_records(recv, keys, vals, aggs)
+            outs.append(pd_.finalize(merged[:2], merged[2:], aggs, [_ffi.I32, _ffi.F64, _ffi.U32], names, [False, True, False]))
+        else:
+            outs.append(eng.finalize_frame(eng.merge_records(recv, keys, vals, aggs, raw=True), keys, vals, aggs, names))
+    got = []
+    for j in range(len(outs[0])):
+        v = np.concatenate([o[j].t.cpu().numpy().view(_ffi.code_np_dtype(o[j].code)) for o in outs])
+        m = np.concatenate([(np.ones(o[j].t.numel(), bool) if o[j].mask is None else o[j].mask.cpu().numpy()) for o in outs])
+        got.append((v, m))
+    keys, vals = _shard_columns(K, V, 0, n)
+    want, _ = oracle.group_by_agg(keys, vals, aggs)
+    util.assert_frames_match(got, util.oracle_to_np(want), 2, what=f"library exchange, world {world}")
+
+
 # ---------------------------------------------------------------------------------------------------
 # BASELINE.json's full sizes: whole-frame parity where the oracle finishes in seconds, size-independent
 # properties (checksum of checksums, counts add up to N, distinct keys) beyond that
