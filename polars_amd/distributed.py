@@ -270,14 +270,20 @@ class HipEngine:
         import torch.distributed as dist
 
         send, sc = self.pack(keys, vals, aggs, world, hint)
-        send_counts = torch.tensor(sc, dtype=torch.int64, device=self.device)
+        # RCCL moves device buffers; over gloo (rehearsals of several ranks on one GPU) the records are staged
+        # through host memory
+        staged = dist.get_backend(group) == "gloo"
+        cdev = torch.device("cpu") if staged else self.device
+        send_counts = torch.tensor(sc, dtype=torch.int64, device=cdev)
         recv_counts = torch.empty_like(send_counts)
         dist.all_to_all_single(recv_counts, send_counts, group=group)
         rc = recv_counts.tolist()  # the one host sync of the exchange
         m = sum(rc)
         rec = send.shape[1]
-        recv = torch.empty((max(m, 1), rec), dtype=torch.uint8, device=self.device)[:m]
-        dist.all_to_all_single(recv, send, output_split_sizes=rc, input_split_sizes=sc, group=group)
+        recv = torch.empty((max(m, 1), rec), dtype=torch.uint8, device=cdev)[:m]
+        dist.all_to_all_single(recv, send.cpu() if staged else send, output_split_sizes=rc, input_split_sizes=sc, group=group)
+        if staged:
+            recv = recv.to(self.device)
         return self.finalize_frame(self.merge_records(recv, keys, vals, aggs, hint, raw=True), keys, vals, aggs, names)
 
 
