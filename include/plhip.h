@@ -97,6 +97,15 @@ typedef struct plhip_agg {
                                         two columns (sum, valid count) as in AggregationExpr::
                                         evaluate_partitioned (crates/polars-lazy/src/physical_plan/
                                         expressions/aggregation.rs:283-365) */
+#define PLHIP_FLAG_KEYS_SORTED 8u    /* the (single) key column carries the reference's sorted flag (ascending or
+                                        descending, nulls contiguous at the front or the back): groups are the runs of
+                                        equal consecutive values, in row order, no hashing
+                                        (create_groups_from_sorted, crates/polars-core/src/frame/group_by/
+                                        into_groups.rs:58-127,142-150; partition_to_groups, crates/polars-arrow/src/
+                                        kernels/sort_partition.rs:71-116).  Values compare as values there: every
+                                        NaN is a run of its own and -0.0 == 0.0.  Like the reference, the library
+                                        trusts the flag: unsorted input yields one output row per run.  Ignored
+                                        with more than one key. */
 
 /* strategy override, PLHIP_STRATEGY env var or plhip_set_strategy(): mirrors the reference's
  * POLARS_NO_PARTITION / POLARS_FORCE_PARTITION switches
@@ -123,6 +132,16 @@ typedef struct plhip_options {
                             without a hint the library samples the keys, as estimate_unique_count does
                             (crates/polars-lazy/src/physical_plan/executors/group_by_partitioned.rs:115-157).
                             A wrong hint costs time, never correctness. */
+  /* slice pushdown: GroupByExec carries `slice: Option<(i64, usize)>` and cuts the groups before it aggregates
+     (crates/polars-lazy/src/physical_plan/executors/group_by.rs:79-82, proxy.rs:504-547).  Here the result
+     frame is cut to rows [offset, offset + len) of the group order, negative offsets counting from the end
+     exactly as slice_offsets does (crates/polars-core/src/utils/mod.rs:199-218); the columns then carry an
+     Arrow offset.  Meaningful with PLHIP_FLAG_MAINTAIN_ORDER (otherwise the group order is unspecified, as in
+     the reference). */
+  int64_t slice_offset;
+  uint64_t slice_len;
+  uint32_t has_slice; /* 0: no slice */
+  uint32_t pad;
 } plhip_options_t;
 
 typedef struct plhip_result plhip_result_t; /* opaque: a frame of output columns */

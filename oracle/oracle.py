@@ -139,3 +139,35 @@ def group_by_agg(keys: list[Column], values: list[Column], aggs: list[tuple[int,
         v, m = agg(col, kind, groups, n_threads, partitioned)
         out.append((f"{values[ci].name if col is not None else 'count'}_{kind}", v, m))
     return out, groups
+
+
+def sorted_key_groups(key: Column) -> list[list[int]]:
+    """The sorted-key fast path: GroupsProxy::Slice as [[first, len], ...] in row order.  Restates
+    create_groups_from_sorted (crates/polars-core/src/frame/group_by/into_groups.rs:58-127) over
+    partition_to_groups_amortized (crates/polars-arrow/src/kernels/sort_partition.rs:71-116): the null_count
+    nulls are taken to sit contiguously at the front (if element 0 is null) or at the back and form one group;
+    among the values a new group starts wherever `val != first` (VALUE comparison: every NaN starts a group,
+    -0.0 == 0.0).  The flag is trusted: unsorted input simply yields one group per run."""
+    vals = key.to_numpy()
+    n = len(vals)
+    if n == 0:
+        return []
+    mask = key.valid_mask()
+    null_count = 0 if mask is None else int((~mask).sum())
+    if null_count == n:
+        return [[0, n]]
+    nulls_first = null_count > 0 and not mask[0]
+    v = vals[null_count:] if nulls_first else vals[:n - null_count]
+    out = []
+    if nulls_first:
+        out.append([0, null_count])
+    base = null_count if nulls_first else 0
+    first_idx, first = 0, v[0]
+    for i in range(len(v)):  # the reference's loop, literally
+        if v[i] != first:
+            out.append([base + first_idx, i - first_idx])
+            first_idx, first = i, v[i]
+    out.append([base + first_idx, len(v) - first_idx])
+    if not nulls_first and null_count > 0:
+        out.append([len(v), null_count])
+    return out

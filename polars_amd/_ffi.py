@@ -30,6 +30,7 @@ AGG_NAMES = {"sum": AGG_SUM, "mean": AGG_MEAN, "min": AGG_MIN, "max": AGG_MAX, "
 
 FLAG_MAINTAIN_ORDER = 1
 FLAG_OUTPUT_DEVICE = 2
+FLAG_KEYS_SORTED = 8
 FLAG_PARTIAL = 4
 
 STRATEGIES = {"auto": 0, "global": 1, "lds": 2, "partitioned": 3, "direct": 4, "tilesort": 5, "sort": 6}
@@ -87,7 +88,8 @@ class FinalStruct(C.Structure):
 class OptionsStruct(C.Structure):
     """plhip_options_t"""
 
-    _fields_ = [("struct_size", C.c_uint64), ("n_groups_hint", C.c_int64)]
+    _fields_ = [("struct_size", C.c_uint64), ("n_groups_hint", C.c_int64), ("slice_offset", C.c_int64),
+                ("slice_len", C.c_uint64), ("has_slice", C.c_uint32), ("pad", C.c_uint32)]
 
 
 def np_dtype_code(dt) -> int:

@@ -54,6 +54,7 @@ class Column:
     def __init__(self, name: str, values, validity=None, *, offset: int = 0, length: int | None = None,
                  dtype: int | None = None, packed: bool = False):
         self.name = name
+        self.sorted_flag = None  # 'ascending' | 'descending': see set_sorted
         if _is_torch(values):
             if values.dim() != 1 or not values.is_contiguous():
                 raise _ffi.PlHipError(6, "column buffers must be 1-D and contiguous")
@@ -104,6 +105,13 @@ class Column:
     # ------------------------------------------------------------------
     def __len__(self) -> int:
         return self.length
+
+    def set_sorted(self, descending: bool = False) -> "Column":
+        """Series.set_sorted: declares the column sorted (IsSorted flag, crates/polars-core/src/series/mod.rs); a
+        single group-by key with the flag takes the sorted fast path (into_groups.rs:142-150).  Like the
+        reference, nobody checks the claim."""
+        self.sorted_flag = "descending" if descending else "ascending"
+        return self
 
     def struct(self) -> _ffi.ColumnStruct:
         return _ffi.ColumnStruct(self._ptr, self._vptr, self.offset, self.length, self.dtype, self.location)

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstddef>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -227,6 +228,7 @@ DevPool g_pool;
 struct plhip_result {
   std::vector<ResultCol> cols;
   int64_t n_rows = 0;
+  int64_t row_offset = 0; // a sliced frame (plhip_options_t::slice_*): the columns' Arrow offset
   bool on_device = false;
   int device = 0;
   ~plhip_result() {
@@ -980,15 +982,18 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
 
 // The sort strategy (sort_path.hip): any number of groups, any skew; also serves wide key tuples (output keys
 // gathered at the first row of each run).  Declines stable order (the general path sorts groups by first row).
-int run_sorted(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, plhip_result_t **out, bool &handled) {
+// keys_sorted: the caller declared the single key column sorted (PLHIP_FLAG_KEYS_SORTED): no sort, groups are the
+// runs of equal consecutive values in row order (which is also the stable order).
+int run_sorted(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, plhip_result_t **out, bool &handled, bool keys_sorted = false) {
   handled = false;
   Ctx &c = g_ctx;
   Plan &P = L.P;
   const int64_t n = P.n_rows;
-  if ((flags & PLHIP_FLAG_MAINTAIN_ORDER) || n < 1 || P.n_accs > 20) return PLHIP_OK;
+  if (n < 1 || P.n_accs > 20 || n > 0xFFFFFFFEll) return PLHIP_OK;
+  if (keys_sorted ? !P.single_key : (flags & PLHIP_FLAG_MAINTAIN_ORDER) != 0) return PLHIP_OK;
   order_accs_by_source(L);
   int rc;
-  if (P.single_key && dk[0].validity) { // nulls become code 0 of a range-compressed key
+  if (!keys_sorted && P.single_key && dk[0].validity) { // nulls become code 0 of a range-compressed key
     std::vector<KeyCol> one(1);
     one[0].col = dk[0]; one[0].nullable = true;
     if ((rc = measure_key_columns(one, n))) return rc;
@@ -1003,7 +1008,7 @@ int run_sorted(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, plhip_result
   size_t temp_bytes = 0;
   HIP_TRY(sort_path_temp_bytes((uint64_t)n, end_bit, &temp_bytes));
   const size_t n8 = ((size_t)n * 8 + 255) & ~(size_t)255, n4 = ((size_t)n * 4 + 255) & ~(size_t)255;
-  HIP_TRY(c.table.reserve(2 * n8));
+  if (!keys_sorted) HIP_TRY(c.table.reserve(2 * n8));
   HIP_TRY(c.slots.reserve(2 * n4));
   HIP_TRY(c.part.reserve(2 * n4));
   HIP_TRY(c.rank.reserve(n4 + 256));
@@ -1022,7 +1027,11 @@ int run_sorted(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, plhip_result
   c.flags_clean = false;
   HIP_TRY(hipMemsetAsync(long_count, 0, 256, c.stream));
   HIP_TRY(hipEventRecord(c.ev[1], c.stream));
-  HIP_TRY(launch_sort_groups(P, keys_a, keys_b, rows_a, rows_b, fl_d, gid, offsets, c.sortkeys.p, temp_bytes, end_bit, dflags, c.stream));
+  if (keys_sorted) {
+    keys_b = nullptr; // output keys are gathered from the key column at each run's first row
+    HIP_TRY(launch_sorted_key_groups(P.keys[0], (uint64_t)n, rows_b, fl_d, gid, offsets, c.sortkeys.p, temp_bytes, dflags, c.stream));
+  } else
+    HIP_TRY(launch_sort_groups(P, keys_a, keys_b, rows_a, rows_b, fl_d, gid, offsets, c.sortkeys.p, temp_bytes, end_bit, dflags, c.stream));
   HIP_TRY(hipEventRecord(c.ev[4], c.stream));
   uint32_t fl[16];
   TableRef t{nullptr, 0, dflags};
@@ -1050,8 +1059,10 @@ int run_sorted(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, plhip_result
   }
   const KeyGather *kg_dev = nullptr;
   hipError_t e = hipSuccess;
-  if (L.KG.enabled) {
-    e = hipMemcpyAsync(c.plans.p, &L.KG, sizeof(KeyGather), hipMemcpyHostToDevice, c.stream);
+  KeyGather KGh = L.KG; // (the async copy below reads it until the stream is synchronised at the end of this function)
+  if (keys_sorted) KGh.enabled = 1;
+  if (KGh.enabled) {
+    e = hipMemcpyAsync(c.plans.p, &KGh, sizeof(KeyGather), hipMemcpyHostToDevice, c.stream);
     kg_dev = (const KeyGather *)c.plans.p;
   }
   if (e == hipSuccess) {
@@ -1068,8 +1079,8 @@ int run_sorted(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, plhip_result
   hipEventElapsedTime(&c.k_ms[1], c.ev[4], c.ev[5]);
   c.part_ms = c.k_ms[0]; c.agg_ms = c.k_ms[1];
   c.dom_ms = std::max(c.k_ms[0], c.k_ms[1]);
-  c.dom_kernel = c.k_ms[0] >= c.k_ms[1] ? "k_pack_rows+rocprim radix sort+run scan" : "k_fold_sorted";
-  c.strategy = "sort";
+  c.dom_kernel = c.k_ms[0] >= c.k_ms[1] ? (keys_sorted ? "k_sorted_run_flags+run scan" : "k_pack_rows+rocprim radix sort+run scan") : "k_fold_sorted";
+  c.strategy = keys_sorted ? "sorted_keys" : "sort";
   handled = true;
   return finish_result(R, G, flags, out);
 }
@@ -1166,6 +1177,9 @@ int32_t plhip_vec_hash(const plhip_column_t *keys, int32_t n_keys, uint64_t null
   return PLHIP_OK;
 }
 
+int32_t group_by_agg_impl(const plhip_column_t *keys, int32_t n_keys, const plhip_column_t *values, int32_t n_values,
+                          const plhip_agg_t *aggs, int32_t n_aggs, uint32_t flags, const plhip_options_t *opts, plhip_result_t **out);
+
 int32_t plhip_group_by_agg(const plhip_column_t *keys, int32_t n_keys, const plhip_column_t *values,
                            int32_t n_values, const plhip_agg_t *aggs, int32_t n_aggs, uint32_t flags,
                            plhip_result_t **out) {
@@ -1175,6 +1189,27 @@ int32_t plhip_group_by_agg(const plhip_column_t *keys, int32_t n_keys, const plh
 int32_t plhip_group_by_agg_opts(const plhip_column_t *keys, int32_t n_keys, const plhip_column_t *values,
                                 int32_t n_values, const plhip_agg_t *aggs, int32_t n_aggs, uint32_t flags,
                                 const plhip_options_t *opts, plhip_result_t **out) {
+  const int rc = group_by_agg_impl(keys, n_keys, values, n_values, aggs, n_aggs, flags, opts, out);
+  // slice pushdown (GroupByExec's `slice`, executors/group_by.rs:79-82; offsets as slice_offsets, utils/mod.rs:199-218)
+  if (!rc && out && *out && opts && opts->struct_size >= offsetof(plhip_options_t, has_slice) + sizeof(uint32_t) && opts->has_slice) {
+    plhip_result *R = *out;
+    const uint64_t len = (uint64_t)R->n_rows, want = opts->slice_len;
+    const int64_t off = opts->slice_offset;
+    const uint64_t a = off < 0 ? (uint64_t)(-(off + 1)) + 1 : (uint64_t)off; // |off| without overflow
+    uint64_t start, count;
+    if (off < 0) {
+      if (a <= len) { start = len - a; count = std::min(want, a); } else { start = 0; count = std::min(want, len); }
+    } else if (a <= len) { start = a; count = std::min(want, len - a); }
+    else { start = len; count = 0; }
+    R->row_offset = (int64_t)start;
+    R->n_rows = (int64_t)count;
+  }
+  return rc;
+}
+
+int32_t group_by_agg_impl(const plhip_column_t *keys, int32_t n_keys, const plhip_column_t *values,
+                          int32_t n_values, const plhip_agg_t *aggs, int32_t n_aggs, uint32_t flags,
+                          const plhip_options_t *opts, plhip_result_t **out) {
   if (!out) return fail(PLHIP_ERR_INVALID, "out is NULL");
   *out = nullptr;
   // group_by/mod.rs:59-62
@@ -1208,9 +1243,14 @@ int32_t plhip_group_by_agg_opts(const plhip_column_t *keys, int32_t n_keys, cons
 
   // ---- strategy ------------------------------------------------------------------------------------
   int strategy = c.forced_strategy > 0 ? c.forced_strategy : env_strategy();
+  if ((flags & PLHIP_FLAG_KEYS_SORTED) && n_keys == 1 && n > 0) { // into_groups.rs:142-150: the flag wins over every hash path
+    bool handled = false;
+    if ((rc = run_sorted(L, dk, flags, out, handled, true))) return rc;
+    if (handled) return PLHIP_OK;
+  }
   if (strategy == PLHIP_STRATEGY_AUTO || strategy == PLHIP_STRATEGY_DIRECT || strategy == PLHIP_STRATEGY_TILESORT) {
     int64_t hint = 0;
-    if (opts && opts->struct_size >= sizeof(plhip_options_t)) hint = opts->n_groups_hint;
+    if (opts && opts->struct_size >= offsetof(plhip_options_t, n_groups_hint) + sizeof(int64_t)) hint = opts->n_groups_hint;
     bool handled = false;
     uint64_t g_seen = 0;
     if ((rc = run_fast(L, dk, flags, hint, strategy, out, handled, g_seen))) return rc;
@@ -1375,7 +1415,7 @@ int32_t plhip_result_column(const plhip_result_t *r, int32_t i, plhip_column_t *
   if (!r || !col || i < 0 || i >= (int32_t)r->cols.size()) return fail(PLHIP_ERR_INVALID, "bad result column index");
   col->values = r->cols[i].values;
   col->validity = r->cols[i].validity;
-  col->offset = 0;
+  col->offset = r->row_offset;
   col->length = r->n_rows;
   col->dtype = r->cols[i].dtype;
   col->location = r->on_device ? PLHIP_DEVICE : PLHIP_HOST;
@@ -1573,6 +1613,7 @@ int frame_layout(RecPlan &R, const plhip_result_t *r) {
   int32_t dt[PLHIP_MAX_OUTS];
   uint8_t nu[PLHIP_MAX_OUTS];
   if (!r || r->cols.size() > PLHIP_MAX_OUTS) return fail(PLHIP_ERR_INVALID, "bad frame");
+  if (r->row_offset) return fail(PLHIP_ERR_INVALID, "a sliced frame cannot enter the exchange");
   for (size_t i = 0; i < r->cols.size(); i++) { dt[i] = r->cols[i].dtype; nu[i] = r->cols[i].validity ? 1 : 0; }
   int rc = rec_layout(R, dt, nu, (int)r->cols.size());
   if (rc) return rc;
@@ -1694,6 +1735,7 @@ int32_t plhip_finalize_partial(const plhip_result_t *merged, int32_t n_keys, con
                                const plhip_column_t *out_cols) {
   if (!merged || !finals || !out_cols) return fail(PLHIP_ERR_INVALID, "NULL pointer");
   if (!merged->on_device) return fail(PLHIP_ERR_INVALID, "the frame must be device-resident (PLHIP_FLAG_OUTPUT_DEVICE)");
+  if (merged->row_offset) return fail(PLHIP_ERR_INVALID, "a sliced frame cannot be finalized");
   if (n_keys < 1 || n_finals < 0 || n_keys + n_finals > PLHIP_MAX_OUTS) return fail(PLHIP_ERR_INVALID, "bad column counts");
   int rc = ensure_ctx();
   if (rc) return rc;

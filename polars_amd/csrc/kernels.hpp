@@ -78,6 +78,8 @@ void launch_agg_groups(const Plan &p, const OutPlan &o, const uint32_t *offsets,
 hipError_t sort_path_temp_bytes(uint64_t n, int end_bit, size_t *bytes);
 hipError_t launch_sort_groups(const Plan &p, uint64_t *keys_a, uint64_t *keys_b, uint32_t *rows_a, uint32_t *rows_b, uint32_t *flags,
                               uint32_t *gid, uint32_t *offsets, void *temp, size_t temp_bytes, int end_bit, uint32_t *dflags, hipStream_t s);
+hipError_t launch_sorted_key_groups(const KeySpec &key, uint64_t n, uint32_t *rows, uint32_t *flags, uint32_t *gid, uint32_t *offsets, void *temp,
+                                    size_t temp_bytes, uint32_t *dflags, hipStream_t s);
 void launch_fold_sorted(const Plan &p, const OutPlan &o, const KeyGather *kg_dev, const uint64_t *skeys, const uint32_t *rows,
                         const uint32_t *offsets, uint64_t G, uint32_t *long_list, uint32_t *long_count, hipStream_t s);
 

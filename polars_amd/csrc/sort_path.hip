@@ -47,6 +47,28 @@ __global__ void __launch_bounds__(256) k_run_offsets(const uint32_t *__restrict_
   if (i == n - 1) { offsets[gid[i]] = (uint32_t)n; dflags[FLAG_NGROUPS] = gid[i]; }
 }
 
+// Sorted-key fast path (create_groups_from_sorted, crates/polars-core/src/frame/group_by/into_groups.rs:58-127;
+// partition_to_groups, crates/polars-arrow/src/kernels/sort_partition.rs:71-116): a group is a maximal run of
+// equal consecutive values, compared as VALUES (`val != first`: every NaN is a run of its own, -0.0 == 0.0), the
+// nulls (contiguous at the front or the back of a sorted column) one run.
+__global__ void __launch_bounds__(256) k_sorted_run_flags(KeySpec K, uint64_t n, uint32_t *__restrict__ flags, uint32_t *__restrict__ rows) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  rows[i] = (uint32_t)i;
+  bool fresh = i == 0;
+  if (!fresh) {
+    const bool va = bit_valid(K.validity, K.boff, (int64_t)i), vb = bit_valid(K.validity, K.boff, (int64_t)i - 1);
+    if (va != vb) fresh = true;
+    else if (va) {
+      const uint64_t a = load_as_u64(K.values, K.dtype, (int64_t)i), b = load_as_u64(K.values, K.dtype, (int64_t)i - 1);
+      if (K.dtype == PLHIP_F32) fresh = __uint_as_float((uint32_t)a) != __uint_as_float((uint32_t)b);
+      else if (K.dtype == PLHIP_F64) fresh = __longlong_as_double((long long)a) != __longlong_as_double((long long)b);
+      else fresh = a != b;
+    }
+  }
+  flags[i] = fresh ? 1u : 0u;
+}
+
 DEVINL void fold_local(const AccSpec &a, uint64_t &state, uint64_t operand) {
   switch (a.op) {
     case ACC_ADD_U64: state += operand; break;
@@ -139,7 +161,7 @@ __global__ void __launch_bounds__(SP_BLOCK) k_fold_sorted(Plan P, OutPlan O, con
     }
     a0 = a1;
   }
-  emit_run(P, O, KG, sst, threadIdx.x, skeys[b], rows[b], g);
+  emit_run(P, O, KG, sst, threadIdx.x, skeys ? skeys[b] : 0ull, rows[b], g);
 }
 
 // one workgroup per long run: lanes stride the index list, partial states are combined in a fixed tree
@@ -170,7 +192,7 @@ __global__ void __launch_bounds__(SP_BLOCK) k_fold_sorted_long(Plan P, OutPlan O
         __syncthreads();
       }
     }
-    if (threadIdx.x == 0) emit_run(P, O, KG, sst, 0, skeys[b], rows[b], g);
+    if (threadIdx.x == 0) emit_run(P, O, KG, sst, 0, skeys ? skeys[b] : 0ull, rows[b], g);
     __syncthreads();
   }
 }
@@ -198,6 +220,16 @@ hipError_t launch_sort_groups(const Plan &p, uint64_t *keys_a, uint64_t *keys_b,
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_run_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, keys_b, n, flags);
   e = rocprim::inclusive_scan(temp, temp_bytes, flags, gid, n, rocprim::plus<uint32_t>(), s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_run_offsets, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, flags, gid, n, offsets, dflags);
+  return hipGetLastError();
+}
+
+// the same without the sort: `key` is a column the caller declares sorted; rows = 0..n-1
+hipError_t launch_sorted_key_groups(const KeySpec &key, uint64_t n, uint32_t *rows, uint32_t *flags, uint32_t *gid, uint32_t *offsets, void *temp,
+                                    size_t temp_bytes, uint32_t *dflags, hipStream_t s) {
+  hipLaunchKernelGGL(k_sorted_run_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, key, n, flags, rows);
+  hipError_t e = rocprim::inclusive_scan(temp, temp_bytes, flags, gid, n, rocprim::plus<uint32_t>(), s);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_run_offsets, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, flags, gid, n, offsets, dflags);
   return hipGetLastError();

@@ -18,7 +18,7 @@ from typing import Iterable, Sequence
 import numpy as np
 
 from . import _ffi
-from .column import Column
+from .column import Column, unpack_validity
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -240,11 +240,25 @@ class LazyGroupBy:
 
 
 class _LazyAgg:
-    def __init__(self, df, by, exprs, mo):
+    def __init__(self, df, by, exprs, mo, slice_=None):
         self._args = (df, by, exprs, mo)
+        self._slice = slice_
+
+    def slice(self, offset: int, length: int | None = None) -> "_LazyAgg":
+        """`.slice()` right after the aggregation: the optimizer pushes it into GroupByExec
+        (crates/polars-lazy/src/physical_plan/executors/group_by.rs:79-82); here into plhip_options_t."""
+        if self._slice is not None:
+            raise _ffi.PlHipError(6, "one slice per query on the accelerated path")
+        return _LazyAgg(*self._args, slice_=(int(offset), (1 << 63) - 1 if length is None else int(length)))
+
+    def head(self, n: int = 5) -> "_LazyAgg":
+        return self.slice(0, n)
+
+    def tail(self, n: int = 5) -> "_LazyAgg":
+        return self.slice(-n, n)
 
     def collect(self) -> DataFrame:
-        return _execute(*self._args)
+        return _execute(*self._args, slice_=self._slice)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -272,7 +286,7 @@ def last_kernel_breakdown() -> tuple[float, float, float]:
 
 
 def group_by_agg_raw(keys: Sequence[Column], values: Sequence[Column], aggs: Sequence[tuple[int, int]],
-                     flags: int = 0, n_groups_hint: int = 0):
+                     flags: int = 0, n_groups_hint: int = 0, slice_: tuple[int, int] | None = None):
     """Thin call of plhip_group_by_agg.  Returns (handle, [ColumnStruct...]); the caller must
     plhip_result_free(handle).  Used by bench.py (device-resident outputs) and by _execute."""
     L = _ffi.lib()
@@ -281,6 +295,8 @@ def group_by_agg_raw(keys: Sequence[Column], values: Sequence[Column], aggs: Seq
     aarr = (_ffi.AggStruct * max(1, len(aggs)))(*[_ffi.AggStruct(c, k) for c, k in aggs])
     handle = C.c_void_p()
     opts = _ffi.OptionsStruct(C.sizeof(_ffi.OptionsStruct), int(n_groups_hint))
+    if slice_ is not None:
+        opts.slice_offset, opts.slice_len, opts.has_slice = int(slice_[0]), int(slice_[1]), 1
     _ffi.check(L.plhip_group_by_agg_opts(karr, len(keys), varr, len(values), aarr, len(aggs), flags, C.byref(opts),
                                          C.byref(handle)))
     cols = []
@@ -292,19 +308,22 @@ def group_by_agg_raw(keys: Sequence[Column], values: Sequence[Column], aggs: Seq
 
 
 def _host_column(name: str, cs: _ffi.ColumnStruct) -> Column:
-    n = cs.length
+    n, off = cs.length, cs.offset  # a sliced frame's columns carry an Arrow offset
     dt = _ffi.code_np_dtype(cs.dtype)
     if n == 0:
         return Column(name, np.empty(0, dtype=dt))
-    vals = np.ctypeslib.as_array(C.cast(cs.values, C.POINTER(C.c_uint8)), shape=(n * dt.itemsize,)).view(dt).copy()
+    vals = np.ctypeslib.as_array(C.cast(cs.values, C.POINTER(C.c_uint8)), shape=((off + n) * dt.itemsize,)).view(dt)[off:].copy()
     validity = None
     if cs.validity:
-        nb = (n + 7) // 8
-        validity = np.ctypeslib.as_array(C.cast(cs.validity, C.POINTER(C.c_uint8)), shape=(nb,)).copy()
-    return Column(name, vals, validity, packed=True)
+        nb = (off + n + 7) // 8
+        bits = np.ctypeslib.as_array(C.cast(cs.validity, C.POINTER(C.c_uint8)), shape=(nb,))
+        validity = unpack_validity(bits, n, off) if off else bits.copy()
+        return Column(name, vals, validity, packed=not off)
+    return Column(name, vals)
 
 
-def _execute(df: DataFrame, by: list[str], exprs: list[Expr], maintain_order: bool, extra_flags: int = 0) -> DataFrame:
+def _execute(df: DataFrame, by: list[str], exprs: list[Expr], maintain_order: bool, extra_flags: int = 0,
+             slice_: tuple[int, int] | None = None) -> DataFrame:
     """group_by_helper (crates/polars-lazy/src/physical_plan/executors/group_by.rs:57-95): keys then aggs."""
     if not by:
         raise _ffi.ComputeError(1, "at least one key is required in a group_by operation")
@@ -328,7 +347,9 @@ def _execute(df: DataFrame, by: list[str], exprs: list[Expr], maintain_order: bo
             raise _ffi.PlHipError(6, f"column with name {e.output_name!r} has more than one occurrence")  # DuplicateError
         names.append(e.output_name)
     flags = (_ffi.FLAG_MAINTAIN_ORDER if maintain_order else 0) | extra_flags
-    handle, cols = group_by_agg_raw(keys, vals, aggs, flags)
+    if len(keys) == 1 and keys[0].sorted_flag is not None:  # IsSorted flag on the key: the sorted fast path
+        flags |= _ffi.FLAG_KEYS_SORTED
+    handle, cols = group_by_agg_raw(keys, vals, aggs, flags, slice_=slice_)
     try:
         out = DataFrame([_host_column(nm, cs) for nm, cs in zip(names, cols)])
     finally:

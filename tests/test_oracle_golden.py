@@ -35,3 +35,38 @@ def test_group_by_known_answers(oracle, case, threads, partitioned):
     cols = [util.to_py(v, m) for _, v, m in out]
     dts = [_ffi.DTYPE_NAMES[_ffi.np_dtype_code(v.dtype)] for _, v, _ in out]
     util.check_known_answer(case, cols, dts)
+
+
+# crates/polars/tests/it/core/group_by.rs:6-96 (test_sorted_group_by) and
+# crates/polars-arrow/src/kernels/sort_partition.rs:143-160 (test_partition_points): [first, len] slices
+SORTED_KEY_CASES = [
+    ([1, 1, 1, 6, 6, None], [[0, 3], [3, 2], [5, 1]]),
+    ([None, None, 1, 1, 1, 6, 6], [[0, 2], [2, 3], [5, 2]]),
+    ([None, None, 3, 3, 1, 1, 1, -1], [[0, 2], [2, 2], [4, 3], [7, 1]]),
+    ([15, 15, 15, 15, 14, 13, 11, 11, 3, 3, 1, 1, 1, -1, None, None, None],
+     [[0, 4], [4, 1], [5, 1], [6, 2], [8, 2], [10, 3], [13, 1], [14, 3]]),
+    ([1, 3, 3, 3, 3, 5, 5, 5, 9, 9, 10], [[0, 1], [1, 4], [5, 3], [8, 2], [10, 1]]),
+    ([None] * 5 + [1, 3, 3, 3, 3, 5, 5, 5, 9, 9, 10], [[0, 5], [5, 1], [6, 4], [10, 3], [13, 2], [15, 1]]),
+    ([1, 3, 3, 3, 3, 5, 5, 5, 9, 9, 10] + [None] * 5, [[0, 1], [1, 4], [5, 3], [8, 2], [10, 1], [11, 5]]),
+]
+
+
+def sorted_case_column(vals):
+    from polars_amd.column import Column
+
+    mask = np.array([v is not None for v in vals])
+    data = np.array([0 if v is None else v for v in vals], dtype=np.int32)
+    return Column("a", data, None if mask.all() else mask)
+
+
+@pytest.mark.parametrize("vals,want", SORTED_KEY_CASES)
+def test_sorted_key_groups_known_answers(oracle, vals, want):
+    assert oracle.sorted_key_groups(sorted_case_column(vals)) == want
+
+
+def test_sorted_key_groups_compare_values_not_bits(oracle):
+    from polars_amd.column import Column
+
+    nan = float("nan")
+    got = oracle.sorted_key_groups(Column("f", np.array([-0.0, 0.0, 1.5, 1.5, nan, nan], dtype=np.float64)))
+    assert got == [[0, 2], [2, 2], [4, 1], [5, 1]]

@@ -431,6 +431,97 @@ def test_sharded_engine_two_shards_one_gpu(oracle):
     util.assert_frames_match(got, util.oracle_to_np(want), 2, what="two shards, one GPU")
 
 
+# ---------------------------------------------------------------------------------------------------
+# sorted-key fast path and slice pushdown (a17)
+# ---------------------------------------------------------------------------------------------------
+def _sorted_frame(key_col, n):
+    v = np.arange(n, dtype=np.int64)
+    return pa.DataFrame({"a": key_col.set_sorted(), "v": Column("v", v)})
+
+
+@pytest.mark.parametrize("vals,want", __import__("tests.test_oracle_golden", fromlist=["x"]).SORTED_KEY_CASES)
+def test_sorted_key_known_answers(vals, want):
+    """crates/polars/tests/it/core/group_by.rs:6-96 + sort_partition.rs:143-160: the [first, len] slices, read back
+    here as (min row, count) per output row, in row order."""
+    from tests.test_oracle_golden import sorted_case_column
+
+    out = _sorted_frame(sorted_case_column(vals), len(vals)).group_by("a").agg(pa.col("v").min().alias("first"), pa.count().alias("len"))
+    assert pa.last_strategy() == "sorted_keys"
+    assert [[f, l] for f, l in zip(out["first"].to_list(), out["len"].to_list())] == want
+    keys = out["a"].to_list()
+    assert keys == [vals[f] for f, _ in want]
+
+
+def test_sorted_key_value_semantics_and_trusted_flag(oracle):
+    nan = float("nan")
+    f = np.array([-0.0, 0.0, 1.5, 1.5, nan, nan], dtype=np.float64)
+    out = _sorted_frame(Column("a", f), len(f)).group_by("a").agg(pa.col("v").min().alias("first"), pa.count().alias("len"))
+    assert [[a, b] for a, b in zip(out["first"].to_list(), out["len"].to_list())] == oracle.sorted_key_groups(Column("a", f))
+    # the flag is trusted: unsorted input yields one row per run, like the reference
+    u = np.array([3, 3, 1, 3, 3, 3, 2], dtype=np.int32)
+    out = _sorted_frame(Column("a", u), len(u)).group_by("a").agg(pa.count().alias("len"))
+    assert out["a"].to_list() == [3, 1, 3, 2] and out["len"].to_list() == [2, 1, 3, 1]
+
+
+@pytest.mark.parametrize("descending", [False, True])
+@pytest.mark.parametrize("nulls", ["none", "first", "last"])
+def test_sorted_key_parity_large(oracle, descending, nulls):
+    """Really sorted keys: the runs are the groups, so the result must equal the stable hash group-by of the
+    oracle, row for row (same order), incl. long runs (the per-workgroup fold) and a run of nulls."""
+    rng = np.random.default_rng(71)
+    n = 300_000
+    k = np.sort(np.concatenate([rng.integers(-5000, 5000, n - 20000), np.full(20000, 77)]).astype(np.int64))
+    if descending:
+        k = k[::-1].copy()
+    mask = None
+    if nulls != "none":
+        mask = np.ones(n, bool)
+        if nulls == "first":
+            mask[:1234] = False
+        else:
+            mask[-1234:] = False
+    v0 = rng.integers(-100, 100, n).astype(np.int32)
+    v1 = np.round(rng.uniform(0, 100, n), 6)
+    v1m = rng.random(n) > 0.1
+    aggs = [(0, "sum"), (1, "mean"), (0, "min"), (1, "max"), (0, "count")]
+    df = pa.DataFrame({"k": Column("k", k, mask).set_sorted(descending), "v0": Column("v0", v0), "v1": Column("v1", v1, v1m)})
+    got = df.group_by("k").agg(pa.col("v0").sum().alias("a0"), pa.col("v1").mean().alias("a1"), pa.col("v0").min().alias("a2"),
+                               pa.col("v1").max().alias("a3"), pa.count().alias("a4"))
+    assert pa.last_strategy() == "sorted_keys"
+    want, _ = oracle.group_by_agg([Column("k", k, mask)], [Column("v0", v0), Column("v1", v1, v1m)], aggs, maintain_order=True)
+    g, w = util.frame_to_np(got), util.oracle_to_np(want)
+    assert np.array_equal(g[0][0][g[0][1] if g[0][1] is not None else slice(None)], w[0][0][w[0][1] if w[0][1] is not None else slice(None)])
+    util.assert_frames_match(g, w, 1, what=f"sorted keys desc={descending} nulls={nulls}")
+
+
+@pytest.mark.parametrize("sl", [(0, 5), (3, 4), (-4, 2), (-100, 3), (7, 100), (50, 2), (0, 0)])
+def test_slice_pushdown(oracle, sl):
+    """GroupByExec's slice (group_by.rs:79-82) with slice_offsets semantics (utils/mod.rs:199-218) on the stable
+    group order."""
+    rng = np.random.default_rng(73)
+    n = 5000
+    k = rng.integers(0, 12, n).astype(np.int32); km = rng.random(n) > 0.05
+    v = np.round(rng.uniform(0, 10, n), 3); vm = rng.random(n) > 0.2
+    df = pa.DataFrame({"k": Column("k", k, km), "v": Column("v", v, vm)})
+    got = df.lazy().group_by("k", maintain_order=True).agg(pa.col("v").sum().alias("s"), pa.col("v").max().alias("m"), pa.count().alias("c")).slice(*sl).collect()
+    want, _ = oracle.group_by_agg([Column("k", k, km)], [Column("v", v, vm)], [(0, "sum"), (0, "max"), (0, "count")], maintain_order=True)
+    w = util.oracle_to_np(want)
+    g_all = len(w[0][0])
+    off, ln = sl
+    if off < 0:
+        start, cnt = (g_all + off, min(ln, -off)) if -off <= g_all else (0, min(ln, g_all))
+    else:
+        start, cnt = (off, min(ln, g_all - off)) if off <= g_all else (g_all, 0)
+    w = [(vv[start:start + cnt], None if mm is None else mm[start:start + cnt]) for vv, mm in w]
+    g = util.frame_to_np(got)
+    assert len(g[0][0]) == cnt
+    if cnt:
+        util.assert_frames_match(g, w, 1, what=f"slice {sl}")
+        gm = g[0][1] if g[0][1] is not None else np.ones(cnt, bool)
+        wm = w[0][1] if w[0][1] is not None else np.ones(cnt, bool)
+        assert np.array_equal(gm, wm) and np.array_equal(g[0][0][gm], w[0][0][wm])  # same rows in the same order
+
+
 def _shard_inputs(rng, n):
     k1 = rng.integers(-30, 30, n).astype(np.int32); k1m = rng.random(n) > 0.05
     k2 = rng.integers(0, 9, n).astype(np.int64)
