@@ -280,6 +280,21 @@ int32_t plhip_merge_records(const void *records, int64_t n_rows, const int32_t *
                             int32_t n_cols, int32_t n_keys, const int32_t *merge_kinds, uint32_t flags,
                             const plhip_options_t *opts, plhip_result_t **out);
 
+/* The same exchange without the counts round trip: fixed-capacity slots.  Every rank packs bucket b into slot b =
+ * a 64-byte header {u64 rows, u64 overflowed} + slot_rows records (plhip_slot_bytes per slot), the slots travel with
+ * ONE equal-split all-to-all, and the receiver reads the rows per slot from the headers.  slot_rows must be the
+ * same on every rank (derive it from the query: the n_groups_hint).  A rank whose bucket exceeds slot_rows sets
+ * `overflowed` in ALL its headers and keeps only the first slot_rows records of that bucket: every receiver then
+ * sees the flag of every sender, and all ranks redo the exchange with plhip_result_pack_by_owner / counts.
+ * counts[n_parts] (host) = the rows per bucket before clamping.  n_parts <= 64. */
+int64_t plhip_slot_bytes(int64_t record_bytes, int64_t slot_rows);
+int32_t plhip_result_pack_slots(const plhip_result_t *r, int32_t n_keys, uint64_t null_hash, int32_t n_parts,
+                                int64_t slot_rows, void *slots, int64_t *counts);
+/* plhip_merge_records over received slots: slot_counts[n_slots] (host) = the header's rows of every slot. */
+int32_t plhip_merge_slots(const void *slots, int32_t n_slots, int64_t slot_rows, const int64_t *slot_counts,
+                          const int32_t *dtypes, const uint8_t *nullable, int32_t n_cols, int32_t n_keys,
+                          const int32_t *merge_kinds, uint32_t flags, const plhip_options_t *opts, plhip_result_t **out);
+
 /* AggregationExpr::finalize (crates/polars-lazy/src/physical_plan/expressions/aggregation.rs:367-483) on a
  * regrouped PARTIAL frame: sum partials wrap into the column's own sum type, counts become IdxSize (u32),
  * mean = sum / count (f32 sources round through f32 first; count 0 -> null), keys / min / max pass through.

@@ -188,6 +188,12 @@ def lib():
     L.plhip_records_to_frame.restype = i32
     L.plhip_merge_records.argtypes = [vp, i64, P(i32), P(C.c_uint8), i32, i32, P(i32), u32, P(OptionsStruct), P(vp)]
     L.plhip_merge_records.restype = i32
+    L.plhip_slot_bytes.argtypes = [i64, i64]
+    L.plhip_slot_bytes.restype = i64
+    L.plhip_result_pack_slots.argtypes = [vp, i32, u64, i32, i64, vp, P(i64)]
+    L.plhip_result_pack_slots.restype = i32
+    L.plhip_merge_slots.argtypes = [vp, i32, i64, P(i64), P(i32), P(C.c_uint8), i32, i32, P(i32), u32, P(OptionsStruct), P(vp)]
+    L.plhip_merge_slots.restype = i32
     L.plhip_finalize_partial.argtypes = [vp, i32, P(FinalStruct), i32, P(ColumnStruct)]
     L.plhip_finalize_partial.restype = i32
     if L.plhip_abi_version() != 1:
@@ -207,5 +213,5 @@ EXPORTED_SYMBOLS = [
     "plhip_last_kernel_ms", "plhip_memcpy", "plhip_last_kernel_breakdown", "plhip_vec_hash", "plhip_group_by_agg", "plhip_group_by_agg_opts", "plhip_result_num_rows",
     "plhip_result_num_columns", "plhip_result_column", "plhip_result_free", "plhip_group_tuples",
     "plhip_groups_num_groups", "plhip_groups_num_rows", "plhip_groups_buffers", "plhip_groups_free",
-    "plhip_agg_groups", "plhip_result_record_bytes", "plhip_result_pack_by_owner", "plhip_records_to_frame", "plhip_merge_records", "plhip_finalize_partial",
+    "plhip_agg_groups", "plhip_result_record_bytes", "plhip_result_pack_by_owner", "plhip_records_to_frame", "plhip_merge_records", "plhip_finalize_partial", "plhip_slot_bytes", "plhip_result_pack_slots", "plhip_merge_slots",
 ]

@@ -1630,21 +1630,24 @@ int64_t plhip_result_record_bytes(const plhip_result_t *r) {
   return frame_layout(R, r) ? -1 : (int64_t)R.rec_bytes;
 }
 
-int32_t plhip_result_pack_by_owner(const plhip_result_t *r, int32_t n_keys, uint64_t null_hash, int32_t n_parts, void *records,
-                                   int64_t *counts) {
+namespace {
+int pack_impl(const plhip_result_t *r, int32_t n_keys, uint64_t null_hash, int32_t n_parts, int64_t slot_rows, void *records, int64_t *counts) {
   if (!r || !counts) return fail(PLHIP_ERR_INVALID, "NULL pointer");
   if (!r->on_device) return fail(PLHIP_ERR_INVALID, "the frame must be device-resident (PLHIP_FLAG_OUTPUT_DEVICE)");
-  if (n_parts < 1 || n_parts > EX_MAX_PARTS) return fail(PLHIP_ERR_INVALID, "owner count out of range");
+  if (n_parts < 1 || n_parts > (slot_rows ? EX_MAX_SLOTS : EX_MAX_PARTS)) return fail(PLHIP_ERR_INVALID, "owner count out of range");
   if (n_keys < 1 || n_keys > (int)r->cols.size() || n_keys > PLHIP_MAX_KEYS) return fail(PLHIP_ERR_INVALID, "bad key count");
+  if (slot_rows < 0 || slot_rows > 0x7FFFFFFFll) return fail(PLHIP_ERR_INVALID, "bad slot capacity");
   int rc = ensure_ctx();
   if (rc) return rc;
   Ctx &c = g_ctx;
   RecPlan R{};
   if ((rc = frame_layout(R, r))) return rc;
   R.n_keys = n_keys; R.n_parts = (uint32_t)n_parts;
+  R.slot_rows = (uint32_t)slot_rows;
+  R.slot_stride = slot_rows ? (uint64_t)EX_SLOT_HDR + (uint64_t)slot_rows * R.rec_bytes : 0;
   for (int p = 0; p < n_parts; p++) counts[p] = 0;
   const int64_t n = r->n_rows;
-  if (n == 0) return PLHIP_OK;
+  if (n == 0 && !slot_rows) return PLHIP_OK;
   if (!records) return fail(PLHIP_ERR_INVALID, "records buffer is NULL");
   if (n > 0xFFFFFFFFll) return fail(PLHIP_ERR_INVALID, "too many rows for one exchange");
   // scratch: counts[n_parts] | cursor[n_parts] | owner[n] (u16)
@@ -1653,8 +1656,10 @@ int32_t plhip_result_pack_by_owner(const plhip_result_t *r, int32_t n_keys, uint
   uint32_t *d_counts = (uint32_t *)c.misc.p, *d_cursor = d_counts + n_parts;
   uint16_t *d_owner = (uint16_t *)((uint8_t *)c.misc.p + head);
   HIP_TRY(hipMemsetAsync(d_counts, 0, head, c.stream));
-  launch_owner_count(R, null_hash, d_owner, d_counts, c.stream);
-  HIP_TRY(hipGetLastError());
+  if (n) {
+    launch_owner_count(R, null_hash, d_owner, d_counts, c.stream);
+    HIP_TRY(hipGetLastError());
+  }
   launch_pack_records(R, d_owner, d_counts, d_cursor, (uint8_t *)records, c.stream);
   HIP_TRY(hipGetLastError());
   std::vector<uint32_t> h(n_parts);
@@ -1663,10 +1668,24 @@ int32_t plhip_result_pack_by_owner(const plhip_result_t *r, int32_t n_keys, uint
   for (int p = 0; p < n_parts; p++) counts[p] = h[p];
   return PLHIP_OK;
 }
+} // namespace
+
+int32_t plhip_result_pack_by_owner(const plhip_result_t *r, int32_t n_keys, uint64_t null_hash, int32_t n_parts, void *records,
+                                   int64_t *counts) {
+  return pack_impl(r, n_keys, null_hash, n_parts, 0, records, counts);
+}
+
+int64_t plhip_slot_bytes(int64_t record_bytes, int64_t slot_rows) { return EX_SLOT_HDR + record_bytes * slot_rows; }
+
+int32_t plhip_result_pack_slots(const plhip_result_t *r, int32_t n_keys, uint64_t null_hash, int32_t n_parts, int64_t slot_rows,
+                                void *records, int64_t *counts) {
+  if (slot_rows < 1) return fail(PLHIP_ERR_INVALID, "bad slot capacity");
+  return pack_impl(r, n_keys, null_hash, n_parts, slot_rows, records, counts);
+}
 
 namespace {
 int records_to_frame_impl(const void *records, int64_t n_rows, const int32_t *dtypes, const uint8_t *nullable, int32_t n_cols, bool sync,
-                          plhip_result **out) {
+                          plhip_result **out, int32_t n_slots = 0, int64_t slot_rows = 0, const int64_t *slot_counts = nullptr) {
   *out = nullptr;
   if (!dtypes || !nullable || n_rows < 0 || (n_rows > 0 && !records)) return fail(PLHIP_ERR_INVALID, "bad arguments");
   int rc = ensure_ctx();
@@ -1675,6 +1694,18 @@ int records_to_frame_impl(const void *records, int64_t n_rows, const int32_t *dt
   RecPlan R{};
   if ((rc = rec_layout(R, dtypes, nullable, n_cols))) return rc;
   R.n_rows = n_rows;
+  if (n_slots) { // slotted layout: the rows of slot s come out at [slot_first[s], slot_first[s + 1])
+    if (n_slots > EX_MAX_SLOTS || slot_rows < 1 || !slot_counts) return fail(PLHIP_ERR_INVALID, "bad slot description");
+    uint64_t run = 0;
+    for (int sidx = 0; sidx < n_slots; sidx++) {
+      if (slot_counts[sidx] < 0 || slot_counts[sidx] > slot_rows) return fail(PLHIP_ERR_INVALID, "a slot holds more rows than its capacity");
+      R.slot_first[sidx] = (uint32_t)run; run += (uint64_t)slot_counts[sidx];
+    }
+    R.slot_first[n_slots] = (uint32_t)run;
+    if ((int64_t)run != n_rows || run > 0xFFFFFFFFull) return fail(PLHIP_ERR_INVALID, "slot counts do not add up to n_rows");
+    R.n_parts = (uint32_t)n_slots; R.slot_rows = (uint32_t)slot_rows;
+    R.slot_stride = (uint64_t)EX_SLOT_HDR + (uint64_t)slot_rows * R.rec_bytes;
+  }
   plhip_result *F = new (std::nothrow) plhip_result();
   if (!F) return fail(PLHIP_ERR_OOM, "host allocation failed");
   F->on_device = true; F->device = c.device; F->n_rows = n_rows;
@@ -1704,13 +1735,35 @@ int32_t plhip_records_to_frame(const void *records, int64_t n_rows, const int32_
   return records_to_frame_impl(records, n_rows, dtypes, nullable, n_cols, true, out);
 }
 
+namespace {
+int merge_impl(const void *records, int64_t n_rows, const int32_t *dtypes, const uint8_t *nullable, int32_t n_cols, int32_t n_keys,
+               const int32_t *merge_kinds, uint32_t flags, const plhip_options_t *opts, plhip_result_t **out, int32_t n_slots,
+               int64_t slot_rows, const int64_t *slot_counts);
+}
+
 int32_t plhip_merge_records(const void *records, int64_t n_rows, const int32_t *dtypes, const uint8_t *nullable, int32_t n_cols,
                             int32_t n_keys, const int32_t *merge_kinds, uint32_t flags, const plhip_options_t *opts, plhip_result_t **out) {
+  return merge_impl(records, n_rows, dtypes, nullable, n_cols, n_keys, merge_kinds, flags, opts, out, 0, 0, nullptr);
+}
+
+int32_t plhip_merge_slots(const void *slots, int32_t n_slots, int64_t slot_rows, const int64_t *slot_counts, const int32_t *dtypes,
+                          const uint8_t *nullable, int32_t n_cols, int32_t n_keys, const int32_t *merge_kinds, uint32_t flags,
+                          const plhip_options_t *opts, plhip_result_t **out) {
+  if (n_slots < 1 || !slot_counts) return fail(PLHIP_ERR_INVALID, "bad slot description");
+  int64_t n_rows = 0;
+  for (int i = 0; i < n_slots; i++) n_rows += slot_counts[i];
+  return merge_impl(slots, n_rows, dtypes, nullable, n_cols, n_keys, merge_kinds, flags, opts, out, n_slots, slot_rows, slot_counts);
+}
+
+namespace {
+int merge_impl(const void *records, int64_t n_rows, const int32_t *dtypes, const uint8_t *nullable, int32_t n_cols, int32_t n_keys,
+               const int32_t *merge_kinds, uint32_t flags, const plhip_options_t *opts, plhip_result_t **out, int32_t n_slots,
+               int64_t slot_rows, const int64_t *slot_counts) {
   if (!out) return fail(PLHIP_ERR_INVALID, "out is NULL");
   *out = nullptr;
   if (n_keys < 1 || n_keys > n_cols || !merge_kinds) return fail(PLHIP_ERR_INVALID, "bad key count / merge kinds");
   plhip_result *F = nullptr;
-  int rc = records_to_frame_impl(records, n_rows, dtypes, nullable, n_cols, false, &F); // same stream: no sync in between
+  int rc = records_to_frame_impl(records, n_rows, dtypes, nullable, n_cols, false, &F, n_slots, slot_rows, slot_counts); // same stream: no sync in between
   if (rc) return rc;
   std::vector<plhip_column_t> cols(n_cols);
   for (int i = 0; i < n_cols; i++) {
@@ -1730,6 +1783,7 @@ int32_t plhip_merge_records(const void *records, int64_t n_rows, const int32_t *
   delete F; // the group-by has synchronised the stream
   return rc;
 }
+} // namespace
 
 int32_t plhip_finalize_partial(const plhip_result_t *merged, int32_t n_keys, const plhip_final_t *finals, int32_t n_finals,
                                const plhip_column_t *out_cols) {

@@ -65,8 +65,17 @@ __global__ void __launch_bounds__(EX_BLOCK) k_pack_records(RecPlan R, const uint
   __shared__ uint32_t start[EX_MAX_PARTS]; // first record of the owner's bucket
   for (uint32_t p = threadIdx.x; p < R.n_parts; p += EX_BLOCK) hist[p] = 0;
   if (threadIdx.x == 0) {
-    uint32_t run = 0;
-    for (uint32_t p = 0; p < R.n_parts; p++) { start[p] = run; run += counts[p]; }
+    uint32_t run = 0, over = 0;
+    for (uint32_t p = 0; p < R.n_parts; p++) {
+      start[p] = R.slot_rows ? 0u : run;
+      run += counts[p];
+      if (R.slot_rows && counts[p] > R.slot_rows) over = 1;
+    }
+    if (R.slot_rows && blockIdx.x == 0) // the slot headers: rows in the bucket, "this sender overflowed somewhere"
+      for (uint32_t p = 0; p < R.n_parts; p++) {
+        unsigned long long *h = (unsigned long long *)(records + (uint64_t)p * R.slot_stride);
+        h[0] = counts[p]; h[1] = over;
+      }
   }
   __syncthreads();
   const int64_t row = (int64_t)blockIdx.x * EX_BLOCK + threadIdx.x;
@@ -83,7 +92,10 @@ __global__ void __launch_bounds__(EX_BLOCK) k_pack_records(RecPlan R, const uint
   }
   __syncthreads();
   if (!live) return;
-  uint8_t *rec = records + (uint64_t)(hist[o] + rank) * R.rec_bytes;
+  const uint32_t pos = hist[o] + rank;
+  if (R.slot_rows && pos >= R.slot_rows) return; // overflow: the header says so, the exchange is redone exactly
+  uint8_t *rec = R.slot_rows ? records + (uint64_t)o * R.slot_stride + EX_SLOT_HDR + (uint64_t)pos * R.rec_bytes
+                             : records + (uint64_t)pos * R.rec_bytes;
   for (int c = 0; c < R.n_cols; c++) {
     const uint32_t w = R.width[c];
     copy_field(rec + R.off[c], R.values[c] + (uint64_t)row * w, w);
@@ -96,6 +108,12 @@ __global__ void __launch_bounds__(EX_BLOCK) k_unpack(RecPlan R, const uint8_t *_
   const int64_t row = (int64_t)blockIdx.x * EX_BLOCK + threadIdx.x;
   const bool live = row < R.n_rows;
   const uint8_t *rec = records + (uint64_t)(live ? row : 0) * R.rec_bytes;
+  if (R.slot_rows) { // slotted layout: output row -> (slot, position)
+    uint32_t sl = 0;
+    const uint32_t r32 = live ? (uint32_t)row : 0u;
+    while (sl + 1 < R.n_parts && R.slot_first[sl + 1] <= r32) sl++;
+    rec = records + (uint64_t)sl * R.slot_stride + EX_SLOT_HDR + (uint64_t)(r32 - R.slot_first[sl]) * R.rec_bytes;
+  }
   for (int c = 0; c < R.n_cols; c++) {
     const uint32_t w = R.width[c];
     if (live) copy_field((uint8_t *)R.values[c] + (uint64_t)row * w, rec + R.off[c], w);
@@ -138,7 +156,8 @@ void launch_owner_count(const RecPlan &r, uint64_t null_hash, uint16_t *owner, u
   hipLaunchKernelGGL(k_owner_count, dim3((unsigned)((r.n_rows + EX_BLOCK - 1) / EX_BLOCK)), dim3(EX_BLOCK), 0, s, r, null_hash, owner, counts);
 }
 void launch_pack_records(const RecPlan &r, const uint16_t *owner, const uint32_t *counts, uint32_t *cursor, uint8_t *records, hipStream_t s) {
-  hipLaunchKernelGGL(k_pack_records, dim3((unsigned)((r.n_rows + EX_BLOCK - 1) / EX_BLOCK)), dim3(EX_BLOCK), 0, s, r, owner, counts, cursor, records);
+  const int64_t blocks = (r.n_rows + EX_BLOCK - 1) / EX_BLOCK; // (an empty frame still writes its slot headers)
+  hipLaunchKernelGGL(k_pack_records, dim3((unsigned)(blocks ? blocks : 1)), dim3(EX_BLOCK), 0, s, r, owner, counts, cursor, records);
 }
 void launch_unpack_records(const RecPlan &r, const uint8_t *records, hipStream_t s) {
   hipLaunchKernelGGL(k_unpack, dim3((unsigned)((r.n_rows + EX_BLOCK - 1) / EX_BLOCK)), dim3(EX_BLOCK), 0, s, r, records);

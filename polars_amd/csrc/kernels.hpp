@@ -85,6 +85,7 @@ void launch_fold_sorted(const Plan &p, const OutPlan &o, const KeyGather *kg_dev
 
 // exchange step of the row-sharded group-by (exchange.hip): frame <-> row records
 #define EX_MAX_PARTS 1024 // owner ranks
+#define EX_MAX_SLOTS 64   // ... of the slotted layout
 struct RecPlan {
   int64_t n_rows;
   int32_t n_cols, n_keys; // the first n_keys columns are the keys the owner is hashed from
@@ -95,7 +96,13 @@ struct RecPlan {
   uint32_t dtype[PLHIP_MAX_OUTS], width[PLHIP_MAX_OUTS];
   uint32_t off[PLHIP_MAX_OUTS];      // field offset inside a record: value bytes, then one validity byte if has_valid
   uint8_t has_valid[PLHIP_MAX_OUTS];
+  // slotted layout (fixed-capacity buckets, no counts exchange): bucket b = EX_SLOT_HDR header bytes
+  // {u64 rows, u64 "this sender overflowed some bucket"} + slot_rows records, at b * slot_stride.  0 = compact layout.
+  uint32_t slot_rows, pad2;
+  uint64_t slot_stride;
+  uint32_t slot_first[EX_MAX_SLOTS + 1]; // unpack: first output row of every slot (prefix sums of the rows per slot)
 };
+#define EX_SLOT_HDR 64
 void launch_owner_count(const RecPlan &r, uint64_t null_hash, uint16_t *owner, uint32_t *counts, hipStream_t s);
 void launch_pack_records(const RecPlan &r, const uint16_t *owner, const uint32_t *counts, uint32_t *cursor, uint8_t *records, hipStream_t s);
 void launch_unpack_records(const RecPlan &r, const uint8_t *records, hipStream_t s);

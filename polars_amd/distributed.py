@@ -172,9 +172,10 @@ class HipEngine:
 
 
     # ---- the exchange with the bucketing and the unpacking done by the library (exchange.hip) ------------
-    def pack(self, keys, vals, aggs, world: int, hint: int = 0):
+    def pack(self, keys, vals, aggs, world: int, hint: int = 0, slot_rows: int = 0):
         """Partial pass, then plhip_result_pack_by_owner: returns (records [G x rec] uint8 on the device, bucket
-        after bucket by owner rank; rows per owner as a list)."""
+        after bucket by owner rank; rows per owner as a list).  With `slot_rows`: plhip_result_pack_slots, the
+        buffer then holds `world` fixed-capacity slots (header + slot_rows records each)."""
         import ctypes as C
 
         import torch
@@ -192,8 +193,12 @@ class HipEngine:
             if g:  # the frame's layout is a property of the schema: every rank computes the same one
                 assert [(cs.dtype, bool(cs.validity)) for cs in cols] == schema, "partial frame does not match the schema"
                 assert L.plhip_result_record_bytes(handle) == rec
-            send = torch.empty((max(g, 1), rec), dtype=torch.uint8, device=self.device)
             counts = (C.c_int64 * world)()
+            if slot_rows:
+                send = torch.empty(world * int(L.plhip_slot_bytes(rec, slot_rows)), dtype=torch.uint8, device=self.device)
+                _ffi.check(L.plhip_result_pack_slots(handle, len(keys), NULL_HASH, world, slot_rows, send.data_ptr(), counts))
+                return send, list(counts)
+            send = torch.empty((max(g, 1), rec), dtype=torch.uint8, device=self.device)
             _ffi.check(L.plhip_result_pack_by_owner(handle, len(keys), NULL_HASH, world, send.data_ptr(), counts))
         finally:
             L.plhip_result_free(handle)
@@ -264,27 +269,87 @@ class HipEngine:
         return out
 
     def sharded(self, keys, vals, aggs, world: int, group, hint: int, names) -> list[Col]:
-        """pack -> counts + ONE all_to_all_single -> merge_records -> finalize_frame.  torch only allocates the
-        buffers and runs the two collectives."""
+        """partial pass -> pack -> exchange -> unpack + regroup -> finalize; torch only allocates the buffers and
+        runs the collectives.  With an n_groups_hint (a query-level bound, the same on every rank) the buckets
+        travel in fixed-capacity slots with ONE equal-split all_to_all_single and no counts round trip; a rank
+        whose bucket does not fit says so in its slot headers, which every rank sees, and all ranks fall back to
+        the exact protocol (counts, then a variable all_to_all_single)."""
+        import ctypes as C
+
         import torch
         import torch.distributed as dist
 
-        send, sc = self.pack(keys, vals, aggs, world, hint)
-        # RCCL moves device buffers; over gloo (rehearsals of several ranks on one GPU) the records are staged
-        # through host memory
+        from .frame import group_by_agg_raw
+
+        L = _ffi.lib()
+        nk = len(keys)
+        schema = partial_schema(keys, vals, aggs)
+        rec = sum(_ffi.code_np_dtype(code).itemsize + (1 if nullable else 0) for code, nullable in schema)
+        codes = [(ci, _ffi.AGG_NAMES[k]) for ci, k in aggs]
+        # RCCL moves device buffers; over gloo (rehearsals of several ranks on one GPU) they are staged through the host
         staged = dist.get_backend(group) == "gloo"
-        cdev = torch.device("cpu") if staged else self.device
-        send_counts = torch.tensor(sc, dtype=torch.int64, device=cdev)
-        recv_counts = torch.empty_like(send_counts)
-        dist.all_to_all_single(recv_counts, send_counts, group=group)
-        rc = recv_counts.tolist()  # the one host sync of the exchange
-        m = sum(rc)
-        rec = send.shape[1]
-        recv = torch.empty((max(m, 1), rec), dtype=torch.uint8, device=cdev)[:m]
-        dist.all_to_all_single(recv, send.cpu() if staged else send, output_split_sizes=rc, input_split_sizes=sc, group=group)
-        if staged:
-            recv = recv.to(self.device)
-        return self.finalize_frame(self.merge_records(recv, keys, vals, aggs, hint, raw=True), keys, vals, aggs, names)
+        self._sync_torch()
+        handle, cols = group_by_agg_raw(keys, vals, codes, _ffi.FLAG_PARTIAL | _ffi.FLAG_OUTPUT_DEVICE, hint)
+        try:
+            g = int(L.plhip_result_num_rows(handle))
+            if g:  # the frame's layout is a property of the schema: every rank computes the same one
+                assert [(cs.dtype, bool(cs.validity)) for cs in cols] == schema, "partial frame does not match the schema"
+            counts = (C.c_int64 * world)()
+            merged = None
+            if hint > 0 and world <= 64 and self.use_slots:
+                slot_rows = -(-5 * int(hint) // (4 * world)) + 512  # 1.25x an even share: overflow needs a badly skewed hash
+                stride = int(L.plhip_slot_bytes(rec, slot_rows))
+                send = torch.empty(world * stride, dtype=torch.uint8, device=self.device)
+                _ffi.check(L.plhip_result_pack_slots(handle, nk, NULL_HASH, world, slot_rows, send.data_ptr(), counts))
+                recv = torch.empty(world * stride, dtype=torch.uint8, device="cpu" if staged else self.device)
+                dist.all_to_all_single(recv, send.cpu() if staged else send, group=group)
+                if staged:
+                    recv = recv.to(self.device)
+                hdr = recv.view(world, stride)[:, :16].cpu().numpy().view(np.uint64)  # the one host sync of the exchange
+                if not hdr[:, 1].any():
+                    rc = (C.c_int64 * world)(*[int(x) for x in hdr[:, 0]])
+                    merged = self._merge_call(recv, schema, nk, aggs, hint, sum(rc), slots=(world, slot_rows, rc))
+            if merged is None:  # no hint, or some rank's bucket overflowed its slot (all ranks saw the flag)
+                send = torch.empty((max(g, 1), rec), dtype=torch.uint8, device=self.device)
+                _ffi.check(L.plhip_result_pack_by_owner(handle, nk, NULL_HASH, world, send.data_ptr(), counts))
+                sc = list(counts)
+                cdev = torch.device("cpu") if staged else self.device
+                send_counts = torch.tensor(sc, dtype=torch.int64, device=cdev)
+                recv_counts = torch.empty_like(send_counts)
+                dist.all_to_all_single(recv_counts, send_counts, group=group)
+                rc = recv_counts.tolist()
+                m = sum(rc)
+                recv = torch.empty((max(m, 1), rec), dtype=torch.uint8, device=cdev)[:m]
+                dist.all_to_all_single(recv, send[:g].cpu() if staged else send[:g], output_split_sizes=rc, input_split_sizes=sc, group=group)
+                if staged:
+                    recv = recv.to(self.device)
+                merged = self._merge_call(recv, schema, nk, aggs, hint, m)
+        finally:
+            L.plhip_result_free(handle)
+        return self.finalize_frame(merged, keys, vals, aggs, names)
+
+    use_slots = True  # tests switch the slotted exchange off to cover the exact protocol
+
+    def _merge_call(self, recv, schema, nk, aggs, hint, m, slots=None):
+        """plhip_merge_records / plhip_merge_slots -> handle of the regrouped partial frame."""
+        import ctypes as C
+
+        L = _ffi.lib()
+        self._sync_torch()
+        dts = (C.c_int32 * len(schema))(*[code for code, _ in schema])
+        nul = (C.c_uint8 * len(schema))(*[1 if nullable else 0 for _, nullable in schema])
+        ops = _merge_ops(aggs)
+        kinds = (C.c_int32 * max(len(ops), 1))(*[_ffi.AGG_NAMES[op] for op in ops])
+        opts = _ffi.OptionsStruct(C.sizeof(_ffi.OptionsStruct), max(min(m, hint) if hint > 0 else m, 1))
+        merged = C.c_void_p()
+        if slots is None:
+            _ffi.check(L.plhip_merge_records(recv.data_ptr() if m else None, m, dts, nul, len(schema), nk, kinds,
+                                             _ffi.FLAG_OUTPUT_DEVICE, C.byref(opts), C.byref(merged)))
+        else:
+            world, slot_rows, rc = slots
+            _ffi.check(L.plhip_merge_slots(recv.data_ptr(), world, slot_rows, rc, dts, nul, len(schema), nk, kinds,
+                                           _ffi.FLAG_OUTPUT_DEVICE, C.byref(opts), C.byref(merged)))
+        return merged
 
 
 def partial_schema(keys, vals, aggs) -> list[tuple[int, bool]]:

@@ -55,18 +55,19 @@ v1 = rng.integers(1, 6, n).astype(np.int32)
 v3 = np.round(rng.uniform(0, 100, n), 6)
 lo, hi = rank * n // world, (rank + 1) * n // world
 aggs = [(0, "sum"), (1, "mean")]
-res = group_by_agg_sharded([Column("id3", k[lo:hi])], [Column("v1", v1[lo:hi]), Column("v3", v3[lo:hi])], aggs, device=dev, n_groups_hint=g)
-mine = []
-for c in res:
-    mine.append(c.t.cpu().numpy().view(_ffi.code_np_dtype(c.code)))
-    mine.append(np.ones(c.t.numel(), bool) if c.mask is None else c.mask.cpu().numpy())
-gathered = [None] * world
-dist.all_gather_object(gathered, mine)
-if rank == 0:
-    from oracle import oracle as orc
+for hint, what in ((g, "slots"), (100, "hint too small: slots overflow, all ranks fall back"), (0, "no hint: counts protocol")):
+    res = group_by_agg_sharded([Column("id3", k[lo:hi])], [Column("v1", v1[lo:hi]), Column("v3", v3[lo:hi])], aggs, device=dev, n_groups_hint=hint)
+    mine = []
+    for c in res:
+        mine.append(c.t.cpu().numpy().view(_ffi.code_np_dtype(c.code)))
+        mine.append(np.ones(c.t.numel(), bool) if c.mask is None else c.mask.cpu().numpy())
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    if rank == 0:
+        from oracle import oracle as orc
 
-    got = [(np.concatenate([x[2 * j] for x in gathered]), np.concatenate([x[2 * j + 1] for x in gathered])) for j in range(3)]
-    want, _ = orc.group_by_agg([Column("id3", k)], [Column("v1", v1), Column("v3", v3)], aggs)
-    util.assert_frames_match(got, util.oracle_to_np(want), 1, what=f"q3 shape, {world} ranks")
-    print(f"ok: q3 shape n={n} world={world} groups={len(got[0][0])} rows per rank={[len(x[0]) for x in gathered]}", flush=True)
+        got = [(np.concatenate([x[2 * j] for x in gathered]), np.concatenate([x[2 * j + 1] for x in gathered])) for j in range(3)]
+        want, _ = orc.group_by_agg([Column("id3", k)], [Column("v1", v1), Column("v3", v3)], aggs)
+        util.assert_frames_match(got, util.oracle_to_np(want), 1, what=f"q3 shape, {world} ranks, {what}")
+        print(f"ok: q3 shape ({what}) n={n} world={world} groups={len(got[0][0])} rows per rank={[len(x[0]) for x in gathered]}", flush=True)
 dist.destroy_process_group()

@@ -431,6 +431,60 @@ def test_sharded_engine_two_shards_one_gpu(oracle):
     util.assert_frames_match(got, util.oracle_to_np(want), 2, what="two shards, one GPU")
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_slotted_exchange_one_gpu(oracle, world):
+    """plhip_result_pack_slots / plhip_merge_slots with the equal-split all-to-all replaced by its definition
+    (rank r receives slot r of every shard); one shard is empty.  Then a slot capacity that is too small: the
+    headers must say so (and the clamped slots must still hold exactly slot_rows records' worth of space)."""
+    import ctypes as C
+
+    import torch
+
+    from polars_amd import distributed as pd_
+
+    rng = np.random.default_rng(67)
+    n = 60000
+    K, V = _shard_inputs(rng, n)
+    aggs = [(0, "sum"), (1, "mean"), (0, "min"), (1, "max"), (0, "count"), (2, "mean"), (2, "sum")]
+    eng = pd_.HipEngine(torch.device("cuda:0"))
+    bounds = [0] + [n * (r + 1) // (world - 1) for r in range(world - 1)] + [n]
+    slot_rows = 400
+    shard_cols, sends = [], []
+    for r in range(world):
+        keys, vals = _shard_columns(K, V, bounds[r], bounds[r + 1])
+        shard_cols.append((keys, vals))
+        send, counts = eng.pack(keys, vals, aggs, world, slot_rows=slot_rows)
+        sends.append((send, counts))
+    schema = pd_.partial_schema(*shard_cols[0], aggs)
+    rec = sum(_ffi.code_np_dtype(c).itemsize + (1 if b else 0) for c, b in schema)
+    stride = int(_ffi.lib().plhip_slot_bytes(rec, slot_rows))
+    names = ["s", "m", "mn", "mx", "c", "m2", "s2"]
+    outs = []
+    for r in range(world):
+        recv = torch.cat([send.view(world, stride)[r] for send, _ in sends]).contiguous()
+        hdr = recv.view(world, stride)[:, :16].cpu().numpy().view(np.uint64)
+        assert not hdr[:, 1].any()
+        assert hdr[:, 0].tolist() == [counts[r] for _, counts in sends]
+        rc = (C.c_int64 * world)(*[int(x) for x in hdr[:, 0]])
+        keys, vals = shard_cols[r]
+        merged = eng._merge_call(recv, schema, 2, aggs, 0, sum(rc), slots=(world, slot_rows, rc))
+        outs.append(eng.finalize_frame(merged, keys, vals, aggs, names))
+    got = []
+    for j in range(len(outs[0])):
+        v = np.concatenate([o[j].t.cpu().numpy().view(_ffi.code_np_dtype(o[j].code)) for o in outs])
+        m = np.concatenate([(np.ones(o[j].t.numel(), bool) if o[j].mask is None else o[j].mask.cpu().numpy()) for o in outs])
+        got.append((v, m))
+    keys, vals = _shard_columns(K, V, 0, n)
+    want, _ = oracle.group_by_agg(keys, vals, aggs)
+    util.assert_frames_match(got, util.oracle_to_np(want), 2, what=f"slotted exchange, world {world}")
+    # overflow: 549 groups over `world` owners cannot fit slots of 16 rows
+    keys, vals = shard_cols[0]
+    send, counts = eng.pack(keys, vals, aggs, world, slot_rows=16)
+    stride = int(_ffi.lib().plhip_slot_bytes(rec, 16))
+    hdr = send.view(world, stride)[:, :16].cpu().numpy().view(np.uint64)
+    assert max(counts) > 16 and hdr[:, 1].all() and hdr[:, 0].tolist() == counts
+
+
 # ---------------------------------------------------------------------------------------------------
 # sorted-key fast path (SURVEY §8 a10) and slice pushdown (a17)
 # ---------------------------------------------------------------------------------------------------
