@@ -119,8 +119,10 @@ typedef enum plhip_strategy {
   PLHIP_STRATEGY_TILESORT = 5,   /* LDS-only: tiles sorted by hash partition in LDS, per-partition LDS tables, merged
                                     in LDS (many groups); AUTO picks DIRECT / TILESORT when the query qualifies and
                                     falls back to the strategies above otherwise */
-  PLHIP_STRATEGY_SORT = 6        /* radix sort of (packed key, row), run boundaries, one fold per run: any number of
+  PLHIP_STRATEGY_SORT = 6,       /* radix sort of (packed key, row), run boundaries, one fold per run: any number of
                                     groups up to all-unique keys, immune to skew */
+  PLHIP_STRATEGY_TILESORT2 = 7   /* two partition levels (radix partition, then the tile sort inside every partition),
+                                    one LDS table per leaf: more groups than TILESORT's 512 tables hold */
 } plhip_strategy_t;
 
 /* Optional knowledge the caller has about the query.  struct_size = sizeof(plhip_options_t). */

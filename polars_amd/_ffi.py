@@ -33,7 +33,7 @@ FLAG_OUTPUT_DEVICE = 2
 FLAG_KEYS_SORTED = 8
 FLAG_PARTIAL = 4
 
-STRATEGIES = {"auto": 0, "global": 1, "lds": 2, "partitioned": 3, "direct": 4, "tilesort": 5, "sort": 6}
+STRATEGIES = {"auto": 0, "global": 1, "lds": 2, "partitioned": 3, "direct": 4, "tilesort": 5, "sort": 6, "tilesort2": 7}
 
 STATUS_NAMES = {
     0: "OK", 1: "ComputeError", 2: "ShapeMismatch", 3: "OutOfMemory", 4: "UnsupportedDtype", 5: "HipError",

@@ -493,6 +493,7 @@ int env_strategy() {
   if (!strcmp(e, "direct")) return PLHIP_STRATEGY_DIRECT;
   if (!strcmp(e, "tilesort")) return PLHIP_STRATEGY_TILESORT;
   if (!strcmp(e, "sort")) return PLHIP_STRATEGY_SORT;
+  if (!strcmp(e, "tilesort2")) return PLHIP_STRATEGY_TILESORT2;
   return PLHIP_STRATEGY_AUTO;
 }
 
@@ -777,27 +778,35 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
   uint64_t g_est;
   if (groups_hint > 0) g_est = (uint64_t)std::min<int64_t>(groups_hint, n);
   else {
-    const int64_t ns = n <= (1 << 17) ? n : (1 << 17); // whole 256-row blocks when sampling
-    const uint32_t set_bits = (uint32_t)std::max(10, ceil_log2((uint64_t)ns * 4));
-    HIP_TRY(c.table.reserve((size_t)4 << set_bits));
-    HIP_TRY(hipMemsetAsync(c.table.p, 0xFF, (size_t)4 << set_bits, c.stream));
-    HIP_TRY(hipMemsetAsync(dflags, 0, 64, c.stream));
-    c.flags_clean = false;
-    launch_estimate(P, ns, ns == n ? 256 : n / (ns >> 8), (uint32_t *)c.table.p, set_bits, dflags, c.stream);
-    HIP_TRY(hipGetLastError());
-    TableRef t{nullptr, 0, dflags};
-    uint32_t f[16];
-    int rc = read_flags(t, f);
-    if (rc) return rc;
-    const double d = f[FLAG_NGROUPS];
-    if (d >= 0.95 * (double)ns) g_est = (uint64_t)n;
-    else { // invert E[d] = G (1 - exp(-s / G))
-      double lo = d, hi = (double)n;
-      for (int it = 0; it < 60; it++) {
-        const double g = 0.5 * (lo + hi);
-        if (g * (1.0 - std::exp(-(double)ns / g)) < d) lo = g; else hi = g;
+    // 131 072 sampled keys resolve up to ~1e6 groups; a sample that comes back (almost) all distinct is taken
+    // again 32x larger when the column is long enough for that to matter (ms-scale queries: the second sample is noise)
+    int64_t ns = n <= (1 << 17) ? n : (1 << 17); // whole 256-row blocks when sampling
+    g_est = (uint64_t)n;
+    for (int round = 0; round < 2; round++) {
+      const uint32_t set_bits = (uint32_t)std::max(10, ceil_log2((uint64_t)ns * 4));
+      HIP_TRY(c.table.reserve((size_t)4 << set_bits));
+      HIP_TRY(hipMemsetAsync(c.table.p, 0xFF, (size_t)4 << set_bits, c.stream));
+      HIP_TRY(hipMemsetAsync(dflags, 0, 64, c.stream));
+      c.flags_clean = false;
+      launch_estimate(P, ns, ns == n ? 256 : n / (ns >> 8), (uint32_t *)c.table.p, set_bits, dflags, c.stream);
+      HIP_TRY(hipGetLastError());
+      TableRef t{nullptr, 0, dflags};
+      uint32_t f[16];
+      int rc = read_flags(t, f);
+      if (rc) return rc;
+      const double d = f[FLAG_NGROUPS];
+      if (d >= 0.95 * (double)ns) {
+        g_est = (uint64_t)n;
+        if (round == 0 && n >= 32 * ns) { ns = std::min<int64_t>((n / 16) & ~(int64_t)255, (int64_t)1 << 22); continue; }
+      } else { // invert E[d] = G (1 - exp(-s / G))
+        double lo = d, hi = (double)n;
+        for (int it = 0; it < 60; it++) {
+          const double g = 0.5 * (lo + hi);
+          if (g * (1.0 - std::exp(-(double)ns / g)) < d) lo = g; else hi = g;
+        }
+        g_est = (uint64_t)std::min<double>((double)n, std::ceil(hi * 1.1));
       }
-      g_est = (uint64_t)std::min<double>((double)n, std::ceil(hi * 1.1));
+      break;
     }
   }
   g_est = std::max<uint64_t>(g_est, 1);
@@ -980,6 +989,152 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
 }
 
 
+// Two partition levels (DESIGN.md "TILESORT2"): more groups than 512 LDS tables hold.  Level 1 = the radix
+// partition of the general path (k_part_hist / scan / plan / scatter) into tile-aligned, partition-contiguous
+// copies; level 2 = the tile sort inside every level-1 partition on the next hash bits; then one LDS table per
+// (level-1, level-2) leaf, which writes its output rows itself (the leaves are disjoint in the keys).
+int run_two_level(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, uint64_t g_est, bool forced, plhip_result_t **out, bool &handled) {
+  handled = false;
+  Ctx &c = g_ctx;
+  Plan &P = L.P;
+  const int64_t n = P.n_rows;
+  if ((flags & PLHIP_FLAG_MAINTAIN_ORDER) || L.KG.enabled || L.first_acc >= 0 || n < 1) return PLHIP_OK;
+  if (!forced && n < (1 << 20)) return PLHIP_OK;
+  order_accs_by_source(L);
+  int rc;
+  if (P.single_key && dk[0].validity) { // the partitioned copies carry no null flag: nulls become code 0 of a packed key
+    std::vector<KeyCol> one(1);
+    one[0].col = dk[0]; one[0].nullable = true;
+    if ((rc = measure_key_columns(one, n))) return rc;
+    if (one[0].bits > 64) return PLHIP_OK;
+    P.single_key = 0;
+    pack_keys(P, one);
+  }
+  const int key_bytes = packed_key_bytes(P, dk);
+  // ---- shape ---------------------------------------------------------------------------------------------------
+  const uint32_t pbits2 = n >= (1 << 22) ? 9u : 8u, np2 = 1u << pbits2;
+  auto runs_lds = [&](uint32_t lb) { return fast_table_bytes(P, lb, key_bytes); };
+  // A leaf workgroup is a chain of dependent round trips (run bounds, rows, output block): ~10 us however little it
+  // folds.  Small tables keep four or five leaves in flight per CU.
+  uint32_t lb_max = 13;
+  const char *dbg_kb = getenv("PLHIP_T2_KB"), *dbg_blk = getenv("PLHIP_T2_BLOCK"), *dbg_p1 = getenv("PLHIP_T2_PBITS1");
+  // (few rows per group: the leaves are all table, and fewer, larger leaves win; measured on config 3 and on q3 at 3e8 rows)
+  const size_t lds_budget = (size_t)(dbg_kb ? atoi(dbg_kb) : ((uint64_t)n / g_est >= 8 ? 32 : 76)) * 1024;
+  while (lb_max > 6 && runs_lds(lb_max) > lds_budget) lb_max--;
+  const double leaf_cap = 0.5 * (double)(1u << lb_max);
+  uint32_t pbits1 = 4;
+  while (pbits1 < 12 && (double)g_est * 1.3 / ((double)(1u << pbits1) * np2) + 8 > leaf_cap) pbits1++;
+  if ((double)g_est * 1.3 / ((double)(1u << pbits1) * np2) + 8 > leaf_cap) return PLHIP_OK;
+  if (dbg_p1 && (uint32_t)atoi(dbg_p1) > pbits1) pbits1 = (uint32_t)atoi(dbg_p1);
+  if (pbits1 + pbits2 + lb_max > 32) return PLHIP_OK; // the table's home slots come from the hash bits below the two levels
+  const uint32_t np1 = 1u << pbits1;
+  const double gf = (double)g_est * 1.3 / ((double)np1 * np2) + 8;
+  uint32_t lbits = 6;
+  while (lbits < lb_max && gf > 0.5 * (double)(1u << lbits)) lbits++;
+  while (lbits < lb_max && gf > 0.25 * (double)(1u << lbits)) lbits++; // sparser when it is free
+  const uint64_t n_pad = (uint64_t)n + (uint64_t)np1 * TS_TILE; // every partition rounded up to whole tiles
+  if (n_pad > 0xFFFFFFFFull) return PLHIP_OK;
+  const uint32_t n_tiles2 = (uint32_t)(n_pad / TS_TILE);
+  const uint32_t lslots = (1u << lbits) + 66;
+  const uint64_t n_items = (uint64_t)np1 * np2;
+  const uint64_t out_cap = std::min<uint64_t>((uint64_t)n, n_items * lslots);
+  // ---- scratch -------------------------------------------------------------------------------------------------
+  const int64_t tile_rows1 = (int64_t)PART_SCATTER_R * 1024;
+  const uint32_t n_tiles1 = (uint32_t)std::max<int64_t>(1, (n + tile_rows1 - 1) / tile_rows1);
+  size_t off_totals = (size_t)np1 * n_tiles1 * 4, off_start = off_totals + (size_t)np1 * 4;
+  size_t off_cnt = (off_start + (size_t)(np1 + 1) * 4 + 63) & ~(size_t)63;
+  HIP_TRY(c.items.reserve(off_cnt + 64));
+  uint8_t *sb = (uint8_t *)c.items.p;
+  uint32_t *counts = (uint32_t *)sb, *totals = (uint32_t *)(sb + off_totals), *pstart = (uint32_t *)(sb + off_start);
+  uint32_t *cnt = (uint32_t *)(sb + off_cnt);
+  PartOut A{}, B{};
+  A.key_bytes = B.key_bytes = (uint32_t)key_bytes;
+  size_t bytes = ((size_t)n_pad * key_bytes + 511) & ~(size_t)255;
+  size_t off_val[PLHIP_MAX_VALS], off_valid[PLHIP_MAX_VALS];
+  for (int v = 0; v < P.n_vals; v++) {
+    off_val[v] = bytes;
+    bytes += ((size_t)n_pad * dtype_width((int)P.vals[v].dtype) + 511) & ~(size_t)255;
+    off_valid[v] = bytes;
+    if (P.vals[v].validity) bytes += ((size_t)n_pad + 511) & ~(size_t)255;
+  }
+  HIP_TRY(c.part.reserve(bytes + 256));
+  HIP_TRY(c.dump.reserve(bytes + 256));
+  HIP_TRY(c.offs.reserve((size_t)(np2 + 2) * n_tiles2 * 4));
+  HIP_TRY(c.flags.reserve(64));
+  uint32_t *dflags = (uint32_t *)c.flags.p;
+  uint8_t *pa = (uint8_t *)c.part.p, *pb = (uint8_t *)c.dump.p;
+  A.keys = pa; B.keys = pb;
+  for (int v = 0; v < P.n_vals; v++) {
+    A.vals[v] = pa + off_val[v]; B.vals[v] = pb + off_val[v];
+    A.valid[v] = P.vals[v].validity ? pa + off_valid[v] : nullptr;
+    B.valid[v] = P.vals[v].validity ? pb + off_valid[v] : nullptr;
+  }
+  // ---- outputs ---------------------------------------------------------------------------------------------------
+  plhip_result *R = new (std::nothrow) plhip_result();
+  if (!R) return fail(PLHIP_ERR_OOM, "host allocation failed");
+  R->on_device = true; R->device = c.device;
+  OutPlan OP{};
+  OP.n_outs = (int)L.outs.size();
+  (void)hipGetLastError();
+  if (!c.flags_clean) HIP_TRY(hipMemsetAsync(dflags, 0, 64, c.stream));
+  c.flags_clean = false;
+  for (size_t i = 0; i < L.outs.size(); i++) {
+    OutSpec o = L.outs[i];
+    ResultCol col;
+    col.dtype = (int)o.dtype;
+    hipError_t e = g_pool.get((size_t)out_cap * dtype_width((int)o.dtype), &col.values, &col.vcap);
+    if (e == hipSuccess && o.validity) {
+      e = g_pool.get((size_t)(out_cap / 64 + 2) * 8, (void **)&col.validity, &col.bcap);
+      if (e == hipSuccess) e = hipMemsetAsync(col.validity, 0, (size_t)(out_cap / 64 + 2) * 8, c.stream);
+    }
+    R->cols.push_back(col);
+    if (e != hipSuccess) { delete R; return fail_hip(e, "hipMalloc(output)"); }
+    o.values = (uint8_t *)col.values; o.validity = col.validity;
+    OP.outs[i] = o;
+  }
+  if (++c.seq == 0) c.seq = 1;
+  const uint32_t seq = c.seq;
+  // ---- level 1 -----------------------------------------------------------------------------------------------------
+  hipEventRecord(c.ev[1], c.stream);
+  launch_part_hist(P, pbits1, tile_rows1, n_tiles1, counts, c.stream);
+  launch_part_scan(counts, np1, n_tiles1, totals, c.stream);
+  launch_part_plan(totals, np1, pstart, nullptr, cnt, cnt + 1, 1u << 30, c.stream, (uint32_t)TS_TILE);
+  launch_part_scatter(P, A, pbits1, tile_rows1, n_tiles1, counts, pstart, c.stream);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { delete R; return fail_hip(e, "level-1 partition launch"); }
+  // ---- level 2 -----------------------------------------------------------------------------------------------------
+  Plan P1 = P; // reads the level-1 copies: plain packed-key column, byte validity
+  P1.n_rows = (int64_t)n_pad;
+  P1.keys[0].values = A.keys; P1.keys[0].validity = nullptr; P1.keys[0].boff = 0;
+  for (int v = 0; v < P.n_vals; v++) { P1.vals[v].values = A.vals[v]; P1.vals[v].validity = A.valid[v]; P1.vals[v].boff = 0; P1.vals[v].valid_bytes = 1; }
+  TileSortLevel1 L1{pstart, totals, np1, pbits1};
+  launch_tile_sort(P1, B, pbits2, n_tiles2, (uint32_t *)c.offs.p, key_bytes == 4 ? 1 : 2, 0ull, key_bytes, c.stream, &L1);
+  if ((e = hipGetLastError()) != hipSuccess) { delete R; return fail_hip(e, "level-2 k_tile_sort launch"); }
+  hipEventRecord(c.ev[4], c.stream);
+  Plan P2 = P; // the key specs stay: the fold decodes the packed keys with them
+  for (int v = 0; v < P.n_vals; v++) { P2.vals[v].values = B.vals[v]; P2.vals[v].validity = B.valid[v]; P2.vals[v].boff = 0; P2.vals[v].valid_bytes = 1; }
+  FoldRunsArgs Af{};
+  Af.pkeys = B.keys; Af.out_cap = out_cap; Af.flags = dflags; Af.offs = (const uint32_t *)c.offs.p; Af.lbits = lbits; Af.np = np2; Af.w = 1;
+  Af.n_pg = np2; Af.has_null_pg = 0; Af.S = np1; Af.n_tiles = n_tiles2; Af.pbits = pbits1 + pbits2;
+  Af.host_sig = c.host_sig_dev; Af.seq = seq; Af.disjoint = 1; Af.seg_start = pstart;
+  launch_fold_runs(P2, Af, OP, key_bytes, dbg_blk ? (uint32_t)atoi(dbg_blk) : ((uint64_t)n / n_items >= 8192 ? 512u : 256u), c.stream);
+  if (getenv("PLHIP_T2_VERBOSE")) fprintf(stderr, "tilesort2: np1 %u np2 %u lbits %u lb_max %u table %zu B leaves %llu rows/leaf %llu\n", np1, np2, lbits, lb_max, fast_table_bytes(P, lbits, key_bytes), (unsigned long long)n_items, (unsigned long long)((uint64_t)n / n_items));
+  if ((e = hipGetLastError()) != hipSuccess) { delete R; return fail_hip(e, "leaf k_fold_runs launch"); }
+  hipEventRecord(c.ev[5], c.stream);
+  uint32_t fl[16] = {0};
+  TableRef t{nullptr, 0, dflags};
+  rc = wait_signal(t, seq, fl);
+  if (rc) { delete R; return rc; }
+  if (hipMemsetAsync(dflags, 0, 64, c.stream) == hipSuccess) c.flags_clean = true;
+  c.timing_pending = 2;
+  c.strategy = "tilesort2";
+  if (fl[FLAG_OVERFLOW]) { delete R; return PLHIP_OK; } // a leaf table overflowed (estimate too low / skew): the sort strategy redoes it
+  const uint64_t G = fl[FLAG_NGROUPS];
+  R->n_rows = (int64_t)G;
+  handled = true;
+  return finish_result(R, G, flags, out);
+}
+
 // The sort strategy (sort_path.hip): any number of groups, any skew; also serves wide key tuples (output keys
 // gathered at the first row of each run).  Declines stable order (the general path sorts groups by first row).
 // keys_sorted: the caller declared the single key column sorted (PLHIP_FLAG_KEYS_SORTED): no sort, groups are the
@@ -1111,7 +1266,7 @@ int32_t plhip_init(int32_t device_id) {
 const char *plhip_last_error(void) { return g_ctx.err.c_str(); }
 
 int32_t plhip_set_strategy(int32_t strategy) {
-  if (strategy < 0 || strategy > PLHIP_STRATEGY_SORT) return fail(PLHIP_ERR_INVALID, "bad strategy");
+  if (strategy < 0 || strategy > PLHIP_STRATEGY_TILESORT2) return fail(PLHIP_ERR_INVALID, "bad strategy");
   g_ctx.forced_strategy = strategy;
   return PLHIP_OK;
 }
@@ -1257,6 +1412,22 @@ int32_t group_by_agg_impl(const plhip_column_t *keys, int32_t n_keys, const plhi
     if (handled) return PLHIP_OK;
     // more groups than the LDS pipeline holds (or wide key tuples): sort instead of hammering HBM with atomics
     strategy = (n >= (1 << 16) && (g_seen > 4096 || L.KG.enabled)) ? PLHIP_STRATEGY_SORT : PLHIP_STRATEGY_AUTO;
+    if (strategy == PLHIP_STRATEGY_SORT && g_seen > 4096 && (uint64_t)n / g_seen >= 2) { // beyond one partition level: two
+      // levels before the sort (nearly all-unique keys: the two are on par, and the sort is immune to skew)
+      if ((rc = run_two_level(L, dk, flags, g_seen, false, out, handled))) return rc;
+      if (handled) return PLHIP_OK;
+    }
+  }
+  if (strategy == PLHIP_STRATEGY_TILESORT2) {
+    bool handled = false;
+    uint64_t g_est = (uint64_t)n;
+    int64_t hint = 0;
+    if (opts && opts->struct_size >= offsetof(plhip_options_t, n_groups_hint) + sizeof(int64_t)) hint = opts->n_groups_hint;
+    if (hint > 0) g_est = (uint64_t)std::min<int64_t>(hint, n);
+    else if (n >= (1 << 14) && (rc = estimate_groups(P, g_est))) return rc;
+    if ((rc = run_two_level(L, dk, flags, std::max<uint64_t>(g_est, 1), true, out, handled))) return rc;
+    if (handled) return PLHIP_OK;
+    strategy = PLHIP_STRATEGY_AUTO;
   }
   if (strategy == PLHIP_STRATEGY_SORT) {
     bool handled = false;

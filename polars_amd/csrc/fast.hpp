@@ -66,7 +66,8 @@ struct FoldRunsArgs {
   uint32_t pbits; // log2(np): the hash bits the tile sort consumed
   uint32_t *host_sig; // pinned host memory (device address): the last workgroup stores seq << 32 | overflow << 31 | groups
   uint32_t seq;       // there, the word the host spins on (nullptr: no signal)
-  uint32_t pad;
+  uint32_t disjoint;  // two-level pipeline: the S segments are level-1 partitions (disjoint in the keys): every workgroup emits
+  const uint32_t *seg_start; // ... and segment s covers the tiles [seg_start[s], seg_start[s + 1]) / TS_TILE (nullptr: equal split)
 };
 
 struct MergeArgs {
@@ -86,8 +87,15 @@ int fast_shape_id(const Plan &p); // index of the pre-instantiated shape the pla
 size_t fast_table_bytes(const Plan &p, uint32_t lbits, int key_bytes);  // LDS bytes of a fold / merge workgroup
 uint64_t fast_dump_stride(const Plan &p, uint32_t cap, int key_bytes);
 void launch_fold_rows(const Plan &p, const FoldRowsArgs &a, int key_bytes, bool quad, uint32_t n_items, uint32_t block, hipStream_t s);
+// Rows that belong to tile t = [t * TS_TILE, ...).  Level 2 of the two-level pipeline: `lvl1` describes the level-1
+// partitions the input consists of (tile-aligned starts, rows per partition) and the hash bits they consumed.
+struct TileSortLevel1 {
+  const uint32_t *part_start; // [np1 + 1], multiples of TS_TILE; nullptr: one flat input of P.n_rows rows
+  const uint32_t *part_rows;  // [np1]
+  uint32_t np1, pshift;       // pshift: hash bits consumed by level 1
+};
 void launch_tile_sort(const Plan &p, const PartOut &o, uint32_t pbits, uint32_t n_tiles, uint32_t *offs, int keymode, uint64_t kxor,
-                      int key_bytes, hipStream_t s);
+                      int key_bytes, hipStream_t s, const TileSortLevel1 *lvl1 = nullptr);
 void launch_fold_runs(const Plan &p2, const FoldRunsArgs &a, const OutPlan &o, int key_bytes, uint32_t block, hipStream_t s);
 void launch_merge_emit(const Plan &p, const MergeArgs &a, const OutPlan &o, int key_bytes, uint32_t n_pg, uint32_t block, hipStream_t s);
 // distinct keys among `n_sample` rows taken every `stride` rows -> flags[FLAG_NGROUPS]

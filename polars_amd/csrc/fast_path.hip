@@ -540,7 +540,7 @@ DEVINL void stage_and_store(uint8_t *stage, const T (&x)[TS_R], const uint32_t (
 #define TS_NPRE 2 // value columns requested together with the keys
 template <typename KS>
 __global__ void __launch_bounds__(TS_BLOCK) k_tile_sort(Plan P, PartOut O, uint32_t pbits, uint32_t n_tiles, uint32_t *__restrict__ offs,
-                                                        int keymode, uint64_t kxor) {
+                                                        int keymode, uint64_t kxor, TileSortLevel1 L1) {
   __shared__ __align__(16) uint32_t hist[(1 << TS_MAX_PBITS) + 4];
   __shared__ __align__(16) uint32_t tmp[TS_BLOCK / 64];
   const uint32_t np = 1u << pbits, nh = np + 1; // partition np holds the rows with a null key
@@ -548,7 +548,13 @@ __global__ void __launch_bounds__(TS_BLOCK) k_tile_sort(Plan P, PartOut O, uint3
   for (uint32_t p = tid; p < nh; p += TS_BLOCK) hist[p] = 0;
   lds_barrier();
   const int64_t r0 = (int64_t)tile * TS_TILE;
-  const uint32_t nt = (uint32_t)((P.n_rows - r0) < TS_TILE ? (P.n_rows - r0) : TS_TILE);
+  uint32_t nt = (uint32_t)((P.n_rows - r0) < TS_TILE ? (P.n_rows - r0) : TS_TILE);
+  if (L1.part_start) { // level 2: the tile lies inside one tile-aligned level-1 partition; rows behind the partition's end are padding
+    uint32_t lo = 0, hi = L1.np1; // largest p with part_start[p] <= r0
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if ((int64_t)L1.part_start[mid] <= r0) lo = mid; else hi = mid; }
+    const int64_t left = (int64_t)L1.part_start[lo] + (int64_t)L1.part_rows[lo] - r0;
+    nt = left <= 0 ? 0u : (left < TS_TILE ? (uint32_t)left : (uint32_t)TS_TILE);
+  }
   uint32_t row[TS_R], pos[TS_R];
   KS key[TS_R];
   uint32_t live = 0;
@@ -581,7 +587,7 @@ __global__ void __launch_bounds__(TS_BLOCK) k_tile_sort(Plan P, PartOut O, uint3
   for (int r = 0; r < TS_R; r++) {
     pos[r] = 0;
     if (!((live >> r) & 1)) continue;
-    const uint32_t p = ((nullm >> r) & 1) ? np : part_of(mix_key(key[r]), pbits);
+    const uint32_t p = ((nullm >> r) & 1) ? np : part_of(mix_key(key[r]) << L1.pshift, pbits);
     pos[r] = p | (atomicAdd(&hist[p], 1u) << 12);
   }
   lds_barrier();
@@ -653,7 +659,7 @@ __global__ void __launch_bounds__(TS_BLOCK) k_tile_sort(Plan P, PartOut O, uint3
 // ---------------------------------------------------------------------------------------------------------
 #define RUNS_NPRE 3
 // The group count reaches the host without a device-to-host copy: every workgroup of the query's last kernel
-// counts itself done (bit 16 up: "my table overflowed"); the last one writes the flags the host needs into pinned
+// counts itself done (after marking a table overflow, fenced: rare); the last one writes the flags the host needs into pinned
 // host memory as ONE 64-bit word (seq << 32 | overflow << 31 | groups) that the host is spinning on.  Only atomics carry the values (they
 // execute memory-side, no fence needed); the host still waits for the kernel's end before it hands the result
 // buffers on, so the output stores need no fence here either.
@@ -661,10 +667,10 @@ DEVINL void publish_done(uint32_t *flags, const uint32_t *sh, uint32_t *host_sig
   if (!host_sig) return;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const uint32_t ovf = sh[2] ? 0x10000u : 0u;
-    const uint32_t old = atomicAdd(&flags[FLAG_DONE], 1u + ovf);
-    if ((old & 0xFFFFu) == gridDim.x - 1) {
-      const uint32_t o = (((old + ovf) >> 16) ? 1u : 0u) | atomicAdd(&flags[FLAG_OVERFLOW], 0u); // earlier kernels' too
+    if (sh[2]) { atomicOr(&flags[FLAG_OVERFLOW], 1u); __threadfence(); } // (rare) the mark is in place before the count
+    const uint32_t old = atomicAdd(&flags[FLAG_DONE], 1u);
+    if (old == gridDim.x - 1) {
+      const uint32_t o = atomicAdd(&flags[FLAG_OVERFLOW], 0u); // this kernel's workgroups and earlier kernels'
       const uint32_t g = atomicAdd(&flags[FLAG_NGROUPS], 0u);
       // one 64-bit store carries everything: no ordering between host words to arrange
       __hip_atomic_store((uint64_t *)host_sig, ((uint64_t)seq << 32) | (o ? 0x80000000u : 0u) | (g & 0x7FFFFFFFu), __ATOMIC_RELAXED,
@@ -689,11 +695,13 @@ __global__ void __launch_bounds__(1024) k_fold_runs(Plan P, FoldRunsArgs A, OutP
     const uint32_t n8 = gridDim.x & ~7u;
     if (item < n8) item = (item & 7u) * (n8 >> 3) + (item >> 3);
   }
-  const uint32_t pg = item / A.S, seg = item % A.S;
+  // two-level pipeline: neighbouring sub-partitions of ONE level-1 partition (their runs are neighbours in memory) are neighbours here
+  const uint32_t pg = A.disjoint ? item % A.n_pg : item / A.S, seg = A.disjoint ? item / A.n_pg : item % A.S;
   const bool null_pg = A.has_null_pg && pg == A.n_pg - 1;
   const uint32_t p0 = null_pg ? A.np : pg * A.w, p1 = null_pg ? A.np + 1 : p0 + A.w;
   const uint32_t per = (A.n_tiles + A.S - 1) / A.S;
-  const uint32_t t0 = seg * per, t1 = t0 + per < A.n_tiles ? t0 + per : A.n_tiles;
+  uint32_t t0 = seg * per, t1 = t0 + per < A.n_tiles ? t0 + per : A.n_tiles;
+  if (A.seg_start) { t0 = A.seg_start[seg] / TS_TILE; t1 = A.seg_start[seg + 1] / TS_TILE; }
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const uint32_t *o0 = A.offs + (uint64_t)p0 * A.n_tiles, *o1 = A.offs + (uint64_t)p1 * A.n_tiles;
   constexpr int RUNS_B = SH::STATIC ? 8 : 4; // tiles per wave batch
@@ -736,7 +744,7 @@ __global__ void __launch_bounds__(1024) k_fold_runs(Plan P, FoldRunsArgs A, OutP
   __syncthreads();
   if (sh[2] && threadIdx.x == 0) A.flags[FLAG_OVERFLOW] = 1;
   uint16_t *list = (uint16_t *)(fsm + table_lds_bytes(P, lslots, sizeof(KS)));
-  if (A.S == 1) {
+  if (A.S == 1 || A.disjoint) {
     emit_table<KS>(P, fsm, A.lbits, sh, bk, list, O, A.flags, A.out_cap);
     publish_done(A.flags, sh, A.host_sig, A.seq);
   } else dump_table<KS>(P, fsm, A.lbits, 0, sh, bk, list, A.D, item);
@@ -985,12 +993,13 @@ void launch_fold_rows(const Plan &p, const FoldRowsArgs &a, int key_bytes, bool 
 }
 
 void launch_tile_sort(const Plan &p, const PartOut &o, uint32_t pbits, uint32_t n_tiles, uint32_t *offs, int keymode, uint64_t kxor,
-                      int key_bytes, hipStream_t s) {
+                      int key_bytes, hipStream_t s, const TileSortLevel1 *lvl1) {
+  const TileSortLevel1 l1 = lvl1 ? *lvl1 : TileSortLevel1{nullptr, nullptr, 0u, 0u};
   static bool once = false;
   if (!once) { allow_big_lds(k_tile_sort<uint32_t>); allow_big_lds(k_tile_sort<uint64_t>); once = true; }
   const size_t bytes = (size_t)TS_TILE * 8;
-  if (key_bytes == 4) hipLaunchKernelGGL(k_tile_sort<uint32_t>, dim3(n_tiles), dim3(TS_BLOCK), bytes, s, p, o, pbits, n_tiles, offs, keymode, kxor);
-  else hipLaunchKernelGGL(k_tile_sort<uint64_t>, dim3(n_tiles), dim3(TS_BLOCK), bytes, s, p, o, pbits, n_tiles, offs, keymode, kxor);
+  if (key_bytes == 4) hipLaunchKernelGGL(k_tile_sort<uint32_t>, dim3(n_tiles), dim3(TS_BLOCK), bytes, s, p, o, pbits, n_tiles, offs, keymode, kxor, l1);
+  else hipLaunchKernelGGL(k_tile_sort<uint64_t>, dim3(n_tiles), dim3(TS_BLOCK), bytes, s, p, o, pbits, n_tiles, offs, keymode, kxor, l1);
 }
 
 template <typename KS, typename SH>

@@ -44,7 +44,7 @@ void launch_lds_agg2(const Plan &p, TableRef t, const WorkItem *items, const uin
 void launch_part_hist(const Plan &p, uint32_t pbits, int64_t tile_rows, uint32_t n_tiles, uint32_t *counts, hipStream_t s);
 void launch_part_scan(uint32_t *counts, uint32_t np, uint32_t n_tiles, uint32_t *totals, hipStream_t s);
 void launch_part_plan(const uint32_t *totals, uint32_t np, uint32_t *part_start, WorkItem *items, uint32_t *n_items,
-                      uint32_t *next_item, uint32_t split_rows, hipStream_t s);
+                      uint32_t *next_item, uint32_t split_rows, hipStream_t s, uint32_t align = 1);
 void launch_part_scatter(const Plan &p, const PartOut &o, uint32_t pbits, int64_t tile_rows, uint32_t n_tiles,
                          const uint32_t *offs, const uint32_t *part_start, hipStream_t s);
 

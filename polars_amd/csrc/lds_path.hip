@@ -486,14 +486,16 @@ __global__ void __launch_bounds__(256) k_part_scan(uint32_t *__restrict__ counts
 }
 
 // single workgroup: partition starts (exclusive scan of totals) + the aggregation pass's work items
+// `align` (a power of two, 1 = packed): every partition starts at a multiple of it (the two-level pipeline runs
+// whole 8192-row tiles inside each partition); items may be nullptr then.
 __global__ void __launch_bounds__(1024) k_part_plan(const uint32_t *__restrict__ totals, uint32_t np, uint32_t *__restrict__ part_start,
                                                     WorkItem *__restrict__ items, uint32_t *__restrict__ n_items, uint32_t *next_item,
-                                                    uint32_t split_rows) {
+                                                    uint32_t split_rows, uint32_t align) {
   __shared__ uint32_t sums[1024];
   const uint32_t chunk = (np + 1023) / 1024;
   const uint32_t b = threadIdx.x * chunk, e = b + chunk < np ? b + chunk : np;
   uint32_t s = 0;
-  for (uint32_t i = b; i < e; i++) s += totals[i];
+  for (uint32_t i = b; i < e; i++) s += (totals[i] + align - 1) & ~(align - 1);
   sums[threadIdx.x] = s;
   __syncthreads();
   for (int off = 1; off < 1024; off <<= 1) {
@@ -508,7 +510,7 @@ __global__ void __launch_bounds__(1024) k_part_plan(const uint32_t *__restrict__
   for (uint32_t p = b; p < e; p++) {
     const uint32_t n = totals[p];
     part_start[p] = run;
-    if (n) {
+    if (n && items) {
       if (n <= split_rows) {
         const uint32_t k = atomicAdd(n_items, 1u);
         items[k] = WorkItem{(int64_t)run, (int64_t)run + n, 1u, 0u};
@@ -522,7 +524,7 @@ __global__ void __launch_bounds__(1024) k_part_plan(const uint32_t *__restrict__
         }
       }
     }
-    run += n;
+    run += (n + align - 1) & ~(align - 1);
   }
   if (threadIdx.x == 1023) part_start[np] = sums[1023];
 }
@@ -680,8 +682,8 @@ void launch_part_scan(uint32_t *counts, uint32_t np, uint32_t n_tiles, uint32_t 
   hipLaunchKernelGGL(k_part_scan, dim3(np), dim3(256), 0, s, counts, n_tiles, totals);
 }
 void launch_part_plan(const uint32_t *totals, uint32_t np, uint32_t *part_start, WorkItem *items, uint32_t *n_items,
-                      uint32_t *next_item, uint32_t split_rows, hipStream_t s) {
-  hipLaunchKernelGGL(k_part_plan, dim3(1), dim3(1024), 0, s, totals, np, part_start, items, n_items, next_item, split_rows);
+                      uint32_t *next_item, uint32_t split_rows, hipStream_t s, uint32_t align) {
+  hipLaunchKernelGGL(k_part_plan, dim3(1), dim3(1024), 0, s, totals, np, part_start, items, n_items, next_item, split_rows, align);
 }
 // tile_rows must be PART_SCATTER_R * PART_BLOCK or less (the tile is sorted in LDS)
 void launch_part_scatter(const Plan &p, const PartOut &o, uint32_t pbits, int64_t tile_rows, uint32_t n_tiles,

@@ -12,7 +12,7 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 KA = util.load_known_answers()
-STRATEGIES = ["auto", "global", "lds", "partitioned", "direct", "tilesort", "sort"]
+STRATEGIES = ["auto", "global", "lds", "partitioned", "direct", "tilesort", "sort", "tilesort2"]
 
 
 @pytest.fixture(autouse=True)
@@ -92,7 +92,7 @@ def check_parity(oracle, keys, values, aggs, strategy="auto", maintain_order=Fal
     want, _ = oracle.group_by_agg(keys, values, aggs, maintain_order=maintain_order)
     got = run_product(keys, values, aggs, maintain_order, strategy)
     ran = pa.last_strategy()
-    if strategy in ("direct", "tilesort", "sort") and ran != strategy:
+    if strategy in ("direct", "tilesort", "sort", "tilesort2") and ran != strategy:
         FELL_BACK.append((what, strategy, ran))
     g, w = util.frame_to_np(got), util.oracle_to_np(want)
     if maintain_order:  # row order itself is part of the contract
@@ -110,7 +110,7 @@ def test_zz_fast_path_coverage():
     """The forced LDS-only strategies may decline (stable order, wide key tuples, more groups than fit);
     they must not decline the plain cases."""
     allowed = {"direct": ("multi-key", "stable", "card=None", "n=0"), "tilesort": ("multi-key", "stable", "card=None", "n=0"),
-               "sort": ("stable", "n=0")}
+               "sort": ("stable", "n=0"), "tilesort2": ("multi-key", "stable", "card=None", "n=0")}
     bad = [w for w, s, _ in FELL_BACK if not any(w.startswith(a) or a in w for a in allowed[s])]
     assert not bad, f"fast path declined: {sorted(bad)}"
 
@@ -772,15 +772,22 @@ def test_wrong_hints_cost_time_not_correctness(oracle):
         util.assert_frames_match(got, util.oracle_to_np(want), 1, what=f"hint {h} via {pa.last_strategy()}")
 
 
-def test_high_cardinality_properties():
+@pytest.mark.parametrize("strategy", ["tilesort2", "sort"])
+def test_high_cardinality_properties(strategy):
     """BASELINE config 3 shape at 2e7 rows (three i64 keys, nearly all-unique tuples): properties that do not
-    need a second implementation at this size."""
+    need a second implementation at this size, for both strategies of that regime (with about one row per group
+    AUTO sorts; from two rows per group on it takes the two partition levels)."""
     import torch
 
     n = 20_000_000
     tensors, keys, vals, aggs, _ = _bench_frame("c3", n)
+    pa.set_strategy(strategy)
     got = _run_raw(keys, vals, aggs, 0)
-    assert pa.last_strategy() == "sort"
+    assert pa.last_strategy() == strategy
+    if strategy == "sort":  # nearly all-unique keys: AUTO's choice
+        pa.set_strategy("auto")
+        got = _run_raw(keys, vals, aggs, 0)
+        assert pa.last_strategy() == "sort"
     k1, k2, k3 = (got[i][0] for i in range(3))
     s1, mn, mx, s3, mean3, cnt = (got[3 + i][0] for i in range(6))
     assert int(cnt.astype(np.int64).sum()) == n                                        # counts add up to N
@@ -794,6 +801,31 @@ def test_high_cardinality_properties():
     assert (mn <= mx).all() and np.allclose(mean3 * cnt, s3, rtol=1e-12)
     one = cnt == 1                                                                     # single-row groups: sum = min = max
     assert (s1[one] == mn[one]).all() and (mn[one] == mx[one]).all()
+
+
+def test_two_levels_vs_oracle_mid_size(oracle):
+    """TILESORT2 against the oracle where the oracle still finishes in seconds: 6e6 rows, ~1.9e6 groups (beyond one
+    partition level), a nullable i64 key, nullable f64 values; forced, and as AUTO's own choice."""
+    rng = np.random.default_rng(83)
+    n = 6_000_000
+    keys = [rand_col(rng, "k", np.int64, n, card=2_000_000, null_frac=0.001)]
+    values = [rand_col(rng, "a", np.int32, n, lo=-1000, hi=1000), rand_col(rng, "b", np.float64, n, null_frac=0.1)]
+    aggs = [(0, "sum"), (1, "mean"), (0, "min"), (1, "max"), (0, "count")]
+    for strategy in ("tilesort2", "auto"):
+        check_parity(oracle, keys, values, aggs, strategy, what=f"two levels {strategy}")
+        assert pa.last_strategy() == "tilesort2"
+
+
+def test_two_levels_skew_falls_back(oracle):
+    """A heavy key plus many light ones: if a leaf table overflows the query is redone by the sort strategy;
+    either way the result is the oracle's."""
+    rng = np.random.default_rng(89)
+    n = 2_000_000
+    k = rng.integers(0, 1_000_000, n).astype(np.int64)
+    k[rng.random(n) < 0.3] = 7
+    keys = [Column("k", k)]
+    values = [rand_col(rng, "a", np.int64, n, lo=-1000, hi=1000)]
+    check_parity(oracle, keys, values, [(0, "sum"), (0, "count"), (0, "max")], "tilesort2", what="two levels skew")
 
 
 # ---------------------------------------------------------------------------------------------------
