@@ -82,8 +82,15 @@ typedef enum plhip_agg_kind {
   PLHIP_AGG_MEAN = 1,  /* aggregations/mod.rs:701-779 (float), 941-1016 (int) */
   PLHIP_AGG_MIN = 2,   /* aggregations/mod.rs:459-537 */
   PLHIP_AGG_MAX = 3,   /* aggregations/mod.rs:539-620 */
-  PLHIP_AGG_COUNT = 4  /* proxy.rs:452-466: group length INCLUDING nulls, as IdxSize (u32) */
+  PLHIP_AGG_COUNT = 4, /* proxy.rs:452-466: group length INCLUDING nulls, as IdxSize (u32) */
+  /* over CSR groups only (plhip_agg_groups): */
+  PLHIP_AGG_FIRST = 5, /* value (null or not) at the group's first index; empty group -> null (dispatch.rs:48-100) */
+  PLHIP_AGG_LAST = 6,  /* ... at its last index */
+  PLHIP_AGG_VAR = 7,   /* online_variance over the valid values as f64 (crates/polars-arrow/src/kernels/take_agg/var.rs:11-40;
+                          aggregations/mod.rs:781-803,1018-1035): f32 -> f32, everything else -> f64; count <= ddof -> null */
+  PLHIP_AGG_STD = 8    /* sqrt of it (aggregations/mod.rs:841-862,1059-1077) */
 } plhip_agg_kind_t;
+#define PLHIP_AGG_DDOF(d) ((uint32_t)(d) << 8) /* delta degrees of freedom for VAR / STD, in plhip_agg_groups' flags */
 
 typedef struct plhip_agg {
   int32_t column; /* index into the `values` array; ignored for COUNT */
@@ -242,9 +249,10 @@ int32_t plhip_groups_buffers(const plhip_groups_t *g, const uint32_t **first, co
                              const uint32_t **indices, int32_t *location);
 void plhip_groups_free(plhip_groups_t *g);
 
-/* Series::agg_sum / agg_mean / agg_min / agg_max on GroupsProxy::Idx
- * (crates/polars-core/src/series/series_trait.rs:129-154, aggregations/mod.rs:459-779,941-1016) and
- * GroupsProxy::group_count (proxy.rs:452-466) for kind == COUNT (values may be NULL then).
+/* Series::agg_sum / agg_mean / agg_min / agg_max / agg_first / agg_last / agg_var / agg_std on GroupsProxy::Idx
+ * (crates/polars-core/src/series/series_trait.rs:129-154, aggregations/mod.rs:459-1077, dispatch.rs:48-100) and
+ * GroupsProxy::group_count (proxy.rs:452-466) for kind == COUNT (values may be NULL then).  VAR / STD take their
+ * ddof from flags (PLHIP_AGG_DDOF).
  * Returns a one-column result frame with G rows. */
 int32_t plhip_agg_groups(const plhip_column_t *values, int32_t kind, const plhip_groups_t *groups,
                          uint32_t flags, plhip_result_t **out);

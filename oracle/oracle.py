@@ -171,3 +171,41 @@ def sorted_key_groups(key: Column) -> list[list[int]]:
     if not nulls_first and null_count > 0:
         out.append([len(v), null_count])
     return out
+
+
+def agg_ext(values: Column, kind: str, groups: Groups, ddof: int = 1):
+    """first / last / var / std over GroupsProxy::Idx, restated in plain Python (small inputs only):
+    agg_first / agg_last (crates/polars-core/src/frame/group_by/aggregations/dispatch.rs:47-76: the value, null
+    or not, at the group's first / last index; empty group -> null) and agg_var / agg_std (aggregations/mod.rs:
+    781-803, 841-862, 1018-1077) over online_variance (crates/polars-arrow/src/kernels/take_agg/var.rs:11-40):
+    valid values as f64 in index order, None when count <= ddof; f32 columns answer in f32, the rest in f64.
+    Returns (values ndarray, valid bool ndarray)."""
+    vals = values.to_numpy()
+    mask = values.valid_mask()
+    G = groups.n_groups
+    if kind in ("first", "last"):
+        out = np.zeros(G, dtype=vals.dtype)
+        valid = np.zeros(G, dtype=bool)
+        for g, idx in enumerate(groups.lists()):
+            if idx:
+                r = idx[0] if kind == "first" else idx[-1]
+                if mask is None or mask[r]:
+                    out[g], valid[g] = vals[r], True
+        return out, valid
+    out = np.zeros(G, dtype=np.float32 if vals.dtype == np.float32 else np.float64)
+    valid = np.zeros(G, dtype=bool)
+    for g, idx in enumerate(groups.lists()):
+        m2 = mean = 0.0
+        count = 0
+        for r in idx:
+            if mask is not None and not mask[r]:
+                continue
+            value = float(vals[r])
+            count += 1
+            delta_1 = value - mean
+            mean = delta_1 / count + mean
+            m2 += delta_1 * (value - mean)
+        if idx and count > ddof:
+            v = m2 / (count - ddof)
+            out[g], valid[g] = (v ** 0.5 if kind == "std" else v), True
+    return out, valid

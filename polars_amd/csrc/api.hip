@@ -1709,7 +1709,7 @@ int32_t plhip_agg_groups(const plhip_column_t *values, int32_t kind, const plhip
   if (!out) return fail(PLHIP_ERR_INVALID, "out is NULL");
   *out = nullptr;
   if (!groups) return fail(PLHIP_ERR_INVALID, "groups handle is NULL");
-  if (kind < 0 || kind > PLHIP_AGG_COUNT) return fail(PLHIP_ERR_INVALID, "bad aggregation kind");
+  if (kind < 0 || kind > PLHIP_AGG_STD) return fail(PLHIP_ERR_INVALID, "bad aggregation kind");
   if (kind != PLHIP_AGG_COUNT && !values) return fail(PLHIP_ERR_INVALID, "values is NULL");
   if (values && kind != PLHIP_AGG_COUNT && values->length != groups->n_rows)
     return fail(PLHIP_ERR_SHAPE_MISMATCH, "the column and the groups differ in length");
@@ -1718,6 +1718,42 @@ int32_t plhip_agg_groups(const plhip_column_t *values, int32_t kind, const plhip
   Ctx &c = g_ctx;
   const uint64_t G = (uint64_t)groups->n_groups;
   const int64_t n = groups->n_rows;
+  if (kind >= PLHIP_AGG_FIRST) { // first / last / var / std: their own kernel
+    Staging st;
+    DevCol dv;
+    if ((rc = stage_column(*values, dv, st, c.stream))) return rc;
+    const uint32_t *offsets = groups->offsets, *indices = groups->indices;
+    if (!groups->on_device) {
+      void *d_off = nullptr, *d_idx = nullptr;
+      HIP_TRY(hipMalloc(&d_off, (G + 1) * 4));
+      st.owned.push_back(d_off);
+      HIP_TRY(hipMalloc(&d_idx, (size_t)std::max<int64_t>(n, 1) * 4));
+      st.owned.push_back(d_idx);
+      HIP_TRY(hipMemcpyAsync(d_off, groups->offsets, (G + 1) * 4, hipMemcpyHostToDevice, c.stream));
+      if (n) HIP_TRY(hipMemcpyAsync(d_idx, groups->indices, (size_t)n * 4, hipMemcpyHostToDevice, c.stream));
+      offsets = (const uint32_t *)d_off; indices = (const uint32_t *)d_idx;
+    }
+    const bool moment = kind == PLHIP_AGG_VAR || kind == PLHIP_AGG_STD;
+    plhip_result *R = new (std::nothrow) plhip_result();
+    if (!R) return fail(PLHIP_ERR_OOM, "host allocation failed");
+    R->n_rows = (int64_t)G; R->on_device = true; R->device = c.device;
+    ResultCol col;
+    col.dtype = moment ? (dv.dtype == PLHIP_F32 ? PLHIP_F32 : PLHIP_F64) : dv.dtype; // aggregations/mod.rs:781-803, 1018-1035
+    hipError_t e = hipMalloc(&col.values, (size_t)std::max<uint64_t>(G, 1) * dtype_width(col.dtype));
+    if (e == hipSuccess) e = hipMalloc((void **)&col.validity, (G / 64 + 1) * 8);
+    if (e == hipSuccess) e = hipMemsetAsync(col.validity, 0, (G / 64 + 1) * 8, c.stream);
+    R->cols.push_back(col);
+    if (e != hipSuccess) { delete R; return fail_hip(e, "hipMalloc(output)"); }
+    AggExtArgs A{};
+    A.values = dv.values; A.validity = dv.validity; A.boff = dv.boff; A.dtype = (uint32_t)dv.dtype; A.width = (uint32_t)dtype_width(dv.dtype);
+    A.kind = (uint32_t)kind; A.ddof = (flags >> 8) & 0xFFu; A.out_dtype = (uint32_t)col.dtype;
+    A.out = (uint8_t *)col.values; A.out_validity = col.validity;
+    launch_agg_groups_ext(A, offsets, indices, G, moment && G > 0 && (uint64_t)n / G >= 64, c.stream);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
+    if (e != hipSuccess) { delete R; return fail_hip(e, "agg_groups"); }
+    return finish_result(R, G, flags & PLHIP_FLAG_OUTPUT_DEVICE, out);
+  }
   Staging st;
   std::vector<DevCol> dv;
   if (kind != PLHIP_AGG_COUNT) {

@@ -408,6 +408,87 @@ __global__ void __launch_bounds__(256) k_agg_groups(Plan P, OutPlan O, const uin
   if (S.validity) atomicOr((unsigned int *)S.validity + (g >> 5), valid ? 1u << (g & 31) : 0u);
 }
 
+// first / last / var / std over CSR groups.  first / last: the value (null or not) at the group's
+// first / last index (crates/polars-core/src/frame/group_by/aggregations/agg_list.rs and dispatch.rs: take by
+// `first` / the last index of `all`).  var / std: online_variance (crates/polars-arrow/src/kernels/take_agg/
+// var.rs:11-40), nulls skipped, values as f64, None when count <= ddof; a thread walks a short group in index order
+// (the reference's own update sequence), a wave walks a long one 64 rows at a time and merges the lanes' (count,
+// mean, M2) triples pairwise (Chan et al.).
+DEVINL double value_as_f64(const uint8_t *p, uint32_t dtype, int64_t row) {
+  switch (dtype) {
+    case PLHIP_I8: return (double)((const int8_t *)p)[row];
+    case PLHIP_I16: return (double)((const int16_t *)p)[row];
+    case PLHIP_I32: return (double)((const int32_t *)p)[row];
+    case PLHIP_I64: return (double)((const int64_t *)p)[row];
+    case PLHIP_U8: return (double)p[row];
+    case PLHIP_U16: return (double)((const uint16_t *)p)[row];
+    case PLHIP_U32: return (double)((const uint32_t *)p)[row];
+    case PLHIP_U64: return (double)((const uint64_t *)p)[row];
+    case PLHIP_F32: return (double)((const float *)p)[row];
+    default: return ((const double *)p)[row];
+  }
+}
+
+template <bool WAVE>
+__global__ void __launch_bounds__(256) k_agg_groups_ext(AggExtArgs A, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ indices,
+                                                        uint64_t G) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t g = WAVE ? t >> 6 : t;
+  const uint32_t lane = threadIdx.x & 63;
+  const bool live = g < G;
+  const uint32_t b = live ? offsets[g] : 0, e = live ? offsets[g + 1] : 0;
+  bool valid = false;
+  if (A.kind == AGG_EXT_FIRST || A.kind == AGG_EXT_LAST) {
+    if (WAVE && lane != 0) return;
+    if (!live) return;
+    if (e > b) {
+      const int64_t row = indices[A.kind == AGG_EXT_FIRST ? b : e - 1];
+      valid = bit_valid(A.validity, A.boff, row);
+      const uint32_t w = A.width;
+      for (uint32_t i = 0; i < w; i++) A.out[g * w + i] = valid ? A.values[(uint64_t)row * w + i] : 0;
+    } else {
+      for (uint32_t i = 0; i < A.width; i++) A.out[g * A.width + i] = 0;
+    }
+  } else {
+    double mean = 0.0, m2 = 0.0, cnt = 0.0;
+    for (uint32_t i = b + (WAVE ? lane : 0); i < e; i += (WAVE ? 64 : 1)) {
+      const int64_t row = indices[i];
+      if (!bit_valid(A.validity, A.boff, row)) continue;
+      const double v = value_as_f64(A.values, A.dtype, row);
+      cnt += 1.0;
+      const double d1 = v - mean;
+      mean = d1 / cnt + mean;
+      m2 += d1 * (v - mean);
+    }
+    if (WAVE) {
+      for (int off = 32; off > 0; off >>= 1) {
+        const double c2 = __shfl_xor(cnt, off), mean2 = __shfl_xor(mean, off), m22 = __shfl_xor(m2, off);
+        const double ct = cnt + c2;
+        if (ct > 0.0) {
+          const double d = mean2 - mean;
+          m2 = m2 + m22 + d * d * (cnt * c2 / ct);
+          mean = mean + d * (c2 / ct);
+        }
+        cnt = ct;
+      }
+      if (lane != 0) return;
+    }
+    if (!live) return;
+    valid = e > b && cnt > (double)A.ddof;
+    double r = valid ? m2 / (cnt - (double)A.ddof) : 0.0;
+    if (A.kind == AGG_EXT_STD) r = sqrt(r);
+    if (A.out_dtype == PLHIP_F32) ((float *)A.out)[g] = (float)r;
+    else ((double *)A.out)[g] = r;
+  }
+  if (valid) atomicOr((unsigned int *)A.out_validity + (g >> 5), 1u << (g & 31)); // zeroed bitmap
+}
+
+void launch_agg_groups_ext(const AggExtArgs &a, const uint32_t *offsets, const uint32_t *indices, uint64_t G, bool wave, hipStream_t s) {
+  if (!G) return;
+  if (wave) hipLaunchKernelGGL(k_agg_groups_ext<true>, dim3((unsigned)((G * 64 + 255) / 256)), dim3(256), 0, s, a, offsets, indices, G);
+  else hipLaunchKernelGGL(k_agg_groups_ext<false>, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, s, a, offsets, indices, G);
+}
+
 void launch_agg_groups(const Plan &p, const OutPlan &o, const uint32_t *offsets, const uint32_t *indices, uint64_t G, bool wave, hipStream_t s) {
   if (!G) return;
   if (wave) hipLaunchKernelGGL(k_agg_groups<true>, dim3((unsigned)((G * 64 + 255) / 256)), dim3(256), 0, s, p, o, offsets, indices, G);

@@ -74,6 +74,21 @@ void launch_csr(const uint32_t *ids_sorted, const uint32_t *indices, uint64_t n,
 // `o.outs[0]` is the one output column; at most 4 accumulators; o.outs[0].validity must be zeroed
 void launch_agg_groups(const Plan &p, const OutPlan &o, const uint32_t *offsets, const uint32_t *indices, uint64_t G, bool wave, hipStream_t s);
 
+// first / last / var / std over CSR groups
+#define AGG_EXT_FIRST 5
+#define AGG_EXT_LAST 6
+#define AGG_EXT_VAR 7
+#define AGG_EXT_STD 8
+struct AggExtArgs {
+  const uint8_t *values;
+  const uint8_t *validity; // LSB-first bitmap or nullptr
+  int64_t boff;
+  uint32_t dtype, width, kind, ddof, out_dtype, pad;
+  uint8_t *out;
+  uint8_t *out_validity; // zeroed bitmap
+};
+void launch_agg_groups_ext(const AggExtArgs &a, const uint32_t *offsets, const uint32_t *indices, uint64_t G, bool wave, hipStream_t s);
+
 // sort strategy (sort_path.hip)
 hipError_t sort_path_temp_bytes(uint64_t n, int end_bit, size_t *bytes);
 hipError_t launch_sort_groups(const Plan &p, uint64_t *keys_a, uint64_t *keys_b, uint32_t *rows_a, uint32_t *rows_b, uint32_t *flags,

@@ -216,6 +216,38 @@ class GroupBy:
     def count(self) -> DataFrame:
         return self._eager("count")
 
+    def _two_step(self, kind: str, suffix: str, ddof: int = 1) -> DataFrame:
+        """The eager GroupBy's non-fused aggregations (group_by/mod.rs:498-662): groups first (GroupsProxy), then one
+        agg_* per selected column over them; keys = each key column taken at the groups' first rows (keys_sliced,
+        mod.rs:250-297); output names as fmt_group_by_column (mod.rs:889-909)."""
+        names = self.selection if self.selection is not None else [c for c in self.df.columns if c not in self.by]
+        g = self.groups()
+        try:
+            cols = []
+            for k in self.by:
+                c = agg_groups(self.df.get_column(k), "first", g)
+                c.name = k
+                cols.append(c)
+            for n in names:
+                c = agg_groups(self.df.get_column(n), kind, g, ddof=ddof)
+                c.name = f"{n}_{suffix}"
+                cols.append(c)
+        finally:
+            g.close()
+        return DataFrame(cols)
+
+    def first(self) -> DataFrame:
+        return self._two_step("first", "first")
+
+    def last(self) -> DataFrame:
+        return self._two_step("last", "last")
+
+    def var(self, ddof: int = 1) -> DataFrame:
+        return self._two_step("var", "agg_var", ddof)
+
+    def std(self, ddof: int = 1) -> DataFrame:
+        return self._two_step("std", "agg_std", ddof)
+
 
 class LazyFrame:
     def __init__(self, df: DataFrame):
@@ -405,13 +437,14 @@ def group_tuples(keys: Sequence[Column], sorted_: bool = False, location: int = 
     return Groups(h)
 
 
-def agg_groups(values: Column | None, kind: str, groups: Groups) -> Column:
-    """Series::agg_sum/mean/min/max on GroupsProxy::Idx and GroupsProxy::group_count (kind='count')
-    through plhip_agg_groups.  Returns the one output column (host)."""
+def agg_groups(values: Column | None, kind: str, groups: Groups, ddof: int = 1) -> Column:
+    """Series::agg_sum/mean/min/max/first/last/var/std on GroupsProxy::Idx and GroupsProxy::group_count
+    (kind='count') through plhip_agg_groups.  Returns the one output column (host).  `ddof`: var / std."""
     L = _ffi.lib()
     h = C.c_void_p()
     vs = C.byref(values.struct()) if values is not None else None
-    _ffi.check(L.plhip_agg_groups(vs, _ffi.AGG_NAMES[kind], groups._h, 0, C.byref(h)))
+    code = _ffi.AGG_NAMES[kind] if kind in _ffi.AGG_NAMES else _ffi.AGG_GROUPS_ONLY[kind]
+    _ffi.check(L.plhip_agg_groups(vs, code, groups._h, (int(ddof) & 0xFF) << 8, C.byref(h)))
     try:
         cs = _ffi.ColumnStruct()
         _ffi.check(L.plhip_result_column(h, 0, C.byref(cs)))

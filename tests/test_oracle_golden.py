@@ -70,3 +70,19 @@ def test_sorted_key_groups_compare_values_not_bits(oracle):
     nan = float("nan")
     got = oracle.sorted_key_groups(Column("f", np.array([-0.0, 0.0, 1.5, 1.5, nan, nan], dtype=np.float64)))
     assert got == [[0, 2], [2, 2], [4, 1], [5, 1]]
+
+
+def test_agg_ext_known_answers(oracle):
+    """test_group_by_var (crates/polars-core/src/frame/group_by/mod.rs:1134-1156): int [1, 2 | 3] by [foo, foo | bar]
+    -> var(1) = 0.5 for foo, std(1) = 1/sqrt(2); the one-row group has count <= ddof -> null."""
+    from polars_amd.column import Column
+
+    g = oracle.Groups([Column("g", np.array([7, 7, 9], dtype=np.int32))], True)
+    v, m = oracle.agg_ext(Column("int", np.array([1, 2, 3], dtype=np.int32)), "var", g, 1)
+    assert v.dtype == np.float64 and m.tolist() == [True, False] and v[0] == 0.5
+    v, m = oracle.agg_ext(Column("int", np.array([1, 2, 3], dtype=np.int32)), "std", g, 1)
+    assert abs(v[0] - 2 ** -0.5) < 1e-15 and m.tolist() == [True, False]
+    v, m = oracle.agg_ext(Column("x", np.array([5, 6, 8], dtype=np.int64), np.array([False, True, True])), "first", g)
+    assert m.tolist() == [False, True] and v[1] == 8
+    v, m = oracle.agg_ext(Column("x", np.array([5, 6, 8], dtype=np.int64), np.array([False, True, True])), "last", g)
+    assert m.tolist() == [True, True] and v.tolist() == [6, 8]

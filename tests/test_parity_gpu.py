@@ -372,6 +372,53 @@ def test_agg_groups_left_fold_is_bit_exact(oracle):
         assert np.array_equal(gv.view(np.uint64), wv.view(np.uint64)), kind
 
 
+@pytest.mark.parametrize("dt", [np.int32, np.uint64, np.float32, np.float64])
+def test_agg_groups_first_last_var_std(oracle, dt):
+    """first / last / var / std over CSR groups against the oracle's restatement of
+    dispatch.rs:47-76 and take_agg/var.rs:11-40; short groups (thread per group: the reference's own update
+    order) and long ones (wave per group, pairwise merge)."""
+    rng = np.random.default_rng(97)
+    for n, card in ((20000, 3000), (60000, 40)):
+        keys = [rand_col(rng, "k", np.int64, n, card=card)]
+        v = rand_col(rng, "v", dt, n, null_frac=0.15, lo=0 if np.dtype(dt).kind != "f" else None, hi=1000 if np.dtype(dt).kind != "f" else None)
+        g_o, g_p = oracle.Groups(keys, True), pa.group_tuples(keys, True)
+        for kind in ("first", "last", "var", "std"):
+            for ddof in ((0, 1, 2) if kind in ("var", "std") else (1,)):
+                wv, wm = oracle.agg_ext(v, kind, g_o, ddof)
+                got = pa.agg_groups(v, kind, g_p, ddof=ddof)
+                gv, gm = got.to_numpy(), got.valid_mask()
+                gm = np.ones(len(gv), bool) if gm is None else gm
+                assert gv.dtype == wv.dtype and np.array_equal(gm, wm), (kind, ddof)
+                if kind in ("first", "last"):
+                    assert np.array_equal(gv[gm].view(np.uint8), wv[wm].view(np.uint8)), kind
+                else:
+                    np.testing.assert_allclose(gv[gm].astype(np.float64), wv[wm].astype(np.float64),
+                                               rtol=1e-5 if gv.dtype == np.float32 else 1e-11, atol=0, err_msg=f"{kind} ddof={ddof}")
+
+
+def test_eager_group_by_var_std_first_last():
+    # test_group_by_var (crates/polars-core/src/frame/group_by/mod.rs:1134-1156) through the eager GroupBy mirror
+    df = pa.DataFrame({"g": np.array([4, 4, 2], dtype=np.int32), "flt": np.array([1.0, 2.0, 3.0]), "int": np.array([1, 2, 3], dtype=np.int32)})
+    out = df.group_by("g", maintain_order=True).select(["int"]).var(1)
+    assert out.columns == ["g", "int_agg_var"] and out["g"].to_list() == [4, 2] and out["int_agg_var"].to_list() == [0.5, None]
+    out = df.group_by("g", maintain_order=True).select(["int"]).std(1)
+    assert abs(out["int_agg_std"].to_list()[0] - 2 ** -0.5) < 1e-6
+    out = df.group_by("g", maintain_order=True).last()
+    assert out.columns == ["g", "flt_last", "int_last"] and out["flt_last"].to_list() == [2.0, 3.0] and out["int_last"].to_list() == [2, 3]
+    out = df.group_by("g", maintain_order=True).first()
+    assert out["flt_first"].to_list() == [1.0, 3.0]
+
+
+def test_agg_groups_var_known_answer():
+    # crates/polars-core/src/frame/group_by/mod.rs:1134-1156
+    g = pa.group_tuples([Column("g", np.array([7, 7, 9], dtype=np.int32))], True)
+    x = Column("int", np.array([1, 2, 3], dtype=np.int32))
+    v = pa.agg_groups(x, "var", g, ddof=1)
+    assert v.to_list() == [0.5, None]
+    s = pa.agg_groups(x, "std", g, ddof=1)
+    assert abs(s.to_list()[0] - 2 ** -0.5) < 1e-6 and s.to_list()[1] is None
+
+
 def test_group_tuples_empty_and_errors():
     g = pa.group_tuples([Column("k", np.empty(0, np.int32))])
     assert g.n_groups == 0 and g.n_rows == 0
