@@ -174,7 +174,7 @@ def sorted_key_groups(key: Column) -> list[list[int]]:
 
 
 def agg_ext(values: Column, kind: str, groups: Groups, ddof: int = 1):
-    """first / last / var / std over GroupsProxy::Idx, restated in plain Python (small inputs only):
+    """first / last / var / std / median over GroupsProxy::Idx, restated in plain Python (small inputs only):
     agg_first / agg_last (crates/polars-core/src/frame/group_by/aggregations/dispatch.rs:47-76: the value, null
     or not, at the group's first / last index; empty group -> null) and agg_var / agg_std (aggregations/mod.rs:
     781-803, 841-862, 1018-1077) over online_variance (crates/polars-arrow/src/kernels/take_agg/var.rs:11-40):
@@ -194,6 +194,22 @@ def agg_ext(values: Column, kind: str, groups: Groups, ddof: int = 1):
         return out, valid
     out = np.zeros(G, dtype=np.float32 if vals.dtype == np.float32 else np.float64)
     valid = np.zeros(G, dtype=bool)
+    if kind == "median":
+        # agg_median = quantile(0.5, Linear) per group (dispatch.rs:98-113; quantile_idx / linear_interpol /
+        # generic_quantile, chunked_array/ops/aggregate/quantile.rs:19-54,133-175): valid values sorted ascending
+        # (NaN last), float_idx = (m - 1) * 0.5, lower + (float_idx - idx) * (upper - lower) in the column's float type
+        ft = out.dtype.type
+        for g, idx in enumerate(groups.lists()):
+            x = np.array([vals[r] for r in idx if mask is None or mask[r]], dtype=vals.dtype)
+            if len(x) == 0:
+                continue
+            x = np.sort(x)
+            float_idx = (len(x) - 1.0) * 0.5
+            i, top = int(float_idx), int(np.ceil(float_idx))
+            lower, upper = ft(x[i]), ft(x[top])
+            out[g] = lower if lower == upper else (ft(float_idx) - ft(i)) * (upper - lower) + lower
+            valid[g] = True
+        return out, valid
     for g, idx in enumerate(groups.lists()):
         m2 = mean = 0.0
         count = 0

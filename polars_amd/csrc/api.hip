@@ -1709,7 +1709,7 @@ int32_t plhip_agg_groups(const plhip_column_t *values, int32_t kind, const plhip
   if (!out) return fail(PLHIP_ERR_INVALID, "out is NULL");
   *out = nullptr;
   if (!groups) return fail(PLHIP_ERR_INVALID, "groups handle is NULL");
-  if (kind < 0 || kind > PLHIP_AGG_STD) return fail(PLHIP_ERR_INVALID, "bad aggregation kind");
+  if (kind < 0 || kind > PLHIP_AGG_MEDIAN) return fail(PLHIP_ERR_INVALID, "bad aggregation kind");
   if (kind != PLHIP_AGG_COUNT && !values) return fail(PLHIP_ERR_INVALID, "values is NULL");
   if (values && kind != PLHIP_AGG_COUNT && values->length != groups->n_rows)
     return fail(PLHIP_ERR_SHAPE_MISMATCH, "the column and the groups differ in length");
@@ -1733,7 +1733,7 @@ int32_t plhip_agg_groups(const plhip_column_t *values, int32_t kind, const plhip
       if (n) HIP_TRY(hipMemcpyAsync(d_idx, groups->indices, (size_t)n * 4, hipMemcpyHostToDevice, c.stream));
       offsets = (const uint32_t *)d_off; indices = (const uint32_t *)d_idx;
     }
-    const bool moment = kind == PLHIP_AGG_VAR || kind == PLHIP_AGG_STD;
+    const bool moment = kind == PLHIP_AGG_VAR || kind == PLHIP_AGG_STD || kind == PLHIP_AGG_MEDIAN; // float-valued results
     plhip_result *R = new (std::nothrow) plhip_result();
     if (!R) return fail(PLHIP_ERR_OOM, "host allocation failed");
     R->n_rows = (int64_t)G; R->on_device = true; R->device = c.device;
@@ -1748,8 +1748,19 @@ int32_t plhip_agg_groups(const plhip_column_t *values, int32_t kind, const plhip
     A.values = dv.values; A.validity = dv.validity; A.boff = dv.boff; A.dtype = (uint32_t)dv.dtype; A.width = (uint32_t)dtype_width(dv.dtype);
     A.kind = (uint32_t)kind; A.ddof = (flags >> 8) & 0xFFu; A.out_dtype = (uint32_t)col.dtype;
     A.out = (uint8_t *)col.values; A.out_validity = col.validity;
-    launch_agg_groups_ext(A, offsets, indices, G, moment && G > 0 && (uint64_t)n / G >= 64, c.stream);
-    e = hipGetLastError();
+    if (kind == PLHIP_AGG_MEDIAN) {
+      if (n > 0x7FFFFFFFll) { delete R; return fail(PLHIP_ERR_INVALID, "too many rows for the segmented sort"); }
+      size_t tb = 0;
+      e = median_temp_bytes((uint64_t)n, G, &tb);
+      const size_t n8 = ((size_t)std::max<int64_t>(n, 1) * 8 + 255) & ~(size_t)255;
+      if (e == hipSuccess) e = c.table.reserve(2 * n8);
+      if (e == hipSuccess) e = c.sortkeys.reserve(tb + 256);
+      if (e == hipSuccess)
+        e = launch_median(A, offsets, indices, (uint64_t)n, G, (uint64_t *)c.table.p, (uint64_t *)((uint8_t *)c.table.p + n8), c.sortkeys.p, tb, c.stream);
+    } else {
+      launch_agg_groups_ext(A, offsets, indices, G, moment && G > 0 && (uint64_t)n / G >= 64, c.stream);
+      e = hipGetLastError();
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
     if (e != hipSuccess) { delete R; return fail_hip(e, "agg_groups"); }
     return finish_result(R, G, flags & PLHIP_FLAG_OUTPUT_DEVICE, out);

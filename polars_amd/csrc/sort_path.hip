@@ -225,6 +225,82 @@ hipError_t launch_sort_groups(const Plan &p, uint64_t *keys_a, uint64_t *keys_b,
   return hipGetLastError();
 }
 
+// ---- median over CSR groups (agg_median -> agg_quantile_generic(0.5, Linear), crates/polars-core/src/frame/group_by/
+// aggregations/mod.rs:420-457 + dispatch.rs:98-113; quantile_idx / linear_interpol, chunked_array/ops/aggregate/
+// quantile.rs:19-54): the group's valid values sorted ascending (NaN last), float_idx = (m - 1) / 2, result =
+// lower + (float_idx - floor) * (upper - lower), in f32 for an f32 column and in f64 otherwise; no valid value -> null.
+// Values travel as order-preserving u64 codes of their f64 value in CSR order, nulls as the largest code, one
+// segmented radix sort (rocPRIM) orders every group, one thread per group picks the middle.
+namespace {
+DEVINL double median_value(const uint8_t *p, uint32_t dtype, int64_t row) {
+  switch (dtype) {
+    case PLHIP_I8: return (double)((const int8_t *)p)[row];
+    case PLHIP_I16: return (double)((const int16_t *)p)[row];
+    case PLHIP_I32: return (double)((const int32_t *)p)[row];
+    case PLHIP_I64: return (double)((const int64_t *)p)[row];
+    case PLHIP_U8: return (double)p[row];
+    case PLHIP_U16: return (double)((const uint16_t *)p)[row];
+    case PLHIP_U32: return (double)((const uint32_t *)p)[row];
+    case PLHIP_U64: return (double)((const uint64_t *)p)[row];
+    case PLHIP_F32: return (double)((const float *)p)[row];
+    default: return ((const double *)p)[row];
+  }
+}
+__global__ void __launch_bounds__(256) k_gather_ordered(AggExtArgs A, const uint32_t *__restrict__ indices, uint64_t n, uint64_t *__restrict__ codes) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t row = indices[i];
+  uint64_t c = ~0ull; // null: behind everything
+  if (bit_valid(A.validity, A.boff, row)) {
+    double d = median_value(A.values, A.dtype, row);
+    if (d != d) d = __longlong_as_double(0x7ff8000000000000ll); // one NaN, behind +inf
+    c = f64_ordered(d);
+  }
+  codes[i] = c;
+}
+__global__ void __launch_bounds__(256) k_median(AggExtArgs A, const uint64_t *__restrict__ sorted, const uint32_t *__restrict__ offsets, uint64_t G) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  const uint32_t b = offsets[g], e = offsets[g + 1];
+  uint32_t lo = b, hi = e; // first null code of the segment
+  while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sorted[mid] == ~0ull) hi = mid; else lo = mid + 1; }
+  const uint32_t m = lo - b;
+  bool valid = m > 0;
+  double r = 0.0;
+  if (valid) {
+    const double float_idx = ((double)m - 1.0) * 0.5;
+    const uint32_t idx = (uint32_t)float_idx, top = (uint32_t)ceil(float_idx);
+    const double lower = f64_from_ordered(sorted[b + idx]), upper = f64_from_ordered(sorted[b + top]);
+    if (A.out_dtype == PLHIP_F32) {
+      const float lf = (float)lower, uf = (float)upper;
+      r = lf == uf ? lf : ((float)float_idx - (float)idx) * (uf - lf) + lf;
+    } else {
+      r = lower == upper ? lower : (float_idx - (double)idx) * (upper - lower) + lower;
+    }
+  }
+  if (A.out_dtype == PLHIP_F32) ((float *)A.out)[g] = (float)r;
+  else ((double *)A.out)[g] = r;
+  if (valid) atomicOr((unsigned int *)A.out_validity + (g >> 5), 1u << (g & 31));
+}
+} // namespace
+
+hipError_t median_temp_bytes(uint64_t n, uint64_t G, size_t *bytes) {
+  return rocprim::segmented_radix_sort_keys(nullptr, *bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, (unsigned int)n, (unsigned int)G,
+                                            (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0, 64);
+}
+// codes_a / codes_b: n u64 each
+hipError_t launch_median(const AggExtArgs &a, const uint32_t *offsets, const uint32_t *indices, uint64_t n, uint64_t G, uint64_t *codes_a,
+                         uint64_t *codes_b, void *temp, size_t temp_bytes, hipStream_t s) {
+  if (!G) return hipSuccess;
+  if (n) {
+    hipLaunchKernelGGL(k_gather_ordered, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, indices, n, codes_a);
+    hipError_t e = rocprim::segmented_radix_sort_keys(temp, temp_bytes, codes_a, codes_b, (unsigned int)n, (unsigned int)G, offsets, offsets + 1, 0, 64, s);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(k_median, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, s, a, codes_b, offsets, G);
+  return hipGetLastError();
+}
+
 // the same without the sort: `key` is a column the caller declares sorted; rows = 0..n-1
 hipError_t launch_sorted_key_groups(const KeySpec &key, uint64_t n, uint32_t *rows, uint32_t *flags, uint32_t *gid, uint32_t *offsets, void *temp,
                                     size_t temp_bytes, uint32_t *dflags, hipStream_t s) {

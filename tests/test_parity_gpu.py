@@ -382,7 +382,7 @@ def test_agg_groups_first_last_var_std(oracle, dt):
         keys = [rand_col(rng, "k", np.int64, n, card=card)]
         v = rand_col(rng, "v", dt, n, null_frac=0.15, lo=0 if np.dtype(dt).kind != "f" else None, hi=1000 if np.dtype(dt).kind != "f" else None)
         g_o, g_p = oracle.Groups(keys, True), pa.group_tuples(keys, True)
-        for kind in ("first", "last", "var", "std"):
+        for kind in ("first", "last", "var", "std", "median"):
             for ddof in ((0, 1, 2) if kind in ("var", "std") else (1,)):
                 wv, wm = oracle.agg_ext(v, kind, g_o, ddof)
                 got = pa.agg_groups(v, kind, g_p, ddof=ddof)
@@ -407,6 +407,20 @@ def test_eager_group_by_var_std_first_last():
     assert out.columns == ["g", "flt_last", "int_last"] and out["flt_last"].to_list() == [2.0, 3.0] and out["int_last"].to_list() == [2, 3]
     out = df.group_by("g", maintain_order=True).first()
     assert out["flt_first"].to_list() == [1.0, 3.0]
+
+
+def test_group_by_shorthands_first_last_median():
+    """test_group_by_shorthands (py-polars/tests/unit/operations/test_group_by.py:59-93): a = [1..5] by b = [a, a, b, b, b],
+    c = [None, 1, None, 1, None] -> first (1, None), (3, None); last (2, 1), (5, None); median (1.5, 1.0), (4.0, 1.0)."""
+    df = pa.DataFrame({"a": np.array([1, 2, 3, 4, 5], dtype=np.int64), "b": np.array([10, 10, 20, 20, 20], dtype=np.int32),
+                       "c": [None, 1, None, 1, None]})
+    gb = lambda: df.group_by("b", maintain_order=True)
+    assert gb().first().rows() == [(10, 1, None), (20, 3, None)]
+    assert gb().last().rows() == [(10, 2, 1), (20, 5, None)]
+    assert gb().median().rows() == [(10, 1.5, 1.0), (20, 4.0, 1.0)]
+    nan = float("nan")
+    f = pa.DataFrame({"k": np.zeros(5, dtype=np.int32), "x": np.array([3.0, nan, 1.0, 2.0, nan])})
+    assert f.group_by("k").median()["x_median"].to_list() == [3.0]  # NaN sorts last: [1, 2, 3, nan, nan] -> 3
 
 
 def test_agg_groups_var_known_answer():
