@@ -778,14 +778,18 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
   uint64_t g_est;
   if (groups_hint > 0) g_est = (uint64_t)std::min<int64_t>(groups_hint, n);
   else {
-    // 131 072 sampled keys resolve up to ~1e6 groups; a sample that comes back (almost) all distinct is taken
-    // again 32x larger when the column is long enough for that to matter (ms-scale queries: the second sample is noise)
+    // 131 072 sampled keys resolve up to ~1e6 groups under the uniform model E[d] = G (1 - exp(-s / G)).  Two things
+    // send the estimate back for a second, larger sample when the column is long enough for it to matter: a sample
+    // that is (almost) all distinct, and skew -- heavy hitters eat the sample and the uniform model then reads far too
+    // few groups; it shows as more once-seen keys than the model allows, and then the estimate is the larger of the
+    // model's and GEE's (sqrt(n / s) * f1 + (d - f1), Charikar et al.), which is built for that case.
     int64_t ns = n <= (1 << 17) ? n : (1 << 17); // whole 256-row blocks when sampling
     g_est = (uint64_t)n;
     for (int round = 0; round < 2; round++) {
       const uint32_t set_bits = (uint32_t)std::max(10, ceil_log2((uint64_t)ns * 4));
-      HIP_TRY(c.table.reserve((size_t)4 << set_bits));
-      HIP_TRY(hipMemsetAsync(c.table.p, 0xFF, (size_t)4 << set_bits, c.stream));
+      const size_t set_bytes = ((size_t)4 << set_bits) + ((size_t)4 << set_bits) / 16; // fingerprints + 2 state bits per slot
+      HIP_TRY(c.table.reserve(set_bytes));
+      HIP_TRY(hipMemsetAsync(c.table.p, 0, set_bytes, c.stream));
       HIP_TRY(hipMemsetAsync(dflags, 0, 64, c.stream));
       c.flags_clean = false;
       launch_estimate(P, ns, ns == n ? 256 : n / (ns >> 8), (uint32_t *)c.table.p, set_bits, dflags, c.stream);
@@ -794,17 +798,24 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
       uint32_t f[16];
       int rc = read_flags(t, f);
       if (rc) return rc;
-      const double d = f[FLAG_NGROUPS];
+      const double d = f[FLAG_NGROUPS], f1 = (double)(int32_t)f[FLAG_F1];
+      const bool more = round == 0 && n >= 32 * ns; // a second sample is possible and worth its time
       if (d >= 0.95 * (double)ns) {
         g_est = (uint64_t)n;
-        if (round == 0 && n >= 32 * ns) { ns = std::min<int64_t>((n / 16) & ~(int64_t)255, (int64_t)1 << 22); continue; }
+        if (more) { ns = std::min<int64_t>((n / 16) & ~(int64_t)255, (int64_t)1 << 22); continue; }
       } else { // invert E[d] = G (1 - exp(-s / G))
         double lo = d, hi = (double)n;
         for (int it = 0; it < 60; it++) {
           const double g = 0.5 * (lo + hi);
           if (g * (1.0 - std::exp(-(double)ns / g)) < d) lo = g; else hi = g;
         }
-        g_est = (uint64_t)std::min<double>((double)n, std::ceil(hi * 1.1));
+        double est = hi;
+        const double f1_uniform = (double)ns * std::exp(-(double)ns / hi);
+        if (ns < n && f1 > 1.25 * f1_uniform + 64) { // skewed
+          if (more) { ns = std::min<int64_t>((n / 16) & ~(int64_t)255, (int64_t)1 << 22); continue; }
+          est = std::max(est, std::sqrt((double)n / (double)ns) * f1 + (d - f1));
+        }
+        g_est = (uint64_t)std::min<double>((double)n, std::ceil(est * 1.1));
       }
       break;
     }
@@ -993,8 +1004,10 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
 // partition of the general path (k_part_hist / scan / plan / scatter) into tile-aligned, partition-contiguous
 // copies; level 2 = the tile sort inside every level-1 partition on the next hash bits; then one LDS table per
 // (level-1, level-2) leaf, which writes its output rows itself (the leaves are disjoint in the keys).
-int run_two_level(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, uint64_t g_est, bool forced, plhip_result_t **out, bool &handled) {
+int run_two_level(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, uint64_t g_est, bool forced, plhip_result_t **out, bool &handled,
+                  bool *overflowed = nullptr) {
   handled = false;
+  if (overflowed) *overflowed = false;
   Ctx &c = g_ctx;
   Plan &P = L.P;
   const int64_t n = P.n_rows;
@@ -1128,7 +1141,11 @@ int run_two_level(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, uint64_t 
   if (hipMemsetAsync(dflags, 0, 64, c.stream) == hipSuccess) c.flags_clean = true;
   c.timing_pending = 2;
   c.strategy = "tilesort2";
-  if (fl[FLAG_OVERFLOW]) { delete R; return PLHIP_OK; } // a leaf table overflowed (estimate too low / skew): the sort strategy redoes it
+  if (fl[FLAG_OVERFLOW]) { // a leaf table overflowed: the estimate was too low
+    if (overflowed) *overflowed = true;
+    delete R;
+    return PLHIP_OK;
+  }
   const uint64_t G = fl[FLAG_NGROUPS];
   R->n_rows = (int64_t)G;
   handled = true;
@@ -1414,8 +1431,13 @@ int32_t group_by_agg_impl(const plhip_column_t *keys, int32_t n_keys, const plhi
     strategy = (n >= (1 << 16) && (g_seen > 4096 || L.KG.enabled)) ? PLHIP_STRATEGY_SORT : PLHIP_STRATEGY_AUTO;
     if (strategy == PLHIP_STRATEGY_SORT && g_seen > 4096 && (uint64_t)n / g_seen >= 2) { // beyond one partition level: two
       // levels before the sort (nearly all-unique keys: the two are on par, and the sort is immune to skew)
-      if ((rc = run_two_level(L, dk, flags, g_seen, false, out, handled))) return rc;
+      bool over = false;
+      if ((rc = run_two_level(L, dk, flags, g_seen, false, out, handled, &over))) return rc;
       if (handled) return PLHIP_OK;
+      if (over && g_seen * 8 <= (uint64_t)n) { // once more with room for 8x the groups (still far cheaper than the sort)
+        if ((rc = run_two_level(L, dk, flags, g_seen * 8, false, out, handled))) return rc;
+        if (handled) return PLHIP_OK;
+      }
     }
   }
   if (strategy == PLHIP_STRATEGY_TILESORT2) {

@@ -99,5 +99,6 @@ void launch_tile_sort(const Plan &p, const PartOut &o, uint32_t pbits, uint32_t 
 void launch_fold_runs(const Plan &p2, const FoldRunsArgs &a, const OutPlan &o, int key_bytes, uint32_t block, hipStream_t s);
 void launch_merge_emit(const Plan &p, const MergeArgs &a, const OutPlan &o, int key_bytes, uint32_t n_pg, uint32_t block, hipStream_t s);
 // distinct keys among `n_sample` rows taken every `stride` rows -> flags[FLAG_NGROUPS]
-// `set`: scratch of 1 << set_bits u32 filled with 0xFF bytes (at least 4x the sample)
+// `set`: ZEROED scratch of (1 << set_bits) + (1 << set_bits) / 16 u32: the fingerprints (at least 4x the sample), then
+// two state bits per slot; flags[FLAG_F1] receives the number of sampled keys seen exactly once
 void launch_estimate(const Plan &p, int64_t n_sample, int64_t stride, uint32_t *set, uint32_t set_bits, uint32_t *flags, hipStream_t s);

@@ -879,28 +879,69 @@ __global__ void __launch_bounds__(1024) k_merge_emit(Plan P, MergeArgs A, OutPla
 // ---------------------------------------------------------------------------------------------------------
 // sampled cardinality (the analogue of estimate_unique_count, group_by_partitioned.rs:115-157): one key per
 // thread from 256-row blocks spread evenly over the column; 32-bit fingerprints go into a scratch set in HBM
-// (one CAS per key: ~1e5 global atomics, a few microseconds) and the new ones are counted.
+// (one CAS per key: ~1e5 global atomics, a few microseconds) and the new ones are counted, together with the
+// keys seen exactly once (two state bits per slot), which is what tells skew from many groups.
 // ---------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_estimate(Plan P, int64_t n_sample, int64_t stride, uint32_t *set, uint32_t set_bits, uint32_t *flags) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  bool fresh = false;
-  if (i < n_sample) {
+#define EST_BLOCK 1024
+#define EST_PER 2                      // samples per thread
+#define EST_CHUNK (EST_BLOCK * EST_PER) // samples per workgroup
+#define EST_LSLOTS 4096u               // LDS pre-aggregation table (load <= 1/2)
+__global__ void __launch_bounds__(EST_BLOCK) k_estimate(Plan P, int64_t n_sample, int64_t stride, uint32_t *set, uint32_t set_bits, uint32_t *flags) {
+  // The workgroup first folds its 2048 samples into an LDS set (hash + sightings): a hot key reaches the global set
+  // once per workgroup instead of once per sample (atomics and memory-side loads on a handful of addresses serialise).
+  __shared__ unsigned long long lh[EST_LSLOTS]; // full hash of the key in the slot, 0 = empty
+  __shared__ uint32_t lc[EST_LSLOTS];           // sightings inside this workgroup
+  __shared__ int s_d, s_f1;
+  for (uint32_t j = threadIdx.x; j < EST_LSLOTS; j += EST_BLOCK) { lh[j] = 0ull; lc[j] = 0u; }
+  if (threadIdx.x == 0) { s_d = 0; s_f1 = 0; }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < EST_PER; r++) {
+    const int64_t i = (int64_t)blockIdx.x * EST_CHUNK + (int64_t)r * EST_BLOCK + threadIdx.x;
+    if (i >= n_sample) continue;
     bool isn;
     const uint64_t key = row_packed_key(P, (i >> 8) * stride + (i & 255), isn);
-    const uint64_t h = isn ? 0x9E3779B97F4A7C15ull : hash_key(key);
+    unsigned long long h = isn ? 0x9E3779B97F4A7C15ull : hash_key(key);
+    if (h == 0ull) h = 1ull;
+    uint32_t s = (uint32_t)(h >> 17) & (EST_LSLOTS - 1);
+    for (;;) { // the table holds twice the samples: a free slot always turns up
+      const unsigned long long k = atomicCAS(&lh[s], 0ull, h);
+      if (k == 0ull || k == h) { atomicAdd(&lc[s], 1u); break; }
+      s = (s + 1) & (EST_LSLOTS - 1);
+    }
+  }
+  __syncthreads();
+  const uint32_t mask = (1u << set_bits) - 1;
+  uint32_t *seen = set + ((size_t)1 << set_bits); // two bits per slot of the global set: seen once, seen twice or more
+  int d = 0, f1 = 0;
+  for (uint32_t j = threadIdx.x; j < EST_LSLOTS; j += EST_BLOCK) {
+    const unsigned long long h = lh[j];
+    if (h == 0ull) continue;
+    const uint32_t c = lc[j];
     uint32_t f = (uint32_t)(h >> 32);
-    if (f == 0xFFFFFFFFu) f = 0x7FFFFFFFu;
-    const uint32_t mask = (1u << set_bits) - 1;
+    if (f == 0u) f = 1u; // 0 = empty slot
     uint32_t s = (uint32_t)h & mask;
     for (uint32_t it = 0; it <= mask; it++) {
-      const uint32_t k = atomicCAS(&set[s], 0xFFFFFFFFu, f);
-      if (k == 0xFFFFFFFFu) { fresh = true; break; }
-      if (k == f) break;
+      const uint32_t k = atomicCAS(&set[s], 0u, f);
+      if (k == 0u || k == f) {
+        if (k == 0u) d++;
+        const uint32_t w = s >> 4, sh = (s & 15u) * 2u;
+        const uint32_t prev = (atomicOr(&seen[w], (c >= 2 ? 3u : 1u) << sh) >> sh) & 3u;
+        if (c >= 2) { if (prev == 1u) f1--; }            // was "once", is "twice or more" now
+        else if (prev == 0u) f1++;                       // first sighting anywhere
+        else if (prev == 1u && !((atomicOr(&seen[w], 2u << sh) >> sh) & 2u)) f1--; // second sighting
+        break;
+      }
       s = (s + 1) & mask;
     }
   }
-  const unsigned long long m = __ballot(fresh);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&flags[FLAG_NGROUPS], (uint32_t)__popcll(m));
+  if (d) atomicAdd(&s_d, d);
+  if (f1) atomicAdd(&s_f1, f1);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (s_d) atomicAdd(&flags[FLAG_NGROUPS], (uint32_t)s_d);
+    if (s_f1) atomicAdd((int *)&flags[FLAG_F1], s_f1);
+  }
 }
 
 // ---- pre-instantiated shapes (accumulators in lowered order: sorted by source column, counters first) ------
@@ -1035,5 +1076,5 @@ void launch_merge_emit(const Plan &p, const MergeArgs &a, const OutPlan &o, int 
 }
 
 void launch_estimate(const Plan &p, int64_t n_sample, int64_t stride, uint32_t *set, uint32_t set_bits, uint32_t *flags, hipStream_t s) {
-  hipLaunchKernelGGL(k_estimate, dim3((unsigned)((n_sample + 255) / 256)), dim3(256), 0, s, p, n_sample, stride, set, set_bits, flags);
+  hipLaunchKernelGGL(k_estimate, dim3((unsigned)((n_sample + EST_CHUNK - 1) / EST_CHUNK)), dim3(EST_BLOCK), 0, s, p, n_sample, stride, set, set_bits, flags);
 }

@@ -14,6 +14,7 @@
 #define FLAG_NGROUPS 3
 #define FLAG_LDS_SPILL 4
 #define FLAG_DONE 5 // workgroups of the last kernel that have finished (fast path: completion signal)
+#define FLAG_F1 6   // k_estimate: sampled keys seen exactly once (signed count)
 
 struct TableRef {
   uint8_t *base;   // keys[slots] u64, then the accumulator arrays (AccSpec::offset)

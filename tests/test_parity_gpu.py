@@ -877,6 +877,21 @@ def test_two_levels_vs_oracle_mid_size(oracle):
         assert pa.last_strategy() == "tilesort2"
 
 
+def test_skewed_keys_estimate_and_auto(oracle):
+    """BASELINE config 5's recipe at a size the oracle handles: half of the rows Zipf-like(1.1) heavy hitters (the top
+    key ~3 % of all rows), half a uniform tail over 2e6 ids.  Heavy hitters eat the cardinality sample; the estimator
+    must still size the pipeline for the ~2e6 groups (once-seen keys / GEE / second sample), AUTO must take the two
+    partition levels and not fall through to the sort, and the result is the oracle's."""
+    rng = np.random.default_rng(101)
+    n, ids = 8_000_000, 2_000_000
+    z = np.floor(np.maximum(rng.random(n), 1e-300) ** -10.0)
+    k = np.where(rng.random(n) < 0.5, np.mod(np.minimum(z, 1e15) - 1, ids), np.floor(rng.random(n) * ids)).astype(np.int64)
+    keys = [Column("k", k)]
+    values = [Column("a", rng.integers(-1000, 1000, n).astype(np.int64)), Column("b", np.round(rng.uniform(0, 100, n), 6))]
+    check_parity(oracle, keys, values, [(0, "sum"), (1, "mean"), (0, "count")], "auto", what="skewed keys")
+    assert pa.last_strategy() == "tilesort2"
+
+
 def test_two_levels_skew_falls_back(oracle):
     """A heavy key plus many light ones: if a leaf table overflows the query is redone by the sort strategy;
     either way the result is the oracle's."""
