@@ -748,6 +748,56 @@ void order_accs_by_source(Lowered &L) {
 
 int ceil_log2(uint64_t x) { int b = 0; while ((1ull << b) < x) b++; return b; }
 
+// Sampled cardinality for the LDS pipelines (fast_path.hip k_estimate): g_est = estimated number of groups.
+int estimate_groups_sampled(const Plan &P, uint64_t &g_est) {
+  Ctx &c = g_ctx;
+  const int64_t n = P.n_rows;
+  HIP_TRY(c.flags.reserve(64));
+  uint32_t *dflags = (uint32_t *)c.flags.p;
+  // 131 072 sampled keys resolve up to ~1e6 groups under the uniform model E[d] = G (1 - exp(-s / G)).  Two things
+  // send the estimate back for a second, larger sample when the column is long enough for it to matter: a sample
+  // that is (almost) all distinct, and skew -- heavy hitters eat the sample and the uniform model then reads far too
+  // few groups; it shows as more once-seen keys than the model allows, and then the estimate is the larger of the
+  // model's and GEE's (sqrt(n / s) * f1 + (d - f1), Charikar et al.), which is built for that case.
+  int64_t ns = n <= (1 << 17) ? n : (1 << 17); // whole 256-row blocks when sampling
+  g_est = (uint64_t)n;
+  for (int round = 0; round < 2; round++) {
+    const uint32_t set_bits = (uint32_t)std::max(10, ceil_log2((uint64_t)ns * 4));
+    const size_t set_bytes = ((size_t)4 << set_bits) + ((size_t)4 << set_bits) / 16; // fingerprints + 2 state bits per slot
+    HIP_TRY(c.table.reserve(set_bytes));
+    HIP_TRY(hipMemsetAsync(c.table.p, 0, set_bytes, c.stream));
+    HIP_TRY(hipMemsetAsync(dflags, 0, 64, c.stream));
+    c.flags_clean = false;
+    launch_estimate(P, ns, ns == n ? 256 : n / (ns >> 8), (uint32_t *)c.table.p, set_bits, dflags, c.stream);
+    HIP_TRY(hipGetLastError());
+    TableRef t{nullptr, 0, dflags};
+    uint32_t f[16];
+    int rc = read_flags(t, f);
+    if (rc) return rc;
+    const double d = f[FLAG_NGROUPS], f1 = (double)(int32_t)f[FLAG_F1];
+    const bool more = round == 0 && n >= 32 * ns; // a second sample is possible and worth its time
+    if (d >= 0.95 * (double)ns) {
+      g_est = (uint64_t)n;
+      if (more) { ns = std::min<int64_t>((n / 16) & ~(int64_t)255, (int64_t)1 << 22); continue; }
+    } else { // invert E[d] = G (1 - exp(-s / G))
+      double lo = d, hi = (double)n;
+      for (int it = 0; it < 60; it++) {
+        const double g = 0.5 * (lo + hi);
+        if (g * (1.0 - std::exp(-(double)ns / g)) < d) lo = g; else hi = g;
+      }
+      double est = hi;
+      const double f1_uniform = (double)ns * std::exp(-(double)ns / hi);
+      if (ns < n && f1 > 1.25 * f1_uniform + 64) { // skewed
+        if (more) { ns = std::min<int64_t>((n / 16) & ~(int64_t)255, (int64_t)1 << 22); continue; }
+        est = std::max(est, std::sqrt((double)n / (double)ns) * f1 + (d - f1));
+      }
+      g_est = (uint64_t)std::min<double>((double)n, std::ceil(est * 1.1));
+    }
+    break;
+  }
+  return PLHIP_OK;
+}
+
 // The LDS-only pipeline (fast_path.hip).  Sets `handled` when it produced the result; otherwise the caller
 // runs the general path (stable order, wide key tuples, tiny inputs, more groups than one partition level
 // brings into LDS, or a cardinality estimate that turned out too low).
@@ -778,47 +828,8 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
   uint64_t g_est;
   if (groups_hint > 0) g_est = (uint64_t)std::min<int64_t>(groups_hint, n);
   else {
-    // 131 072 sampled keys resolve up to ~1e6 groups under the uniform model E[d] = G (1 - exp(-s / G)).  Two things
-    // send the estimate back for a second, larger sample when the column is long enough for it to matter: a sample
-    // that is (almost) all distinct, and skew -- heavy hitters eat the sample and the uniform model then reads far too
-    // few groups; it shows as more once-seen keys than the model allows, and then the estimate is the larger of the
-    // model's and GEE's (sqrt(n / s) * f1 + (d - f1), Charikar et al.), which is built for that case.
-    int64_t ns = n <= (1 << 17) ? n : (1 << 17); // whole 256-row blocks when sampling
-    g_est = (uint64_t)n;
-    for (int round = 0; round < 2; round++) {
-      const uint32_t set_bits = (uint32_t)std::max(10, ceil_log2((uint64_t)ns * 4));
-      const size_t set_bytes = ((size_t)4 << set_bits) + ((size_t)4 << set_bits) / 16; // fingerprints + 2 state bits per slot
-      HIP_TRY(c.table.reserve(set_bytes));
-      HIP_TRY(hipMemsetAsync(c.table.p, 0, set_bytes, c.stream));
-      HIP_TRY(hipMemsetAsync(dflags, 0, 64, c.stream));
-      c.flags_clean = false;
-      launch_estimate(P, ns, ns == n ? 256 : n / (ns >> 8), (uint32_t *)c.table.p, set_bits, dflags, c.stream);
-      HIP_TRY(hipGetLastError());
-      TableRef t{nullptr, 0, dflags};
-      uint32_t f[16];
-      int rc = read_flags(t, f);
-      if (rc) return rc;
-      const double d = f[FLAG_NGROUPS], f1 = (double)(int32_t)f[FLAG_F1];
-      const bool more = round == 0 && n >= 32 * ns; // a second sample is possible and worth its time
-      if (d >= 0.95 * (double)ns) {
-        g_est = (uint64_t)n;
-        if (more) { ns = std::min<int64_t>((n / 16) & ~(int64_t)255, (int64_t)1 << 22); continue; }
-      } else { // invert E[d] = G (1 - exp(-s / G))
-        double lo = d, hi = (double)n;
-        for (int it = 0; it < 60; it++) {
-          const double g = 0.5 * (lo + hi);
-          if (g * (1.0 - std::exp(-(double)ns / g)) < d) lo = g; else hi = g;
-        }
-        double est = hi;
-        const double f1_uniform = (double)ns * std::exp(-(double)ns / hi);
-        if (ns < n && f1 > 1.25 * f1_uniform + 64) { // skewed
-          if (more) { ns = std::min<int64_t>((n / 16) & ~(int64_t)255, (int64_t)1 << 22); continue; }
-          est = std::max(est, std::sqrt((double)n / (double)ns) * f1 + (d - f1));
-        }
-        g_est = (uint64_t)std::min<double>((double)n, std::ceil(est * 1.1));
-      }
-      break;
-    }
+    int rc = estimate_groups_sampled(P, g_est);
+    if (rc) return rc;
   }
   g_est = std::max<uint64_t>(g_est, 1);
   g_seen = g_est;
@@ -1162,7 +1173,8 @@ int run_sorted(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, plhip_result
   Plan &P = L.P;
   const int64_t n = P.n_rows;
   if (n < 1 || P.n_accs > 20 || n > 0xFFFFFFFEll) return PLHIP_OK;
-  if (keys_sorted ? !P.single_key : (flags & PLHIP_FLAG_MAINTAIN_ORDER) != 0) return PLHIP_OK;
+  if (keys_sorted && !P.single_key) return PLHIP_OK;
+  const bool stable = !keys_sorted && (flags & PLHIP_FLAG_MAINTAIN_ORDER); // runs come out in key order: reordered by first row below
   order_accs_by_source(L);
   int rc;
   if (!keys_sorted && P.single_key && dk[0].validity) { // nulls become code 0 of a range-compressed key
@@ -1238,8 +1250,22 @@ int run_sorted(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, plhip_result
     kg_dev = (const KeyGather *)c.plans.p;
   }
   if (e == hipSuccess) {
-    launch_fold_sorted(P, OP, kg_dev, keys_b, rows_b, offsets, G, long_list, long_count, c.stream);
-    e = hipGetLastError();
+    const uint32_t *gmap = nullptr;
+    if (stable && G > 1) {
+      size_t tb = 0;
+      e = stable_order_temp_bytes(G, &tb);
+      if (e == hipSuccess) e = c.misc.reserve((size_t)G * 20 + 256);
+      if (e == hipSuccess) e = c.sortkeys.reserve(std::max(tb, temp_bytes));
+      if (e == hipSuccess) {
+        uint32_t *buf = (uint32_t *)c.misc.p;
+        e = launch_stable_order(rows_b, offsets, G, buf, buf + 4 * G, c.sortkeys.p, std::max(tb, temp_bytes), c.stream);
+        gmap = buf + 4 * G;
+      }
+    }
+    if (e == hipSuccess) {
+      launch_fold_sorted(P, OP, kg_dev, keys_b, rows_b, offsets, G, long_list, long_count, c.stream, gmap);
+      e = hipGetLastError();
+    }
   }
   hipEventRecord(c.ev[5], c.stream);
   hipEventRecord(c.ev[3], c.stream);
@@ -1446,10 +1472,11 @@ int32_t group_by_agg_impl(const plhip_column_t *keys, int32_t n_keys, const plhi
     int64_t hint = 0;
     if (opts && opts->struct_size >= offsetof(plhip_options_t, n_groups_hint) + sizeof(int64_t)) hint = opts->n_groups_hint;
     if (hint > 0) g_est = (uint64_t)std::min<int64_t>(hint, n);
-    else if (n >= (1 << 14) && (rc = estimate_groups(P, g_est))) return rc;
-    if ((rc = run_two_level(L, dk, flags, std::max<uint64_t>(g_est, 1), true, out, handled))) return rc;
+    else if (n > 0 && (rc = estimate_groups_sampled(P, g_est))) return rc;
+    bool over = false;
+    if ((rc = run_two_level(L, dk, flags, std::max<uint64_t>(g_est, 1), true, out, handled, &over))) return rc;
     if (handled) return PLHIP_OK;
-    strategy = PLHIP_STRATEGY_AUTO;
+    strategy = over ? PLHIP_STRATEGY_SORT : PLHIP_STRATEGY_AUTO; // (declined: stable order, wide tuples -> the general path)
   }
   if (strategy == PLHIP_STRATEGY_SORT) {
     bool handled = false;
@@ -1459,6 +1486,12 @@ int32_t group_by_agg_impl(const plhip_column_t *keys, int32_t n_keys, const plhi
   }
   uint64_t g_est = (uint64_t)n;
   if (n >= (1 << 14) && (rc = estimate_groups(P, g_est))) return rc;
+  if (strategy == PLHIP_STRATEGY_AUTO && (flags & PLHIP_FLAG_MAINTAIN_ORDER) && n >= (1 << 20) && g_est > (1u << 16)) {
+    // stable order with many groups: the sort strategy (reordered by first row) instead of an HBM table full of atomics
+    bool handled = false;
+    if ((rc = run_sorted(L, dk, flags, out, handled))) return rc;
+    if (handled) return PLHIP_OK;
+  }
   const int key_bytes = packed_key_bytes(P, dk);
   // largest LDS table (log2 slots) for two / one workgroup(s) per CU
   uint32_t lbits2 = 13, lbits1 = 14;

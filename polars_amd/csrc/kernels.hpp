@@ -100,8 +100,13 @@ hipError_t launch_sort_groups(const Plan &p, uint64_t *keys_a, uint64_t *keys_b,
                               uint32_t *gid, uint32_t *offsets, void *temp, size_t temp_bytes, int end_bit, uint32_t *dflags, hipStream_t s);
 hipError_t launch_sorted_key_groups(const KeySpec &key, uint64_t n, uint32_t *rows, uint32_t *flags, uint32_t *gid, uint32_t *offsets, void *temp,
                                     size_t temp_bytes, uint32_t *dflags, hipStream_t s);
+// gmap (optional, G u32): output row of every run (stable order)
 void launch_fold_sorted(const Plan &p, const OutPlan &o, const KeyGather *kg_dev, const uint64_t *skeys, const uint32_t *rows,
-                        const uint32_t *offsets, uint64_t G, uint32_t *long_list, uint32_t *long_count, hipStream_t s);
+                        const uint32_t *offsets, uint64_t G, uint32_t *long_list, uint32_t *long_count, hipStream_t s,
+                        const uint32_t *gmap = nullptr);
+hipError_t stable_order_temp_bytes(uint64_t G, size_t *bytes);
+hipError_t launch_stable_order(const uint32_t *rows, const uint32_t *offsets, uint64_t G, uint32_t *buf, uint32_t *gmap, void *temp, size_t temp_bytes,
+                               hipStream_t s);
 
 // exchange step of the row-sharded group-by (exchange.hip): frame <-> row records
 #define EX_MAX_PARTS 1024 // owner ranks

@@ -109,7 +109,8 @@ DEVINL void emit_run(const Plan &P, const OutPlan &O, const KeyGather *KG, const
 __global__ void __launch_bounds__(SP_BLOCK) k_fold_sorted(Plan P, OutPlan O, const KeyGather *__restrict__ KG,
                                                           const uint64_t *__restrict__ skeys, const uint32_t *__restrict__ rows,
                                                           const uint32_t *__restrict__ offsets, uint64_t G,
-                                                          uint32_t *__restrict__ long_list, uint32_t *__restrict__ long_count) {
+                                                          uint32_t *__restrict__ long_list, uint32_t *__restrict__ long_count,
+                                                          const uint32_t *__restrict__ gmap) {
   extern __shared__ __align__(16) uint64_t sst[]; // [n_accs][SP_BLOCK]
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= G) return;
@@ -161,14 +162,15 @@ __global__ void __launch_bounds__(SP_BLOCK) k_fold_sorted(Plan P, OutPlan O, con
     }
     a0 = a1;
   }
-  emit_run(P, O, KG, sst, threadIdx.x, skeys ? skeys[b] : 0ull, rows[b], g);
+  emit_run(P, O, KG, sst, threadIdx.x, skeys ? skeys[b] : 0ull, rows[b], gmap ? gmap[g] : g); // gmap: stable (first-row) order
 }
 
 // one workgroup per long run: lanes stride the index list, partial states are combined in a fixed tree
 __global__ void __launch_bounds__(SP_BLOCK) k_fold_sorted_long(Plan P, OutPlan O, const KeyGather *__restrict__ KG,
                                                                const uint64_t *__restrict__ skeys, const uint32_t *__restrict__ rows,
                                                                const uint32_t *__restrict__ offsets,
-                                                               const uint32_t *__restrict__ long_list, const uint32_t *__restrict__ long_count) {
+                                                               const uint32_t *__restrict__ long_list, const uint32_t *__restrict__ long_count,
+                                                               const uint32_t *__restrict__ gmap) {
   extern __shared__ __align__(16) uint64_t sst[]; // [n_accs][SP_BLOCK]
   for (uint32_t li = blockIdx.x; li < *long_count; li += gridDim.x) {
     const uint64_t g = long_list[li];
@@ -192,7 +194,7 @@ __global__ void __launch_bounds__(SP_BLOCK) k_fold_sorted_long(Plan P, OutPlan O
         __syncthreads();
       }
     }
-    if (threadIdx.x == 0) emit_run(P, O, KG, sst, 0, skeys ? skeys[b] : 0ull, rows[b], g);
+    if (threadIdx.x == 0) emit_run(P, O, KG, sst, 0, skeys ? skeys[b] : 0ull, rows[b], gmap ? gmap[g] : g);
     __syncthreads();
   }
 }
@@ -311,13 +313,41 @@ hipError_t launch_sorted_key_groups(const KeySpec &key, uint64_t n, uint32_t *ro
   return hipGetLastError();
 }
 
+// group_by_stable (hashing.rs:32-79: groups ordered by their first row): first[g] = the run's first (= smallest) row,
+// a radix sort of (first, g), and gmap[g] = the position of g in that order, which the fold writes its output row to
+namespace {
+__global__ void __launch_bounds__(256) k_run_first(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ offsets, uint64_t G,
+                                                   uint32_t *__restrict__ first, uint32_t *__restrict__ gid) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < G) { first[g] = rows[offsets[g]]; gid[g] = (uint32_t)g; }
+}
+__global__ void __launch_bounds__(256) k_invert(const uint32_t *__restrict__ sorted_g, uint64_t G, uint32_t *__restrict__ gmap) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < G) gmap[sorted_g[i]] = (uint32_t)i;
+}
+} // namespace
+hipError_t stable_order_temp_bytes(uint64_t G, size_t *bytes) {
+  return rocprim::radix_sort_pairs(nullptr, *bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, G, 0, 32);
+}
+// buf: 4 * G u32 (first, gid, first sorted, gid sorted); gmap: G u32
+hipError_t launch_stable_order(const uint32_t *rows, const uint32_t *offsets, uint64_t G, uint32_t *buf, uint32_t *gmap, void *temp, size_t temp_bytes,
+                               hipStream_t s) {
+  if (!G) return hipSuccess;
+  uint32_t *first = buf, *gid = buf + G, *first_s = buf + 2 * G, *gid_s = buf + 3 * G;
+  hipLaunchKernelGGL(k_run_first, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, s, rows, offsets, G, first, gid);
+  hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, first, first_s, gid, gid_s, G, 0, 32, s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_invert, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, s, gid_s, G, gmap);
+  return hipGetLastError();
+}
+
 void launch_fold_sorted(const Plan &p, const OutPlan &o, const KeyGather *kg_dev, const uint64_t *skeys, const uint32_t *rows,
-                        const uint32_t *offsets, uint64_t G, uint32_t *long_list, uint32_t *long_count, hipStream_t s) {
+                        const uint32_t *offsets, uint64_t G, uint32_t *long_list, uint32_t *long_count, hipStream_t s, const uint32_t *gmap) {
   if (!G) return;
   const size_t lds = (size_t)(p.n_accs ? p.n_accs : 1) * SP_BLOCK * 8;
   hipLaunchKernelGGL(k_fold_sorted, dim3((unsigned)((G + SP_BLOCK - 1) / SP_BLOCK)), dim3(SP_BLOCK), lds, s, p, o, kg_dev, skeys, rows, offsets, G,
-                     long_list, long_count);
+                     long_list, long_count, gmap);
   const uint64_t max_long = (uint64_t)p.n_rows / SP_LONG + 1;
   hipLaunchKernelGGL(k_fold_sorted_long, dim3((unsigned)(max_long < 4096 ? max_long : 4096)), dim3(SP_BLOCK), lds, s, p, o, kg_dev, skeys, rows,
-                     offsets, long_list, long_count);
+                     offsets, long_list, long_count, gmap);
 }

@@ -110,7 +110,7 @@ def test_zz_fast_path_coverage():
     """The forced LDS-only strategies may decline (stable order, wide key tuples, more groups than fit);
     they must not decline the plain cases."""
     allowed = {"direct": ("multi-key", "stable", "card=None", "n=0"), "tilesort": ("multi-key", "stable", "card=None", "n=0"),
-               "sort": ("stable", "n=0"), "tilesort2": ("multi-key", "stable", "card=None", "n=0")}
+               "sort": ("n=0",), "tilesort2": ("multi-key", "stable", "card=None", "n=0")}
     bad = [w for w, s, _ in FELL_BACK if not any(w.startswith(a) or a in w for a in allowed[s])]
     assert not bad, f"fast path declined: {sorted(bad)}"
 
@@ -875,6 +875,18 @@ def test_two_levels_vs_oracle_mid_size(oracle):
     for strategy in ("tilesort2", "auto"):
         check_parity(oracle, keys, values, aggs, strategy, what=f"two levels {strategy}")
         assert pa.last_strategy() == "tilesort2"
+
+
+def test_stable_order_many_groups_takes_the_sort(oracle):
+    """maintain_order beyond the LDS range: the sort strategy, its runs reordered by first row (hashing.rs:32-79)."""
+    rng = np.random.default_rng(103)
+    n = 2_000_000
+    keys = [rand_col(rng, "k", np.int64, n, card=400_000, null_frac=0.001)]
+    values = [rand_col(rng, "a", np.int32, n, lo=-1000, hi=1000), rand_col(rng, "b", np.float64, n, null_frac=0.1)]
+    check_parity(oracle, keys, values, [(0, "sum"), (1, "mean"), (1, "min"), (0, "count")], "auto", maintain_order=True, what="stable, many groups")
+    assert pa.last_strategy() == "sort"
+    check_parity(oracle, keys, values, [(0, "sum"), (0, "count")], "sort", maintain_order=True, what="stable, forced sort")
+    assert pa.last_strategy() == "sort"
 
 
 def test_skewed_keys_estimate_and_auto(oracle):
