@@ -1123,7 +1123,20 @@ int run_two_level(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, uint64_t 
   launch_part_hist(P, pbits1, tile_rows1, n_tiles1, counts, c.stream);
   launch_part_scan(counts, np1, n_tiles1, totals, c.stream);
   launch_part_plan(totals, np1, pstart, nullptr, cnt, cnt + 1, 1u << 30, c.stream, (uint32_t)TS_TILE);
-  launch_part_scatter(P, A, pbits1, tile_rows1, n_tiles1, counts, pstart, c.stream);
+  if (pbits1 <= TS_MAX_PBITS && tile_rows1 == TS_TILE && !getenv("PLHIP_T2_LEGACY_SCATTER")) {
+    // the tile sort's scatter variant (LDS-only barriers, loads in flight across them): 2x the legacy scatter's rate
+    int keymode1 = 0;
+    uint64_t kxor1 = 0;
+    if (P.single_key && !dk[0].validity) {
+      const int w = dtype_width(dk[0].dtype);
+      if (w == 4) { keymode1 = 1; kxor1 = dk[0].dtype == PLHIP_I32 ? 0x80000000ull : 0ull; }
+      if (w == 8) { keymode1 = 2; kxor1 = dk[0].dtype == PLHIP_I64 ? 0x8000000000000000ull : 0ull; }
+    }
+    TileSortLevel1 S1{pstart, totals, np1, 0u};
+    launch_tile_sort(P, A, pbits1, n_tiles1, counts, keymode1, kxor1, key_bytes, c.stream, &S1, true);
+  } else {
+    launch_part_scatter(P, A, pbits1, tile_rows1, n_tiles1, counts, pstart, c.stream);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { delete R; return fail_hip(e, "level-1 partition launch"); }
   // ---- level 2 -----------------------------------------------------------------------------------------------------

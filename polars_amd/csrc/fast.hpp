@@ -95,7 +95,7 @@ struct TileSortLevel1 {
   uint32_t np1, pshift;       // pshift: hash bits consumed by level 1
 };
 void launch_tile_sort(const Plan &p, const PartOut &o, uint32_t pbits, uint32_t n_tiles, uint32_t *offs, int keymode, uint64_t kxor,
-                      int key_bytes, hipStream_t s, const TileSortLevel1 *lvl1 = nullptr);
+                      int key_bytes, hipStream_t s, const TileSortLevel1 *lvl1 = nullptr, bool scatter = false);
 void launch_fold_runs(const Plan &p2, const FoldRunsArgs &a, const OutPlan &o, int key_bytes, uint32_t block, hipStream_t s);
 void launch_merge_emit(const Plan &p, const MergeArgs &a, const OutPlan &o, int key_bytes, uint32_t n_pg, uint32_t block, hipStream_t s);
 // distinct keys among `n_sample` rows taken every `stride` rows -> flags[FLAG_NGROUPS]

@@ -537,19 +537,38 @@ DEVINL void stage_and_store(uint8_t *stage, const T (&x)[TS_R], const uint32_t (
   lds_barrier();
 }
 
+// scatter variant (level 1 of the two-level pipeline): the sorted tile goes to partition-contiguous copies instead of
+// back to its own place; element j of the sorted tile lands at dest[j] (consecutive inside a run)
+template <typename T>
+DEVINL void stage_and_scatter(uint8_t *stage, const T (&x)[TS_R], const uint32_t (&pos)[TS_R], uint32_t live, uint8_t *dst_base,
+                              const uint32_t (&dest)[TS_R], uint32_t nt) {
+#pragma unroll
+  for (int r = 0; r < TS_R; r++) if ((live >> r) & 1) ((T *)stage)[pos[r]] = x[r];
+  lds_barrier();
+#pragma unroll
+  for (int i = 0; i < TS_R; i++) {
+    const uint32_t j = (uint32_t)i * TS_BLOCK + threadIdx.x;
+    if (j < nt) ((T *)dst_base)[dest[i]] = ((const T *)stage)[j];
+  }
+  lds_barrier();
+}
+
 #define TS_NPRE 2 // value columns requested together with the keys
-template <typename KS>
+// SCATTER: `offs` is the per-(partition, tile) exclusive row prefix of k_part_hist + k_part_scan (read, not written),
+// L1.part_start the partitions' first rows in the output; partition = top bits of mix_a(key), as k_part_hist has it.
+template <typename KS, bool SCATTER>
 __global__ void __launch_bounds__(TS_BLOCK) k_tile_sort(Plan P, PartOut O, uint32_t pbits, uint32_t n_tiles, uint32_t *__restrict__ offs,
                                                         int keymode, uint64_t kxor, TileSortLevel1 L1) {
   __shared__ __align__(16) uint32_t hist[(1 << TS_MAX_PBITS) + 4];
   __shared__ __align__(16) uint32_t tmp[TS_BLOCK / 64];
+  __shared__ __align__(16) uint32_t gdelta[SCATTER ? (1 << TS_MAX_PBITS) + 4 : 1]; // output row of a run's first element - its sorted position
   const uint32_t np = 1u << pbits, nh = np + 1; // partition np holds the rows with a null key
   const uint32_t tid = threadIdx.x, tile = blockIdx.x;
   for (uint32_t p = tid; p < nh; p += TS_BLOCK) hist[p] = 0;
   lds_barrier();
   const int64_t r0 = (int64_t)tile * TS_TILE;
   uint32_t nt = (uint32_t)((P.n_rows - r0) < TS_TILE ? (P.n_rows - r0) : TS_TILE);
-  if (L1.part_start) { // level 2: the tile lies inside one tile-aligned level-1 partition; rows behind the partition's end are padding
+  if (!SCATTER && L1.part_start) { // level 2: the tile lies inside one tile-aligned level-1 partition; rows behind the partition's end are padding
     uint32_t lo = 0, hi = L1.np1; // largest p with part_start[p] <= r0
     while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if ((int64_t)L1.part_start[mid] <= r0) lo = mid; else hi = mid; }
     const int64_t left = (int64_t)L1.part_start[lo] + (int64_t)L1.part_rows[lo] - r0;
@@ -579,15 +598,16 @@ __global__ void __launch_bounds__(TS_BLOCK) k_tile_sort(Plan P, PartOut O, uint3
     for (int r = 0; r < TS_R; r++) key[r] = (KS)(raw[r] ^ kxor);
   }
   // the first value columns are requested now and land under the histogram / scan / key phases
-  uint64_t pre[TS_NPRE][TS_R];
+  constexpr int NPRE_ = SCATTER ? 0 : TS_NPRE; // (the scatter variant needs the registers for its destinations)
+  uint64_t pre[NPRE_ ? NPRE_ : 1][TS_R];
 #pragma unroll
-  for (int c = 0; c < TS_NPRE; c++)
+  for (int c = 0; c < NPRE_; c++)
     if (c < P.n_vals) load_raw<TS_R, false>(P.vals[c].values, wbytes(P.vals[c].dtype), row, pre[c]);
 #pragma unroll
   for (int r = 0; r < TS_R; r++) {
     pos[r] = 0;
     if (!((live >> r) & 1)) continue;
-    const uint32_t p = ((nullm >> r) & 1) ? np : part_of(mix_key(key[r]) << L1.pshift, pbits);
+    const uint32_t p = ((nullm >> r) & 1) ? np : (SCATTER ? part_of(mix_a((uint64_t)key[r]), pbits) : part_of(mix_key(key[r]) << L1.pshift, pbits));
     pos[r] = p | (atomicAdd(&hist[p], 1u) << 12);
   }
   lds_barrier();
@@ -595,20 +615,36 @@ __global__ void __launch_bounds__(TS_BLOCK) k_tile_sort(Plan P, PartOut O, uint3
   const uint32_t excl = block_scan_excl_lds(mine, tmp);
   if (tid < nh) {
     hist[tid] = excl;
-    offs[(uint64_t)tid * n_tiles + tile] = excl;
+    if (SCATTER) gdelta[tid] = tid < np ? L1.part_start[tid] + offs[(uint64_t)tid * n_tiles + tile] - excl : 0u;
+    else offs[(uint64_t)tid * n_tiles + tile] = excl;
   }
-  if (tid == 0) offs[(uint64_t)(np + 1) * n_tiles + tile] = nt;
+  if (!SCATTER && tid == 0) offs[(uint64_t)(np + 1) * n_tiles + tile] = nt;
   lds_barrier();
 #pragma unroll
   for (int r = 0; r < TS_R; r++) if ((live >> r) & 1) pos[r] = hist[pos[r] & 0xFFFu] + (pos[r] >> 12);
+  uint32_t dest[TS_R]; // SCATTER: output row of sorted element i * TS_BLOCK + tid
+  if (SCATTER) {
+#pragma unroll
+    for (int i = 0; i < TS_R; i++) {
+      const uint32_t j = (uint32_t)i * TS_BLOCK + tid;
+      uint32_t lo = 0, hi = np; // the partition whose run holds sorted position j: last p with hist[p] <= j
+      while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (hist[mid] <= j) lo = mid; else hi = mid; }
+      dest[i] = j + gdelta[lo];
+    }
+  }
+#define TS_STORE(T, x, dstcol)                                                                              \
+  do {                                                                                                      \
+    if (SCATTER) stage_and_scatter<T>(fsm, x, pos, live, dstcol, dest, nt);                                 \
+    else stage_and_store<T>(fsm, x, pos, live, (dstcol) + (size_t)r0 * sizeof(T), nt);                      \
+  } while (0)
 
-  stage_and_store<KS>(fsm, key, pos, live, O.keys + (size_t)r0 * sizeof(KS), nt);
+  TS_STORE(KS, key, O.keys);
   for (int v = 0; v < P.n_vals; v++) {
     const ValSpec V = P.vals[v];
-    if (v < TS_NPRE) {
+    if (v < NPRE_) {
       uint64_t raw[TS_R];
 #pragma unroll
-      for (int c = 0; c < TS_NPRE; c++)
+      for (int c = 0; c < NPRE_; c++)
         if (v == c) {
 #pragma unroll
           for (int r = 0; r < TS_R; r++) raw[r] = pre[c][r];
@@ -618,7 +654,7 @@ __global__ void __launch_bounds__(TS_BLOCK) k_tile_sort(Plan P, PartOut O, uint3
   {                                                                                                     \
     T x[TS_R];                                                                                          \
     _Pragma("unroll") for (int r = 0; r < TS_R; r++) x[r] = (T)raw[r];                                  \
-    stage_and_store<T>(fsm, x, pos, live, O.vals[v] + (size_t)r0 * sizeof(T), nt);                      \
+    TS_STORE(T, x, O.vals[v]);                                                                          \
   }                                                                                                     \
   break;
         case 1: SORT_PRE(uint8_t)
@@ -633,7 +669,7 @@ __global__ void __launch_bounds__(TS_BLOCK) k_tile_sort(Plan P, PartOut O, uint3
   {                                                                                                     \
     T x[TS_R];                                                                                          \
     _Pragma("unroll") for (int r = 0; r < TS_R; r++) x[r] = ((const T *)V.values)[row[r]];              \
-    stage_and_store<T>(fsm, x, pos, live, O.vals[v] + (size_t)r0 * sizeof(T), nt);                      \
+    TS_STORE(T, x, O.vals[v]);                                                                          \
   }                                                                                                     \
   break;
         case 1: SORT_COL(uint8_t)
@@ -647,9 +683,10 @@ __global__ void __launch_bounds__(TS_BLOCK) k_tile_sort(Plan P, PartOut O, uint3
       uint8_t x[TS_R];
 #pragma unroll
       for (int r = 0; r < TS_R; r++) x[r] = val_valid(V, (int64_t)row[r]) ? 1 : 0;
-      stage_and_store<uint8_t>(fsm, x, pos, live, O.valid[v] + (size_t)r0, nt);
+      TS_STORE(uint8_t, x, O.valid[v]);
     }
   }
+#undef TS_STORE
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1034,13 +1071,22 @@ void launch_fold_rows(const Plan &p, const FoldRowsArgs &a, int key_bytes, bool 
 }
 
 void launch_tile_sort(const Plan &p, const PartOut &o, uint32_t pbits, uint32_t n_tiles, uint32_t *offs, int keymode, uint64_t kxor,
-                      int key_bytes, hipStream_t s, const TileSortLevel1 *lvl1) {
+                      int key_bytes, hipStream_t s, const TileSortLevel1 *lvl1, bool scatter) {
   const TileSortLevel1 l1 = lvl1 ? *lvl1 : TileSortLevel1{nullptr, nullptr, 0u, 0u};
   static bool once = false;
-  if (!once) { allow_big_lds(k_tile_sort<uint32_t>); allow_big_lds(k_tile_sort<uint64_t>); once = true; }
+  if (!once) {
+    allow_big_lds(k_tile_sort<uint32_t, false>); allow_big_lds(k_tile_sort<uint64_t, false>);
+    allow_big_lds(k_tile_sort<uint32_t, true>); allow_big_lds(k_tile_sort<uint64_t, true>);
+    once = true;
+  }
   const size_t bytes = (size_t)TS_TILE * 8;
-  if (key_bytes == 4) hipLaunchKernelGGL(k_tile_sort<uint32_t>, dim3(n_tiles), dim3(TS_BLOCK), bytes, s, p, o, pbits, n_tiles, offs, keymode, kxor, l1);
-  else hipLaunchKernelGGL(k_tile_sort<uint64_t>, dim3(n_tiles), dim3(TS_BLOCK), bytes, s, p, o, pbits, n_tiles, offs, keymode, kxor, l1);
+  if (scatter) { // level 1 of the two-level pipeline: `offs` = k_part_scan's prefixes, lvl1->part_start = the partitions' first rows
+    if (key_bytes == 4) hipLaunchKernelGGL((k_tile_sort<uint32_t, true>), dim3(n_tiles), dim3(TS_BLOCK), bytes, s, p, o, pbits, n_tiles, offs, keymode, kxor, l1);
+    else hipLaunchKernelGGL((k_tile_sort<uint64_t, true>), dim3(n_tiles), dim3(TS_BLOCK), bytes, s, p, o, pbits, n_tiles, offs, keymode, kxor, l1);
+    return;
+  }
+  if (key_bytes == 4) hipLaunchKernelGGL((k_tile_sort<uint32_t, false>), dim3(n_tiles), dim3(TS_BLOCK), bytes, s, p, o, pbits, n_tiles, offs, keymode, kxor, l1);
+  else hipLaunchKernelGGL((k_tile_sort<uint64_t, false>), dim3(n_tiles), dim3(TS_BLOCK), bytes, s, p, o, pbits, n_tiles, offs, keymode, kxor, l1);
 }
 
 template <typename KS, typename SH>
