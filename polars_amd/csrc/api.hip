@@ -1042,12 +1042,21 @@ int run_two_level(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, uint64_t 
   // folds.  Small tables keep four or five leaves in flight per CU.
   uint32_t lb_max = 13;
   const char *dbg_kb = getenv("PLHIP_T2_KB"), *dbg_blk = getenv("PLHIP_T2_BLOCK"), *dbg_p1 = getenv("PLHIP_T2_PBITS1");
-  // (few rows per group: the leaves are all table, and fewer, larger leaves win; measured on config 3 and on q3 at 3e8 rows)
-  const size_t lds_budget = (size_t)(dbg_kb ? atoi(dbg_kb) : ((uint64_t)n / g_est >= 8 ? 32 : 76)) * 1024;
-  while (lb_max > 6 && runs_lds(lb_max) > lds_budget) lb_max--;
-  const double leaf_cap = 0.5 * (double)(1u << lb_max);
+  // Small tables (32 KB) unless they would need 512 or more level-1 partitions (the scatter's runs are then 16 rows):
+  // then 76 KB tables with a quarter of the partitions.  Measured: 256 partitions + small tables beat 128 + large ones
+  // on uniform keys (3e8 rows, 3e7 ids: 14.2 against 16.7 ms) and lose 7 % on config 5 (53.5 against 49.7 ms); small
+  // tables win on skewed keys at 1e8 rows / 1e7 ids (leaf fold 3.3 against 5.1 ms) and on q3 at 3e8 rows (6.7 / 7.1 ms).
+  double leaf_cap = 0;
   uint32_t pbits1 = 4;
-  while (pbits1 < 12 && (double)g_est * 1.3 / ((double)(1u << pbits1) * np2) + 8 > leaf_cap) pbits1++;
+  for (int kb : {32, 76}) {
+    const size_t lds_budget = (size_t)(dbg_kb ? atoi(dbg_kb) : kb) * 1024;
+    lb_max = 13;
+    while (lb_max > 6 && runs_lds(lb_max) > lds_budget) lb_max--;
+    leaf_cap = 0.5 * (double)(1u << lb_max);
+    pbits1 = 4;
+    while (pbits1 < 12 && (double)g_est * 1.3 / ((double)(1u << pbits1) * np2) + 8 > leaf_cap) pbits1++;
+    if (pbits1 < (getenv("PLHIP_T2_SWITCH") ? (uint32_t)atoi(getenv("PLHIP_T2_SWITCH")) : 9u) || dbg_kb) break;
+  }
   if ((double)g_est * 1.3 / ((double)(1u << pbits1) * np2) + 8 > leaf_cap) return PLHIP_OK;
   if (dbg_p1 && (uint32_t)atoi(dbg_p1) > pbits1) pbits1 = (uint32_t)atoi(dbg_p1);
   if (pbits1 + pbits2 + lb_max > 32) return PLHIP_OK; // the table's home slots come from the hash bits below the two levels
@@ -1085,6 +1094,20 @@ int run_two_level(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, uint64_t 
   HIP_TRY(c.dump.reserve(bytes + 256));
   HIP_TRY(c.offs.reserve((size_t)(np2 + 2) * n_tiles2 * 4));
   HIP_TRY(c.flags.reserve(64));
+  // heavy hitters (fast.hpp, HotState): leaves with >= hot_min rows in long runs are folded by several workgroups
+  const bool hot_on = !getenv("PLHIP_T2_NOHOT") && n_items <= (1u << 22);
+  const char *dbg_hc = getenv("PLHIP_T2_HOT_CHUNK"); // (tests: split at small sizes)
+  const uint32_t hot_chunk = dbg_hc ? (uint32_t)std::max(1024, atoi(dbg_hc)) : 65536u, hot_min = 4 * hot_chunk;
+  const uint32_t max_extra = hot_on ? (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(64, (uint64_t)n / hot_chunk / 4)) : 0u;
+  const uint32_t hot_items = max_extra + HOT_MAX_LEAVES;
+  const uint64_t hot_stride = fast_dump_stride(P, lslots, key_bytes);
+  const size_t hoff_state = ((size_t)n_items * 4 + 255) & ~(size_t)255, hoff_hdr = hoff_state + ((sizeof(HotState) + 255) & ~(size_t)255);
+  if (hot_on) {
+    HIP_TRY(c.misc.reserve(hoff_hdr + (size_t)hot_items * sizeof(DumpHdr)));
+    HIP_TRY(c.slots.reserve((size_t)hot_items * hot_stride));
+  }
+  uint32_t *hot_rows = hot_on ? (uint32_t *)c.misc.p : nullptr;
+  HotState *hot_state = hot_on ? (HotState *)((uint8_t *)c.misc.p + hoff_state) : nullptr;
   uint32_t *dflags = (uint32_t *)c.flags.p;
   uint8_t *pa = (uint8_t *)c.part.p, *pb = (uint8_t *)c.dump.p;
   A.keys = pa; B.keys = pb;
@@ -1144,8 +1167,10 @@ int run_two_level(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, uint64_t 
   P1.n_rows = (int64_t)n_pad;
   P1.keys[0].values = A.keys; P1.keys[0].validity = nullptr; P1.keys[0].boff = 0;
   for (int v = 0; v < P.n_vals; v++) { P1.vals[v].values = A.vals[v]; P1.vals[v].validity = A.valid[v]; P1.vals[v].boff = 0; P1.vals[v].valid_bytes = 1; }
-  TileSortLevel1 L1{pstart, totals, np1, pbits1};
+  TileSortLevel1 L1{pstart, totals, np1, pbits1, hot_rows, std::max<uint32_t>(128u, 16u * (uint32_t)TS_TILE / np2), 0u};
+  if (hot_on) HIP_TRY(hipMemsetAsync(hot_rows, 0, (size_t)n_items * 4, c.stream));
   launch_tile_sort(P1, B, pbits2, n_tiles2, (uint32_t *)c.offs.p, key_bytes == 4 ? 1 : 2, 0ull, key_bytes, c.stream, &L1);
+  if (hot_on) launch_hot_plan(hot_rows, (uint32_t)n_items, np2, pstart, hot_min, hot_chunk, max_extra, hot_state, c.stream);
   if ((e = hipGetLastError()) != hipSuccess) { delete R; return fail_hip(e, "level-2 k_tile_sort launch"); }
   hipEventRecord(c.ev[4], c.stream);
   Plan P2 = P; // the key specs stay: the fold decodes the packed keys with them
@@ -1154,6 +1179,10 @@ int run_two_level(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, uint64_t 
   Af.pkeys = B.keys; Af.out_cap = out_cap; Af.flags = dflags; Af.offs = (const uint32_t *)c.offs.p; Af.lbits = lbits; Af.np = np2; Af.w = 1;
   Af.n_pg = np2; Af.has_null_pg = 0; Af.S = np1; Af.n_tiles = n_tiles2; Af.pbits = pbits1 + pbits2;
   Af.host_sig = c.host_sig_dev; Af.seq = seq; Af.disjoint = 1; Af.seg_start = pstart;
+  if (hot_on) {
+    Af.hot = hot_state; Af.hot_of_leaf = hot_rows; Af.max_extra = max_extra;
+    Af.D.base = (uint8_t *)c.slots.p; Af.D.hdr = (DumpHdr *)((uint8_t *)c.misc.p + hoff_hdr); Af.D.item_stride = hot_stride; Af.D.cap = lslots;
+  }
   launch_fold_runs(P2, Af, OP, key_bytes, dbg_blk ? (uint32_t)atoi(dbg_blk) : ((uint64_t)n / n_items >= 8192 ? 512u : 256u), c.stream);
   if (getenv("PLHIP_T2_VERBOSE")) fprintf(stderr, "tilesort2: np1 %u np2 %u lbits %u lb_max %u table %zu B leaves %llu rows/leaf %llu\n", np1, np2, lbits, lb_max, fast_table_bytes(P, lbits, key_bytes), (unsigned long long)n_items, (unsigned long long)((uint64_t)n / n_items));
   if ((e = hipGetLastError()) != hipSuccess) { delete R; return fail_hip(e, "leaf k_fold_runs launch"); }

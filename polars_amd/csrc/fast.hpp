@@ -50,6 +50,19 @@ struct FoldRowsArgs {
   uint32_t pad;
 };
 
+// Heavy hitters in the two-level pipeline: a leaf that holds a hot key has as many rows as the key has, and one
+// workgroup would fold them all.  The level-2 tile sort adds up the long runs per leaf (hot_rows), k_hot_plan turns
+// the leaves above a threshold into entries, and the leaf fold gives every such leaf `chunks` workgroups (chunk 0 = the
+// leaf's own, the others from a block of extra workgroups behind the grid), each over a share of the leaf's tiles; they
+// dump their tables, and the one that finishes last merges the dumps and writes the leaf's output rows.
+#define HOT_MAX_LEAVES 256
+#define HOT_MAX_CHUNKS 256
+struct HotEntry { uint32_t leaf, chunks, first_extra, done; };
+struct HotState {
+  uint32_t n_hot, n_extra, pad[2];
+  HotEntry e[HOT_MAX_LEAVES]; // ascending in leaf and in first_extra; chunk c of entry h dumps into item first_extra + h + c
+};
+
 struct FoldRunsArgs {
   DumpRef D;
   uint32_t *flags;
@@ -68,6 +81,9 @@ struct FoldRunsArgs {
   uint32_t seq;       // there, the word the host spins on (nullptr: no signal)
   uint32_t disjoint;  // two-level pipeline: the S segments are level-1 partitions (disjoint in the keys): every workgroup emits
   const uint32_t *seg_start; // ... and segment s covers the tiles [seg_start[s], seg_start[s + 1]) / TS_TILE (nullptr: equal split)
+  HotState *hot;              // disjoint only, may be nullptr: the split leaves (the grid then has max_extra workgroups behind the leaves')
+  const uint32_t *hot_of_leaf; // [n_pg * S]: entry index + 1, 0 = an ordinary leaf
+  uint32_t max_extra, pad2;
 };
 
 struct MergeArgs {
@@ -93,7 +109,13 @@ struct TileSortLevel1 {
   const uint32_t *part_start; // [np1 + 1], multiples of TS_TILE; nullptr: one flat input of P.n_rows rows
   const uint32_t *part_rows;  // [np1]
   uint32_t np1, pshift;       // pshift: hash bits consumed by level 1
+  uint32_t *hot_rows;         // level 2, may be nullptr: [np1 << pbits] zeroed; runs of at least hot_run rows are added to their leaf's word
+  uint32_t hot_run, pad;
 };
+// hot_rows[] (rows in long runs per leaf) -> H + hot_rows[] rewritten as entry index + 1 / 0.  A leaf is split when it has
+// at least min_rows such rows, into ceil(rows / chunk_rows) chunks (at most HOT_MAX_CHUNKS, at most its tiles).
+void launch_hot_plan(uint32_t *hot_rows, uint32_t n_leaves, uint32_t n_pg, const uint32_t *seg_start, uint32_t min_rows, uint32_t chunk_rows,
+                     uint32_t max_extra, HotState *H, hipStream_t s);
 void launch_tile_sort(const Plan &p, const PartOut &o, uint32_t pbits, uint32_t n_tiles, uint32_t *offs, int keymode, uint64_t kxor,
                       int key_bytes, hipStream_t s, const TileSortLevel1 *lvl1 = nullptr, bool scatter = false);
 void launch_fold_runs(const Plan &p2, const FoldRunsArgs &a, const OutPlan &o, int key_bytes, uint32_t block, hipStream_t s);

@@ -568,9 +568,11 @@ __global__ void __launch_bounds__(TS_BLOCK) k_tile_sort(Plan P, PartOut O, uint3
   lds_barrier();
   const int64_t r0 = (int64_t)tile * TS_TILE;
   uint32_t nt = (uint32_t)((P.n_rows - r0) < TS_TILE ? (P.n_rows - r0) : TS_TILE);
+  uint32_t l1p = 0; // level 2: the level-1 partition of this tile
   if (!SCATTER && L1.part_start) { // level 2: the tile lies inside one tile-aligned level-1 partition; rows behind the partition's end are padding
     uint32_t lo = 0, hi = L1.np1; // largest p with part_start[p] <= r0
     while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if ((int64_t)L1.part_start[mid] <= r0) lo = mid; else hi = mid; }
+    l1p = lo;
     const int64_t left = (int64_t)L1.part_start[lo] + (int64_t)L1.part_rows[lo] - r0;
     nt = left <= 0 ? 0u : (left < TS_TILE ? (uint32_t)left : (uint32_t)TS_TILE);
   }
@@ -612,6 +614,7 @@ __global__ void __launch_bounds__(TS_BLOCK) k_tile_sort(Plan P, PartOut O, uint3
   }
   lds_barrier();
   const uint32_t mine = tid < nh ? hist[tid] : 0;
+  if (!SCATTER && L1.hot_rows && tid < np && mine >= L1.hot_run) atomicAdd(&L1.hot_rows[l1p * np + tid], mine); // a heavy hitter's leaf
   const uint32_t excl = block_scan_excl_lds(mine, tmp);
   if (tid < nh) {
     hist[tid] = excl;
@@ -695,6 +698,99 @@ __global__ void __launch_bounds__(TS_BLOCK) k_tile_sort(Plan P, PartOut O, uint3
 // together.  With one segment per group the workgroup writes the output columns itself.
 // ---------------------------------------------------------------------------------------------------------
 #define RUNS_NPRE 3
+// one compact dump (dump_table) -> the workgroup's LDS table; every thread of the workgroup calls it
+template <typename KS>
+DEVINL void merge_dump(const Plan &P, uint8_t *sm, uint32_t lbits, uint32_t pshift, uint32_t *used, const DumpRef &D, uint32_t item) {
+  const uint32_t lcap = 1u << lbits, lslots = lcap + FP_EXTRA_SLOTS;
+  KS *lkeys = (KS *)sm;
+  const DumpHdr *H = &D.hdr[item];
+  const uint32_t nh = H->n_hash, hs = H->has_sent, hn = H->has_null, n = nh + hs + hn;
+  const uint8_t *base = D.base + (uint64_t)item * D.item_stride;
+  for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) {
+    uint32_t slot;
+    if (k < nh) slot = ltab_slot<KS>(lkeys, lbits, pshift, used, ((const KS *)base)[k]);
+    else if (k == nh && hs) { slot = lcap; used[0] = 1; }
+    else { slot = lcap + 1; used[1] = 1; }
+    if (slot == ~0u) continue; // (table full: used[2] is set, the query is redone)
+    uint32_t loff = al8(lslots * (uint32_t)sizeof(KS));
+    uint64_t goff = al16((uint64_t)D.cap * sizeof(KS));
+    for (int a = 0; a < P.n_accs; a++) {
+      const AccSpec Ac = P.accs[a];
+      const uint64_t part = Ac.width == 8 ? ((const uint64_t *)(base + goff))[k] : (uint64_t)((const uint32_t *)(base + goff))[k];
+      uint8_t *p = sm + loff + slot * Ac.width;
+      loff += al8(lslots * Ac.width);
+      goff += al16((uint64_t)D.cap * Ac.width);
+      if (part == Ac.init) continue; // identity: nothing to fold
+      switch (Ac.op) {
+        case ACC_ADD_U64: atomicAdd((unsigned long long *)p, (unsigned long long)part); break;
+        case ACC_ADD_F64: atomicAdd((double *)p, __longlong_as_double((long long)part)); break;
+        case ACC_MIN_I64: atomicMin((long long *)p, (long long)part); break;
+        case ACC_MAX_I64: atomicMax((long long *)p, (long long)part); break;
+        case ACC_MIN_U64: atomicMin((unsigned long long *)p, (unsigned long long)part); break;
+        case ACC_MAX_U64: atomicMax((unsigned long long *)p, (unsigned long long)part); break;
+        case ACC_CNT_ALL: case ACC_CNT_VALID: atomicAdd((unsigned int *)p, (unsigned int)part); break;
+        case ACC_FIRST_ROW: atomicMin((unsigned int *)p, (unsigned int)part); break;
+      }
+    }
+  }
+}
+
+// One workgroup: the leaves with enough rows in long runs become HotState entries (in leaf order: thread t owns a
+// contiguous range of leaves, two block scans place its entries), hot_rows[leaf] becomes entry index + 1 or 0.
+__global__ void __launch_bounds__(1024) k_hot_plan(uint32_t *__restrict__ hot_rows, uint32_t n_leaves, uint32_t n_pg, const uint32_t *__restrict__ seg_start,
+                                                   uint32_t min_rows, uint32_t chunk_rows, uint32_t max_extra, HotState *__restrict__ H) {
+  __shared__ __align__(16) uint32_t tmp[16];
+  const uint32_t per = (n_leaves + blockDim.x - 1) / blockDim.x;
+  const uint32_t l0 = threadIdx.x * per < n_leaves ? threadIdx.x * per : n_leaves, l1 = l0 + per < n_leaves ? l0 + per : n_leaves;
+  auto chunks_of = [&](uint32_t leaf, uint32_t rows) -> uint32_t {
+    if (rows < min_rows) return 1u;
+    const uint32_t seg = leaf / n_pg, tiles = (seg_start[seg + 1] - seg_start[seg]) / TS_TILE;
+    uint32_t c = (rows + chunk_rows - 1) / chunk_rows;
+    c = c < HOT_MAX_CHUNKS ? c : HOT_MAX_CHUNKS;
+    return c < tiles ? c : tiles;
+  };
+  // too many hot leaves for the entry table or the extra workgroups: the thresholds double until the largest ones fit
+  __shared__ uint32_t s_nh, s_ne, s_th, s_te;
+  if (threadIdx.x == 0) { s_nh = 0; s_ne = 0; }
+  uint32_t nh = 0, ne = 0;
+  for (int round = 0; round < 12; round++) {
+    if (threadIdx.x == 0) { s_th = 0; s_te = 0; }
+    __syncthreads();
+    nh = 0; ne = 0;
+    for (uint32_t l = l0; l < l1; l++) {
+      const uint32_t c = chunks_of(l, hot_rows[l]);
+      if (c > 1) { nh++; ne += c - 1; }
+    }
+    if (nh) { atomicAdd(&s_th, nh); atomicAdd(&s_te, ne); }
+    __syncthreads();
+    const bool fits = s_th <= HOT_MAX_LEAVES && s_te <= max_extra;
+    __syncthreads();
+    if (fits) break;
+    min_rows *= 2; chunk_rows *= 2;
+  }
+  uint32_t h = block_scan_excl(nh, tmp);
+  __syncthreads();
+  uint32_t e = block_scan_excl(ne, tmp);
+  // h, e run over ALL hot leaves in leaf order; both are monotone, so the leaves inside both limits are a prefix and
+  // the accepted entries are dense in H->e[] (past the limits a leaf stays with its one workgroup)
+  for (uint32_t l = l0; l < l1; l++) {
+    const uint32_t c = chunks_of(l, hot_rows[l]);
+    uint32_t mark = 0;
+    if (c > 1) {
+      if (h < HOT_MAX_LEAVES && e + (c - 1) <= max_extra) {
+        H->e[h] = HotEntry{l, c, e, 0u};
+        mark = h + 1;
+        atomicMax(&s_nh, h + 1);
+        atomicMax(&s_ne, e + (c - 1));
+      }
+      h++; e += c - 1;
+    }
+    hot_rows[l] = mark;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) { H->n_hot = s_nh; H->n_extra = s_ne; H->pad[0] = 0; H->pad[1] = 0; }
+}
+
 // The group count reaches the host without a device-to-host copy: every workgroup of the query's last kernel
 // counts itself done (after marking a table overflow, fenced: rare); the last one writes the flags the host needs into pinned
 // host memory as ONE 64-bit word (seq << 32 | overflow << 31 | groups) that the host is spinning on.  Only atomics carry the values (they
@@ -728,9 +824,23 @@ __global__ void __launch_bounds__(1024) k_fold_runs(Plan P, FoldRunsArgs A, OutP
   // are observed to land on one XCD, so they are given neighbouring partitions: the second reader of a line
   // then hits in that XCD's L2 instead of fetching it over the fabric again (speed only, never correctness).
   uint32_t item = blockIdx.x;
-  {
-    const uint32_t n8 = gridDim.x & ~7u;
+  const uint32_t n_main = A.hot ? A.n_pg * A.S : gridDim.x;
+  uint32_t chunk = 0, chunks = 1, hidx = 0, hslot = 0; // a split leaf (HotState): this workgroup folds chunk `chunk` of `chunks`
+  if (item < n_main) {
+    const uint32_t n8 = n_main & ~7u;
     if (item < n8) item = (item & 7u) * (n8 >> 3) + (item >> 3);
+    if (A.hot) {
+      const uint32_t h1 = A.hot_of_leaf[item];
+      if (h1 && h1 <= HOT_MAX_LEAVES) { hidx = h1 - 1; chunks = A.hot->e[hidx].chunks; hslot = A.hot->e[hidx].first_extra + hidx; }
+    }
+  } else { // one of the extra workgroups: chunk >= 1 of a split leaf, or nothing to do
+    const uint32_t e = item - n_main;
+    const uint32_t n_hot = A.hot->n_hot;
+    if (e >= A.hot->n_extra || n_hot == 0 || n_hot > HOT_MAX_LEAVES) { publish_done(A.flags, sh, A.host_sig, A.seq); return; }
+    uint32_t lo = 0, hi = n_hot; // the last entry with first_extra <= e
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (A.hot->e[mid].first_extra <= e) lo = mid; else hi = mid; }
+    hidx = lo; chunks = A.hot->e[lo].chunks; chunk = e - A.hot->e[lo].first_extra + 1; hslot = A.hot->e[lo].first_extra + lo;
+    item = A.hot->e[lo].leaf;
   }
   // two-level pipeline: neighbouring sub-partitions of ONE level-1 partition (their runs are neighbours in memory) are neighbours here
   const uint32_t pg = A.disjoint ? item % A.n_pg : item / A.S, seg = A.disjoint ? item / A.n_pg : item % A.S;
@@ -739,6 +849,11 @@ __global__ void __launch_bounds__(1024) k_fold_runs(Plan P, FoldRunsArgs A, OutP
   const uint32_t per = (A.n_tiles + A.S - 1) / A.S;
   uint32_t t0 = seg * per, t1 = t0 + per < A.n_tiles ? t0 + per : A.n_tiles;
   if (A.seg_start) { t0 = A.seg_start[seg] / TS_TILE; t1 = A.seg_start[seg + 1] / TS_TILE; }
+  if (chunks > 1) {
+    const uint32_t per_c = (t1 - t0 + chunks - 1) / chunks;
+    t0 = t0 + chunk * per_c < t1 ? t0 + chunk * per_c : t1;
+    t1 = t0 + per_c < t1 ? t0 + per_c : t1;
+  }
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const uint32_t *o0 = A.offs + (uint64_t)p0 * A.n_tiles, *o1 = A.offs + (uint64_t)p1 * A.n_tiles;
   constexpr int RUNS_B = SH::STATIC ? 8 : 4; // tiles per wave batch
@@ -782,7 +897,27 @@ __global__ void __launch_bounds__(1024) k_fold_runs(Plan P, FoldRunsArgs A, OutP
   if (sh[2] && threadIdx.x == 0) A.flags[FLAG_OVERFLOW] = 1;
   uint16_t *list = (uint16_t *)(fsm + table_lds_bytes(P, lslots, sizeof(KS)));
   if (A.S == 1 || A.disjoint) {
-    emit_table<KS>(P, fsm, A.lbits, sh, bk, list, O, A.flags, A.out_cap);
+    bool emit = true;
+    if (chunks > 1) { // a split leaf: every chunk dumps its table; the workgroup that finishes last merges them
+      dump_table<KS>(P, fsm, A.lbits, 0, sh, bk, list, A.D, hslot + chunk);
+      __threadfence(); // the dump is visible device-wide before this chunk counts as done
+      __syncthreads();
+      if (threadIdx.x == 0) sh[4] = atomicAdd(&A.hot->e[hidx].done, 1u);
+      __syncthreads();
+      emit = sh[4] == chunks - 1;
+      if (emit) {
+        __threadfence(); // the other chunks' dumps, not stale lines of this XCD's L2
+        const uint32_t over = sh[2];
+        __syncthreads();
+        if (threadIdx.x < 8) sh[threadIdx.x] = threadIdx.x == 2 ? over : 0u;
+        ltab_init<KS>(P, fsm, lslots);
+        __syncthreads();
+        for (uint32_t c = 0; c < chunks; c++) merge_dump<KS>(P, fsm, A.lbits, A.pbits, sh, A.D, hslot + c);
+        __syncthreads();
+        if (sh[2] && threadIdx.x == 0) A.flags[FLAG_OVERFLOW] = 1;
+      }
+    }
+    if (emit) emit_table<KS>(P, fsm, A.lbits, sh, bk, list, O, A.flags, A.out_cap);
     publish_done(A.flags, sh, A.host_sig, A.seq);
   } else dump_table<KS>(P, fsm, A.lbits, 0, sh, bk, list, A.D, item);
 }
@@ -1072,7 +1207,7 @@ void launch_fold_rows(const Plan &p, const FoldRowsArgs &a, int key_bytes, bool 
 
 void launch_tile_sort(const Plan &p, const PartOut &o, uint32_t pbits, uint32_t n_tiles, uint32_t *offs, int keymode, uint64_t kxor,
                       int key_bytes, hipStream_t s, const TileSortLevel1 *lvl1, bool scatter) {
-  const TileSortLevel1 l1 = lvl1 ? *lvl1 : TileSortLevel1{nullptr, nullptr, 0u, 0u};
+  const TileSortLevel1 l1 = lvl1 ? *lvl1 : TileSortLevel1{nullptr, nullptr, 0u, 0u, nullptr, 0u, 0u};
   static bool once = false;
   if (!once) {
     allow_big_lds(k_tile_sort<uint32_t, false>); allow_big_lds(k_tile_sort<uint64_t, false>);
@@ -1093,7 +1228,7 @@ template <typename KS, typename SH>
 void launch_fold_runs_t(const Plan &p2, const FoldRunsArgs &a, const OutPlan &o, size_t bytes, uint32_t block, hipStream_t s) {
   static bool once = false;
   if (!once) { allow_big_lds(k_fold_runs<KS, SH>); once = true; }
-  hipLaunchKernelGGL((k_fold_runs<KS, SH>), dim3(a.n_pg * a.S), dim3(block), bytes, s, p2, a, o);
+  hipLaunchKernelGGL((k_fold_runs<KS, SH>), dim3(a.n_pg * a.S + (a.hot ? a.max_extra : 0u)), dim3(block), bytes, s, p2, a, o);
 }
 
 void launch_fold_runs(const Plan &p2, const FoldRunsArgs &a, const OutPlan &o, int key_bytes, uint32_t block, hipStream_t s) {
@@ -1123,4 +1258,9 @@ void launch_merge_emit(const Plan &p, const MergeArgs &a, const OutPlan &o, int 
 
 void launch_estimate(const Plan &p, int64_t n_sample, int64_t stride, uint32_t *set, uint32_t set_bits, uint32_t *flags, hipStream_t s) {
   hipLaunchKernelGGL(k_estimate, dim3((unsigned)((n_sample + EST_CHUNK - 1) / EST_CHUNK)), dim3(EST_BLOCK), 0, s, p, n_sample, stride, set, set_bits, flags);
+}
+
+void launch_hot_plan(uint32_t *hot_rows, uint32_t n_leaves, uint32_t n_pg, const uint32_t *seg_start, uint32_t min_rows, uint32_t chunk_rows,
+                     uint32_t max_extra, HotState *H, hipStream_t s) {
+  hipLaunchKernelGGL(k_hot_plan, dim3(1), dim3(1024), 0, s, hot_rows, n_leaves, n_pg, seg_start, min_rows, chunk_rows, max_extra, H);
 }

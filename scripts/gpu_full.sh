@@ -1,0 +1,6 @@
+#!/bin/bash
+mkdir -p gpurun_out
+timeout -k 10 900 python -u -m pytest tests -x -q -m gpu --timeout 120 --timeout-method thread > gpurun_out/full_tests.log 2>&1 || { tail -40 gpurun_out/full_tests.log; exit 1; }
+tail -3 gpurun_out/full_tests.log
+STRATS=auto timeout -k 10 200 python scripts/skew_profile.py 1e9 1e8 && \
+STRATS=auto timeout -k 10 200 python scripts/skew_profile.py 1e8 1e7 && bash scripts/gpu_c3.sh

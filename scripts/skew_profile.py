@@ -15,14 +15,14 @@ dev = torch.device("cuda:0")
 g = torch.Generator(device=dev); g.manual_seed(108)
 u = torch.rand(n, device=dev, dtype=torch.float64, generator=g).clamp_min(1e-300)
 z = torch.floor(u.pow(-10.0)).clamp_max(float(ids) * 1e6)
-k = torch.where(torch.rand(n, device=dev, generator=g) < 0.5, (z - 1) % ids, torch.floor(torch.rand(n, device=dev, dtype=torch.float64, generator=g) * ids)).to(torch.int64)
+k = torch.where(torch.rand(n, device=dev, generator=g) < float(os.environ.get("SKEW_FRAC", "0.5")), (z - 1) % ids, torch.floor(torch.rand(n, device=dev, dtype=torch.float64, generator=g) * ids)).to(torch.int64)
 del u, z
 v3 = torch.rand(n, device=dev, dtype=torch.float64, generator=g) * 100
 v1 = torch.randint(1, 6, (n,), device=dev, dtype=torch.int64, generator=g)
 top = torch.bincount((k % 1024).to(torch.int64)).max().item()
 keys, vals = [Column("k", k)], [Column("v3", v3), Column("v1", v1)]
 print(f"rows {n} ids {ids} distinct {int(torch.unique(k).numel())} rows of key 0: {int((k == 0).sum())}", flush=True)
-for strategy in ("auto", "tilesort2", "sort"):
+for strategy in os.environ.get("STRATS", "auto,tilesort2,sort").split(","):
     pa.set_strategy(strategy)
     best = 1e9
     for it in range(3):

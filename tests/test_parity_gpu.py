@@ -916,6 +916,25 @@ def test_two_levels_skew_falls_back(oracle):
     check_parity(oracle, keys, values, [(0, "sum"), (0, "count"), (0, "max")], "tilesort2", what="two levels skew")
 
 
+def test_two_levels_hot_leaves_are_split(oracle, monkeypatch):
+    """Heavy hitters in the two-level pipeline: leaves with many rows are folded by several workgroups whose tables the
+    last one merges (fast.hpp, HotState).  A lowered chunk size makes a dozen leaves split at a size the oracle
+    handles; nullable key (the null group is a heavy hitter too), nullable values, every accumulator kind."""
+    monkeypatch.setenv("PLHIP_T2_HOT_CHUNK", "4096")
+    rng = np.random.default_rng(131)
+    n, ids = 4_000_000, 1_500_000
+    z = np.floor(np.maximum(rng.random(n), 1e-300) ** -10.0)
+    k = np.where(rng.random(n) < 0.5, np.mod(np.minimum(z, 1e15) - 1, ids), np.floor(rng.random(n) * ids)).astype(np.int64)
+    km = rng.random(n) > 0.02
+    keys = [Column("k", k, km)]
+    values = [Column("a", rng.integers(-1000, 1000, n).astype(np.int64)), rand_col(rng, "b", np.float64, n, null_frac=0.1)]
+    aggs = [(0, "sum"), (1, "mean"), (0, "min"), (1, "max"), (0, "count"), (1, "sum")]
+    check_parity(oracle, keys, values, aggs, "tilesort2", what="hot leaves split")
+    assert pa.last_strategy() == "tilesort2"
+    monkeypatch.setenv("PLHIP_T2_NOHOT", "1")
+    check_parity(oracle, keys, values, aggs, "tilesort2", what="hot leaves, one workgroup each")
+
+
 # ---------------------------------------------------------------------------------------------------
 # the reference's FfiPlugin boundary (include/plhip_plugin.h), driven through the Arrow C Data Interface
 # ---------------------------------------------------------------------------------------------------
