@@ -89,9 +89,12 @@ typedef enum plhip_agg_kind {
   PLHIP_AGG_VAR = 7,   /* online_variance over the valid values as f64 (crates/polars-arrow/src/kernels/take_agg/var.rs:11-40;
                           aggregations/mod.rs:781-803,1018-1035): f32 -> f32, everything else -> f64; count <= ddof -> null */
   PLHIP_AGG_STD = 8,   /* sqrt of it (aggregations/mod.rs:841-862,1059-1077) */
-  PLHIP_AGG_MEDIAN = 9 /* agg_median = quantile 0.5, linear interpolation over the sorted valid values, NaN last
+  PLHIP_AGG_MEDIAN = 9, /* agg_median = quantile 0.5, linear interpolation over the sorted valid values, NaN last
                           (dispatch.rs:98-113, chunked_array/ops/aggregate/quantile.rs:19-54,133-175): f32 -> f32,
                           everything else -> f64; no valid value -> null */
+  PLHIP_AGG_N_UNIQUE = 10 /* agg_n_unique (dispatch.rs:82-107) = ChunkUnique::n_unique of the group's values
+                          (chunked_array/ops/unique/mod.rs:136-171): sorted, then one per change of value; nulls are one
+                          value, -0.0 == 0.0, every NaN counts (NaN != NaN); IdxSize (u32); empty group -> null */
 } plhip_agg_kind_t;
 #define PLHIP_AGG_DDOF(d) ((uint32_t)(d) << 8) /* delta degrees of freedom for VAR / STD, in plhip_agg_groups' flags */
 

@@ -192,6 +192,22 @@ def agg_ext(values: Column, kind: str, groups: Groups, ddof: int = 1):
                 if mask is None or mask[r]:
                     out[g], valid[g] = vals[r], True
         return out, valid
+    if kind == "n_unique":
+        # agg_n_unique (dispatch.rs:82-107): empty group -> None, else ChunkUnique::n_unique of the taken values
+        # (chunked_array/ops/unique/mod.rs:136-171): sorted, then one per element that differs from its predecessor
+        # as Option<T> (nulls equal each other; floats compare by IEEE: -0.0 == 0.0, NaN != NaN), as IdxSize
+        out = np.zeros(G, dtype=np.uint32)
+        valid = np.zeros(G, dtype=bool)
+        for g, idx in enumerate(groups.lists()):
+            if not idx:
+                continue
+            x = np.sort(np.array([vals[r] for r in idx if mask is None or mask[r]], dtype=vals.dtype))  # NaN last
+            cnt = 1 if len(x) < len(idx) else 0  # the nulls
+            for i in range(len(x)):
+                if i == 0 or x[i] != x[i - 1]:
+                    cnt += 1
+            out[g], valid[g] = cnt, True
+        return out, valid
     out = np.zeros(G, dtype=np.float32 if vals.dtype == np.float32 else np.float64)
     valid = np.zeros(G, dtype=bool)
     if kind == "median":

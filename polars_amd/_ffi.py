@@ -25,9 +25,9 @@ DTYPE_NAMES = {I8: "i8", I16: "i16", I32: "i32", I64: "i64", U8: "u8", U16: "u16
 HOST, DEVICE = 0, 1
 
 # plhip_agg_kind_t
-AGG_SUM, AGG_MEAN, AGG_MIN, AGG_MAX, AGG_COUNT, AGG_FIRST, AGG_LAST, AGG_VAR, AGG_STD, AGG_MEDIAN = range(10)
+AGG_SUM, AGG_MEAN, AGG_MIN, AGG_MAX, AGG_COUNT, AGG_FIRST, AGG_LAST, AGG_VAR, AGG_STD, AGG_MEDIAN, AGG_N_UNIQUE = range(11)
 AGG_NAMES = {"sum": AGG_SUM, "mean": AGG_MEAN, "min": AGG_MIN, "max": AGG_MAX, "count": AGG_COUNT}
-AGG_GROUPS_ONLY = {"first": AGG_FIRST, "last": AGG_LAST, "var": AGG_VAR, "std": AGG_STD, "median": AGG_MEDIAN}  # plhip_agg_groups only
+AGG_GROUPS_ONLY = {"first": AGG_FIRST, "last": AGG_LAST, "var": AGG_VAR, "std": AGG_STD, "median": AGG_MEDIAN, "n_unique": AGG_N_UNIQUE}  # plhip_agg_groups only
 
 FLAG_MAINTAIN_ORDER = 1
 FLAG_OUTPUT_DEVICE = 2

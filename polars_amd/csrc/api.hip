@@ -1809,7 +1809,7 @@ int32_t plhip_agg_groups(const plhip_column_t *values, int32_t kind, const plhip
   if (!out) return fail(PLHIP_ERR_INVALID, "out is NULL");
   *out = nullptr;
   if (!groups) return fail(PLHIP_ERR_INVALID, "groups handle is NULL");
-  if (kind < 0 || kind > PLHIP_AGG_MEDIAN) return fail(PLHIP_ERR_INVALID, "bad aggregation kind");
+  if (kind < 0 || kind > PLHIP_AGG_N_UNIQUE) return fail(PLHIP_ERR_INVALID, "bad aggregation kind");
   if (kind != PLHIP_AGG_COUNT && !values) return fail(PLHIP_ERR_INVALID, "values is NULL");
   if (values && kind != PLHIP_AGG_COUNT && values->length != groups->n_rows)
     return fail(PLHIP_ERR_SHAPE_MISMATCH, "the column and the groups differ in length");
@@ -1839,6 +1839,7 @@ int32_t plhip_agg_groups(const plhip_column_t *values, int32_t kind, const plhip
     R->n_rows = (int64_t)G; R->on_device = true; R->device = c.device;
     ResultCol col;
     col.dtype = moment ? (dv.dtype == PLHIP_F32 ? PLHIP_F32 : PLHIP_F64) : dv.dtype; // aggregations/mod.rs:781-803, 1018-1035
+    if (kind == PLHIP_AGG_N_UNIQUE) col.dtype = PLHIP_U32; // IdxSize (dispatch.rs:82-107)
     hipError_t e = hipMalloc(&col.values, (size_t)std::max<uint64_t>(G, 1) * dtype_width(col.dtype));
     if (e == hipSuccess) e = hipMalloc((void **)&col.validity, (G / 64 + 1) * 8);
     if (e == hipSuccess) e = hipMemsetAsync(col.validity, 0, (G / 64 + 1) * 8, c.stream);
@@ -1848,14 +1849,18 @@ int32_t plhip_agg_groups(const plhip_column_t *values, int32_t kind, const plhip
     A.values = dv.values; A.validity = dv.validity; A.boff = dv.boff; A.dtype = (uint32_t)dv.dtype; A.width = (uint32_t)dtype_width(dv.dtype);
     A.kind = (uint32_t)kind; A.ddof = (flags >> 8) & 0xFFu; A.out_dtype = (uint32_t)col.dtype;
     A.out = (uint8_t *)col.values; A.out_validity = col.validity;
-    if (kind == PLHIP_AGG_MEDIAN) {
+    if (kind == PLHIP_AGG_MEDIAN || kind == PLHIP_AGG_N_UNIQUE) {
       if (n > 0x7FFFFFFFll) { delete R; return fail(PLHIP_ERR_INVALID, "too many rows for the segmented sort"); }
       size_t tb = 0;
       e = median_temp_bytes((uint64_t)n, G, &tb);
       const size_t n8 = ((size_t)std::max<int64_t>(n, 1) * 8 + 255) & ~(size_t)255;
       if (e == hipSuccess) e = c.table.reserve(2 * n8);
       if (e == hipSuccess) e = c.sortkeys.reserve(tb + 256);
-      if (e == hipSuccess)
+      if (e == hipSuccess && kind == PLHIP_AGG_N_UNIQUE) e = c.rank.reserve((G / 16 + 1) * 4);
+      if (e == hipSuccess && kind == PLHIP_AGG_N_UNIQUE)
+        e = launch_n_unique(A, offsets, indices, (uint64_t)n, G, (uint64_t *)c.table.p, (uint64_t *)((uint8_t *)c.table.p + n8), (uint32_t *)c.rank.p,
+                            c.sortkeys.p, tb, c.stream);
+      else if (e == hipSuccess)
         e = launch_median(A, offsets, indices, (uint64_t)n, G, (uint64_t *)c.table.p, (uint64_t *)((uint8_t *)c.table.p + n8), c.sortkeys.p, tb, c.stream);
     } else {
       launch_agg_groups_ext(A, offsets, indices, G, moment && G > 0 && (uint64_t)n / G >= 64, c.stream);

@@ -89,7 +89,10 @@ struct AggExtArgs {
   uint8_t *out_validity; // zeroed bitmap
 };
 #define AGG_EXT_MEDIAN 9
+#define AGG_EXT_N_UNIQUE 10
 hipError_t median_temp_bytes(uint64_t n, uint64_t G, size_t *bytes);
+hipError_t launch_n_unique(const AggExtArgs &a, const uint32_t *offsets, const uint32_t *indices, uint64_t n, uint64_t G, uint64_t *codes_a,
+                           uint64_t *codes_b, uint32_t *marks, void *temp, size_t temp_bytes, hipStream_t s);
 hipError_t launch_median(const AggExtArgs &a, const uint32_t *offsets, const uint32_t *indices, uint64_t n, uint64_t G, uint64_t *codes_a,
                          uint64_t *codes_b, void *temp, size_t temp_bytes, hipStream_t s);
 void launch_agg_groups_ext(const AggExtArgs &a, const uint32_t *offsets, const uint32_t *indices, uint64_t G, bool wave, hipStream_t s);

@@ -260,6 +260,79 @@ __global__ void __launch_bounds__(256) k_gather_ordered(AggExtArgs A, const uint
   }
   codes[i] = c;
 }
+// ---- n_unique over CSR groups (agg_n_unique, dispatch.rs:82-107 -> ChunkUnique::n_unique, chunked_array/ops/unique/
+// mod.rs:136-171: the group's values sorted, one per change of value with Option<T> / IEEE comparison): exact
+// order-preserving u64 codes (integers by value, floats by f64 value with -0.0 folded onto 0.0 and one NaN code), nulls
+// as the largest code, the same segmented sort, then every element that differs from its predecessor in the segment
+// (or is a NaN: NaN != NaN) counts one for its group.  A real value whose code is the nulls' (u64::MAX / i64::MAX) would
+// merge with them: both sightings are recorded per group and the count corrected.
+#define NU_NAN_CODE 0xFFF8000000000000ull // f64_ordered(canonical NaN)
+DEVINL uint64_t exact_code(const uint8_t *p, uint32_t dtype, int64_t row) {
+  switch (dtype) {
+    case PLHIP_I8: return (uint64_t)(int64_t)((const int8_t *)p)[row] ^ 0x8000000000000000ull;
+    case PLHIP_I16: return (uint64_t)(int64_t)((const int16_t *)p)[row] ^ 0x8000000000000000ull;
+    case PLHIP_I32: return (uint64_t)(int64_t)((const int32_t *)p)[row] ^ 0x8000000000000000ull;
+    case PLHIP_I64: return (uint64_t)((const int64_t *)p)[row] ^ 0x8000000000000000ull;
+    case PLHIP_U8: return p[row];
+    case PLHIP_U16: return ((const uint16_t *)p)[row];
+    case PLHIP_U32: return ((const uint32_t *)p)[row];
+    case PLHIP_U64: return ((const uint64_t *)p)[row];
+    default: {
+      double d = dtype == PLHIP_F32 ? (double)((const float *)p)[row] : ((const double *)p)[row];
+      if (d != d) return NU_NAN_CODE;
+      if (d == 0.0) d = 0.0; // -0.0 == 0.0
+      return f64_ordered(d);
+    }
+  }
+}
+DEVINL uint32_t segment_of(const uint32_t *__restrict__ offsets, uint64_t G, uint32_t i) { // last g with offsets[g] <= i
+  uint64_t lo = 0, hi = G;
+  while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (offsets[mid] <= i) lo = mid; else hi = mid; }
+  return (uint32_t)lo;
+}
+// marks[g] bit 0: the group holds a null, bit 1: it holds a value whose code is the nulls'
+__global__ void __launch_bounds__(256) k_gather_exact(AggExtArgs A, const uint32_t *__restrict__ indices, const uint32_t *__restrict__ offsets,
+                                                      uint64_t n, uint64_t G, uint64_t *__restrict__ codes, uint32_t *__restrict__ marks) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t row = indices[i];
+  uint64_t c = ~0ull;
+  uint32_t mark = 1u;
+  if (bit_valid(A.validity, A.boff, row)) {
+    c = exact_code(A.values, A.dtype, row);
+    mark = c == ~0ull ? 2u : 0u;
+  }
+  codes[i] = c;
+  if (mark) {
+    const uint32_t g = segment_of(offsets, G, (uint32_t)i);
+    atomicOr(&marks[g >> 4], mark << ((g & 15u) * 2u));
+  }
+}
+__global__ void __launch_bounds__(256) k_count_changes(AggExtArgs A, const uint64_t *__restrict__ sorted, const uint32_t *__restrict__ offsets,
+                                                       uint64_t n, uint64_t G, uint32_t is_float) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t c = sorted[i];
+  bool counts = i == 0 || sorted[i - 1] != c || (is_float && c == NU_NAN_CODE);
+  uint32_t g = 0;
+  bool have_g = false;
+  if (!counts) { // equal to its predecessor: still the first of its segment?
+    g = segment_of(offsets, G, (uint32_t)i);
+    have_g = true;
+    counts = offsets[g] == (uint32_t)i;
+  }
+  if (!counts) return;
+  if (!have_g) g = segment_of(offsets, G, (uint32_t)i);
+  atomicAdd((unsigned int *)A.out + g, 1u);
+}
+__global__ void __launch_bounds__(256) k_n_unique_finish(AggExtArgs A, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ marks, uint64_t G) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  if (offsets[g + 1] == offsets[g]) return; // empty group: null
+  const uint32_t m = (marks[g >> 4] >> ((g & 15u) * 2u)) & 3u;
+  if (m == 3u) ((uint32_t *)A.out)[g] += 1u; // nulls and the largest value shared one code
+  atomicOr((unsigned int *)A.out_validity + (g >> 5), 1u << (g & 31));
+}
 __global__ void __launch_bounds__(256) k_median(AggExtArgs A, const uint64_t *__restrict__ sorted, const uint32_t *__restrict__ offsets, uint64_t G) {
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= G) return;
@@ -300,6 +373,25 @@ hipError_t launch_median(const AggExtArgs &a, const uint32_t *offsets, const uin
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(k_median, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, s, a, codes_b, offsets, G);
+  return hipGetLastError();
+}
+
+// marks: (G / 16 + 1) u32; A.out: G u32 -- both zeroed here
+hipError_t launch_n_unique(const AggExtArgs &a, const uint32_t *offsets, const uint32_t *indices, uint64_t n, uint64_t G, uint64_t *codes_a,
+                           uint64_t *codes_b, uint32_t *marks, void *temp, size_t temp_bytes, hipStream_t s) {
+  if (!G) return hipSuccess;
+  hipError_t e = hipMemsetAsync(marks, 0, (G / 16 + 1) * 4, s);
+  if (e == hipSuccess) e = hipMemsetAsync(a.out, 0, G * 4, s);
+  if (e != hipSuccess) return e;
+  if (n) {
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_gather_exact, dim3(grid), dim3(256), 0, s, a, indices, offsets, n, G, codes_a, marks);
+    e = rocprim::segmented_radix_sort_keys(temp, temp_bytes, codes_a, codes_b, (unsigned int)n, (unsigned int)G, offsets, offsets + 1, 0, 64, s);
+    if (e != hipSuccess) return e;
+    const uint32_t is_float = a.dtype == PLHIP_F32 || a.dtype == PLHIP_F64;
+    hipLaunchKernelGGL(k_count_changes, dim3(grid), dim3(256), 0, s, a, codes_b, offsets, n, G, is_float);
+  }
+  hipLaunchKernelGGL(k_n_unique_finish, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, s, a, offsets, marks, G);
   return hipGetLastError();
 }
 

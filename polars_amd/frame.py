@@ -251,6 +251,9 @@ class GroupBy:
     def median(self) -> DataFrame:
         return self._two_step("median", "median")
 
+    def n_unique(self) -> DataFrame:
+        return self._two_step("n_unique", "n_unique")
+
 
 class LazyFrame:
     def __init__(self, df: DataFrame):
@@ -441,7 +444,7 @@ def group_tuples(keys: Sequence[Column], sorted_: bool = False, location: int = 
 
 
 def agg_groups(values: Column | None, kind: str, groups: Groups, ddof: int = 1) -> Column:
-    """Series::agg_sum/mean/min/max/first/last/var/std/median on GroupsProxy::Idx and GroupsProxy::group_count
+    """Series::agg_sum/mean/min/max/first/last/var/std/median/n_unique on GroupsProxy::Idx and GroupsProxy::group_count
     (kind='count') through plhip_agg_groups.  Returns the one output column (host).  `ddof`: var / std."""
     L = _ffi.lib()
     h = C.c_void_p()

@@ -86,3 +86,13 @@ def test_agg_ext_known_answers(oracle):
     assert m.tolist() == [False, True] and v[1] == 8
     v, m = oracle.agg_ext(Column("x", np.array([5, 6, 8], dtype=np.int64), np.array([False, True, True])), "last", g)
     assert m.tolist() == [True, True] and v.tolist() == [6, 8]
+    # test_group_by_agg_n_unique_floats (py-polars/tests/unit/dataframe/test_df.py:1726-1734): [1.0, 2.0 | 2.0] -> [2, 1]
+    for dt in (np.float32, np.float64):
+        v, m = oracle.agg_ext(Column("b", np.array([1.0, 2.0, 2.0], dtype=dt)), "n_unique", g)
+        assert v.dtype == np.uint32 and v.tolist() == [2, 1] and m.all()
+    # test_group_by_shorthands (test_group_by.py:59-93): a = [1..5], c = [None, 1, None, 1, None] by b = [a, a, b, b, b]
+    g5 = oracle.Groups([Column("b", np.array([10, 10, 20, 20, 20], dtype=np.int32))], True)
+    v, _ = oracle.agg_ext(Column("a", np.array([1, 2, 3, 4, 5], dtype=np.int64)), "n_unique", g5)
+    assert v.tolist() == [2, 3]
+    v, _ = oracle.agg_ext(Column("c", np.array([0, 1, 0, 1, 0], dtype=np.int64), np.array([False, True, False, True, False])), "n_unique", g5)
+    assert v.tolist() == [2, 2]

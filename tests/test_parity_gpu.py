@@ -382,14 +382,14 @@ def test_agg_groups_first_last_var_std(oracle, dt):
         keys = [rand_col(rng, "k", np.int64, n, card=card)]
         v = rand_col(rng, "v", dt, n, null_frac=0.15, lo=0 if np.dtype(dt).kind != "f" else None, hi=1000 if np.dtype(dt).kind != "f" else None)
         g_o, g_p = oracle.Groups(keys, True), pa.group_tuples(keys, True)
-        for kind in ("first", "last", "var", "std", "median"):
+        for kind in ("first", "last", "var", "std", "median", "n_unique"):
             for ddof in ((0, 1, 2) if kind in ("var", "std") else (1,)):
                 wv, wm = oracle.agg_ext(v, kind, g_o, ddof)
                 got = pa.agg_groups(v, kind, g_p, ddof=ddof)
                 gv, gm = got.to_numpy(), got.valid_mask()
                 gm = np.ones(len(gv), bool) if gm is None else gm
                 assert gv.dtype == wv.dtype and np.array_equal(gm, wm), (kind, ddof)
-                if kind in ("first", "last"):
+                if kind in ("first", "last", "n_unique"):
                     assert np.array_equal(gv[gm].view(np.uint8), wv[wm].view(np.uint8)), kind
                 else:
                     np.testing.assert_allclose(gv[gm].astype(np.float64), wv[wm].astype(np.float64),
@@ -418,6 +418,32 @@ def test_group_by_shorthands_first_last_median():
     assert gb().first().rows() == [(10, 1, None), (20, 3, None)]
     assert gb().last().rows() == [(10, 2, 1), (20, 5, None)]
     assert gb().median().rows() == [(10, 1.5, 1.0), (20, 4.0, 1.0)]
+    assert gb().n_unique().rows() == [(10, 2, 2), (20, 3, 2)]  # test_group_by.py:81: the nulls are one value
+
+
+def test_agg_groups_n_unique_edges(oracle):
+    """agg_n_unique (dispatch.rs:82-107 over unique/mod.rs:136-171): test_group_by_agg_n_unique_floats (test_df.py:1726-1734:
+    b = [1.0, 2.0 | 2.0] by a = [1, 1 | 3] -> [2, 1], f32 and f64); -0.0 == 0.0, every NaN counts; a value equal to the
+    dtype's maximum beside nulls (they share the sort code and are told apart by the per-group marks); i64 values that
+    differ only below f64 precision; an empty group (slice of nothing) stays null."""
+    nan = float("nan")
+    for dt in (np.float32, np.float64):
+        g = pa.group_tuples([Column("a", np.array([1, 1, 3], dtype=np.int64))], True)
+        got = pa.agg_groups(Column("b", np.array([1.0, 2.0, 2.0], dtype=dt)), "n_unique", g)
+        assert got.to_numpy().dtype == np.uint32 and got.to_list() == [2, 1]
+    cases = [
+        Column("f", np.array([-0.0, 0.0, nan, nan, 1.0, 1.0, nan, 5.0], dtype=np.float64)),
+        Column("f", np.array([-0.0, 0.0, nan, nan, 1.0, 1.0, nan, 5.0], dtype=np.float32), np.array([1, 1, 1, 0, 1, 1, 1, 0], bool)),
+        Column("u", np.array([2**64 - 1, 2**64 - 1, 0, 7, 2**64 - 1, 7, 1, 1], dtype=np.uint64), np.array([1, 0, 1, 1, 1, 0, 1, 1], bool)),
+        Column("i", np.array([2**63 - 1, 2**63 - 2, 2**53, 2**53 + 1, -2**63, 2**53 + 1, 0, 0], dtype=np.int64), np.array([1, 1, 1, 1, 1, 1, 0, 0], bool)),
+        Column("b", np.array([-128, 127, 127, 0, 0, -128, 5, 5], dtype=np.int8)),
+    ]
+    keys = [Column("k", np.array([1, 1, 1, 1, 2, 2, 2, 2], dtype=np.int32))]
+    g_o, g_p = oracle.Groups(keys, True), pa.group_tuples(keys, True)
+    for v in cases:
+        wv, wm = oracle.agg_ext(v, "n_unique", g_o)
+        got = pa.agg_groups(v, "n_unique", g_p)
+        assert got.to_numpy().tolist() == wv.tolist() and wm.all() and (got.valid_mask() is None or got.valid_mask().all()), v.name
     nan = float("nan")
     f = pa.DataFrame({"k": np.zeros(5, dtype=np.int32), "x": np.array([3.0, nan, 1.0, 2.0, nan])})
     assert f.group_by("k").median()["x_median"].to_list() == [3.0]  # NaN sorts last: [1, 2, 3, nan, nan] -> 3
