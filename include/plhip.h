@@ -263,6 +263,18 @@ void plhip_groups_free(plhip_groups_t *g);
 int32_t plhip_agg_groups(const plhip_column_t *values, int32_t kind, const plhip_groups_t *groups,
                          uint32_t flags, plhip_result_t **out);
 
+/* QuantileInterpolOptions (crates/polars-arrow/src/kernels/rolling/no_nulls/mod.rs:70-77) */
+typedef enum plhip_quantile_interpol {
+  PLHIP_QUANTILE_NEAREST = 0, PLHIP_QUANTILE_LOWER = 1, PLHIP_QUANTILE_HIGHER = 2, PLHIP_QUANTILE_MIDPOINT = 3, PLHIP_QUANTILE_LINEAR = 4
+} plhip_quantile_interpol_t;
+/* Series::agg_quantile on GroupsProxy::Idx (dispatch.rs:115-140 -> agg_quantile_generic, aggregations/mod.rs:333-414;
+ * quantile_idx / linear_interpol / midpoint_interpol / generic_quantile, chunked_array/ops/aggregate/quantile.rs:19-61,
+ * 133-179): the group's valid values sorted ascending (NaN last), index arithmetic in f64 with the group's null count
+ * as the reference has it; f32 column -> f32 (the f64 answer cast), everything else -> f64; no valid value -> null; a
+ * quantile outside [0, 1] -> an all-null column of the input dtype (mod.rs:346-349). */
+int32_t plhip_agg_groups_quantile(const plhip_column_t *values, const plhip_groups_t *groups, double quantile,
+                                  int32_t interpolation, uint32_t flags, plhip_result_t **out);
+
 /* ---- exchange step of the row-sharded group-by (one process per GPU) ---------------------------- */
 
 /* The reference runs the partitioned group-by between THREADS: local group-by with mergeable partials ->

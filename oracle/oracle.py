@@ -9,6 +9,8 @@ import ctypes as C
 import subprocess
 from pathlib import Path
 
+import math
+
 import numpy as np
 
 from polars_amd import _ffi
@@ -173,6 +175,52 @@ def sorted_key_groups(key: Column) -> list[list[int]]:
     return out
 
 
+INTERPOLATIONS = ("nearest", "lower", "higher", "midpoint", "linear")
+
+
+def agg_quantile(values: Column, quantile: float, interpolation: str, groups: Groups):
+    """agg_quantile over GroupsProxy::Idx (dispatch.rs:115-140 -> agg_quantile_generic, aggregations/mod.rs:333-362):
+    per group generic_quantile / quantile_slice (chunked_array/ops/aggregate/quantile.rs:19-61, 90-179) of the taken
+    values: quantile_idx counts in the sorted column WITH its nulls in front -- base_idx = trunc(((len - nulls) [- 1]) * q
+    + nulls) (ceil for Higher; Nearest without the - 1), clamped to len - 1; float_idx = (len - nulls - 1) * q + nulls;
+    top_idx = ceil(float_idx) -- Midpoint / Linear interpolate towards sorted[idx + 1] when top_idx != idx; all in f64,
+    an f32 column's answer is that cast (quantile.rs:231-246).  A quantile outside [0, 1] -> all-null column of the input
+    dtype (mod.rs:346-349).  Returns (values ndarray, valid bool ndarray)."""
+    vals = values.to_numpy()
+    mask = values.valid_mask()
+    G = groups.n_groups
+    if not 0.0 <= quantile <= 1.0:
+        return np.zeros(G, dtype=vals.dtype), np.zeros(G, dtype=bool)
+    out = np.zeros(G, dtype=np.float32 if vals.dtype == np.float32 else np.float64)
+    valid = np.zeros(G, dtype=bool)
+    for g, idx in enumerate(groups.lists()):
+        x = np.sort(np.array([vals[r] for r in idx if mask is None or mask[r]], dtype=vals.dtype))  # NaN last
+        length, m = len(idx), len(x)
+        if m == 0:
+            continue
+        nc = length - m
+        float_idx = (float(m) - 1.0) * quantile + float(nc)
+        if interpolation == "nearest":
+            base = int(float(m) * quantile + float(nc))
+        elif interpolation == "higher":
+            base = int(math.ceil(float_idx))
+        else:
+            base = int(float_idx)
+        base = min(max(base, 0), length - 1)
+        top = int(math.ceil(float_idx))
+        i = base - nc
+        lower = float(x[i])
+        r = lower
+        if interpolation in ("midpoint", "linear") and top != base:
+            upper = float(x[i + 1])
+            if lower != upper:
+                r = (lower + upper) / 2.0 if interpolation == "midpoint" else (float_idx - float(base)) * (upper - lower) + lower
+        with np.errstate(over="ignore"):
+            out[g] = r
+        valid[g] = True
+    return out, valid
+
+
 def agg_ext(values: Column, kind: str, groups: Groups, ddof: int = 1):
     """first / last / var / std / median over GroupsProxy::Idx, restated in plain Python (small inputs only):
     agg_first / agg_last (crates/polars-core/src/frame/group_by/aggregations/dispatch.rs:47-76: the value, null
@@ -213,7 +261,7 @@ def agg_ext(values: Column, kind: str, groups: Groups, ddof: int = 1):
     if kind == "median":
         # agg_median = quantile(0.5, Linear) per group (dispatch.rs:98-113; quantile_idx / linear_interpol /
         # generic_quantile, chunked_array/ops/aggregate/quantile.rs:19-54,133-175): valid values sorted ascending
-        # (NaN last), float_idx = (m - 1) * 0.5, lower + (float_idx - idx) * (upper - lower) in the column's float type
+        # (NaN last), float_idx = (m - 1) * 0.5, lower + (float_idx - idx) * (upper - lower) in f64, cast for an f32 column
         ft = out.dtype.type
         for g, idx in enumerate(groups.lists()):
             x = np.array([vals[r] for r in idx if mask is None or mask[r]], dtype=vals.dtype)
@@ -222,8 +270,8 @@ def agg_ext(values: Column, kind: str, groups: Groups, ddof: int = 1):
             x = np.sort(x)
             float_idx = (len(x) - 1.0) * 0.5
             i, top = int(float_idx), int(np.ceil(float_idx))
-            lower, upper = ft(x[i]), ft(x[top])
-            out[g] = lower if lower == upper else (ft(float_idx) - ft(i)) * (upper - lower) + lower
+            lower, upper = float(x[i]), float(x[top])  # f64 throughout; an f32 column's answer is the cast (quantile.rs:231-246)
+            out[g] = ft(lower if lower == upper else (float_idx - float(i)) * (upper - lower) + lower)
             valid[g] = True
         return out, valid
     for g, idx in enumerate(groups.lists()):

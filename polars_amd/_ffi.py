@@ -181,6 +181,8 @@ def lib():
     L.plhip_groups_free.restype = None
     L.plhip_agg_groups.argtypes = [P(ColumnStruct), i32, vp, u32, P(vp)]
     L.plhip_agg_groups.restype = i32
+    L.plhip_agg_groups_quantile.argtypes = [P(ColumnStruct), vp, C.c_double, i32, u32, P(vp)]
+    L.plhip_agg_groups_quantile.restype = i32
     L.plhip_result_record_bytes.argtypes = [vp]
     L.plhip_result_record_bytes.restype = i64
     L.plhip_result_pack_by_owner.argtypes = [vp, i32, u64, i32, vp, P(i64)]
@@ -214,5 +216,5 @@ EXPORTED_SYMBOLS = [
     "plhip_last_kernel_ms", "plhip_memcpy", "plhip_last_kernel_breakdown", "plhip_vec_hash", "plhip_group_by_agg", "plhip_group_by_agg_opts", "plhip_result_num_rows",
     "plhip_result_num_columns", "plhip_result_column", "plhip_result_free", "plhip_group_tuples",
     "plhip_groups_num_groups", "plhip_groups_num_rows", "plhip_groups_buffers", "plhip_groups_free",
-    "plhip_agg_groups", "plhip_result_record_bytes", "plhip_result_pack_by_owner", "plhip_records_to_frame", "plhip_merge_records", "plhip_finalize_partial", "plhip_slot_bytes", "plhip_result_pack_slots", "plhip_merge_slots",
+    "plhip_agg_groups", "plhip_agg_groups_quantile", "plhip_result_record_bytes", "plhip_result_pack_by_owner", "plhip_records_to_frame", "plhip_merge_records", "plhip_finalize_partial", "plhip_slot_bytes", "plhip_result_pack_slots", "plhip_merge_slots",
 ]

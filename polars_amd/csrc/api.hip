@@ -1803,13 +1803,12 @@ int32_t plhip_group_tuples(const plhip_column_t *keys, int32_t n_keys, int32_t s
   return PLHIP_OK;
 }
 
-// Series::agg_sum / agg_mean / agg_min / agg_max and GroupsProxy::group_count over the CSR groups.
-int32_t plhip_agg_groups(const plhip_column_t *values, int32_t kind, const plhip_groups_t *groups, uint32_t flags,
-                         plhip_result_t **out) {
+static int32_t agg_groups_impl(const plhip_column_t *values, int32_t kind, const plhip_groups_t *groups, uint32_t flags, double quantile,
+                               int interp, plhip_result_t **out) {
   if (!out) return fail(PLHIP_ERR_INVALID, "out is NULL");
   *out = nullptr;
   if (!groups) return fail(PLHIP_ERR_INVALID, "groups handle is NULL");
-  if (kind < 0 || kind > PLHIP_AGG_N_UNIQUE) return fail(PLHIP_ERR_INVALID, "bad aggregation kind");
+  if (kind < 0 || kind > AGG_EXT_QUANTILE) return fail(PLHIP_ERR_INVALID, "bad aggregation kind");
   if (kind != PLHIP_AGG_COUNT && !values) return fail(PLHIP_ERR_INVALID, "values is NULL");
   if (values && kind != PLHIP_AGG_COUNT && values->length != groups->n_rows)
     return fail(PLHIP_ERR_SHAPE_MISMATCH, "the column and the groups differ in length");
@@ -1833,7 +1832,7 @@ int32_t plhip_agg_groups(const plhip_column_t *values, int32_t kind, const plhip
       if (n) HIP_TRY(hipMemcpyAsync(d_idx, groups->indices, (size_t)n * 4, hipMemcpyHostToDevice, c.stream));
       offsets = (const uint32_t *)d_off; indices = (const uint32_t *)d_idx;
     }
-    const bool moment = kind == PLHIP_AGG_VAR || kind == PLHIP_AGG_STD || kind == PLHIP_AGG_MEDIAN; // float-valued results
+    const bool moment = kind == PLHIP_AGG_VAR || kind == PLHIP_AGG_STD || kind == PLHIP_AGG_MEDIAN || kind == AGG_EXT_QUANTILE; // float-valued results
     plhip_result *R = new (std::nothrow) plhip_result();
     if (!R) return fail(PLHIP_ERR_OOM, "host allocation failed");
     R->n_rows = (int64_t)G; R->on_device = true; R->device = c.device;
@@ -1849,7 +1848,7 @@ int32_t plhip_agg_groups(const plhip_column_t *values, int32_t kind, const plhip
     A.values = dv.values; A.validity = dv.validity; A.boff = dv.boff; A.dtype = (uint32_t)dv.dtype; A.width = (uint32_t)dtype_width(dv.dtype);
     A.kind = (uint32_t)kind; A.ddof = (flags >> 8) & 0xFFu; A.out_dtype = (uint32_t)col.dtype;
     A.out = (uint8_t *)col.values; A.out_validity = col.validity;
-    if (kind == PLHIP_AGG_MEDIAN || kind == PLHIP_AGG_N_UNIQUE) {
+    if (kind == PLHIP_AGG_MEDIAN || kind == PLHIP_AGG_N_UNIQUE || kind == AGG_EXT_QUANTILE) {
       if (n > 0x7FFFFFFFll) { delete R; return fail(PLHIP_ERR_INVALID, "too many rows for the segmented sort"); }
       size_t tb = 0;
       e = median_temp_bytes((uint64_t)n, G, &tb);
@@ -1861,7 +1860,8 @@ int32_t plhip_agg_groups(const plhip_column_t *values, int32_t kind, const plhip
         e = launch_n_unique(A, offsets, indices, (uint64_t)n, G, (uint64_t *)c.table.p, (uint64_t *)((uint8_t *)c.table.p + n8), (uint32_t *)c.rank.p,
                             c.sortkeys.p, tb, c.stream);
       else if (e == hipSuccess)
-        e = launch_median(A, offsets, indices, (uint64_t)n, G, (uint64_t *)c.table.p, (uint64_t *)((uint8_t *)c.table.p + n8), c.sortkeys.p, tb, c.stream);
+        e = launch_quantile(A, offsets, indices, (uint64_t)n, G, (uint64_t *)c.table.p, (uint64_t *)((uint8_t *)c.table.p + n8), c.sortkeys.p, tb,
+                            quantile, interp, c.stream);
     } else {
       launch_agg_groups_ext(A, offsets, indices, G, moment && G > 0 && (uint64_t)n / G >= 64, c.stream);
       e = hipGetLastError();
@@ -1992,6 +1992,44 @@ int pack_impl(const plhip_result_t *r, int32_t n_keys, uint64_t null_hash, int32
   return PLHIP_OK;
 }
 } // namespace
+
+// Series::agg_sum / agg_mean / agg_min / agg_max and GroupsProxy::group_count over the CSR groups; first / last / var / std /
+// median / n_unique through their own kernels.
+int32_t plhip_agg_groups(const plhip_column_t *values, int32_t kind, const plhip_groups_t *groups, uint32_t flags,
+                         plhip_result_t **out) {
+  if (kind < 0 || kind > PLHIP_AGG_N_UNIQUE) { if (out) *out = nullptr; return fail(PLHIP_ERR_INVALID, "bad aggregation kind"); }
+  return agg_groups_impl(values, kind, groups, flags, 0.5, 4 /* Linear: agg_median */, out);
+}
+
+// Series::agg_quantile (dispatch.rs:115-140 -> agg_quantile_generic, aggregations/mod.rs:333-414): a quantile outside [0, 1]
+// answers an all-null column of the INPUT dtype (mod.rs:346-349).
+int32_t plhip_agg_groups_quantile(const plhip_column_t *values, const plhip_groups_t *groups, double quantile, int32_t interpolation,
+                                  uint32_t flags, plhip_result_t **out) {
+  if (!out) return fail(PLHIP_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  if (!values || !groups) return fail(PLHIP_ERR_INVALID, "values / groups is NULL");
+  if (interpolation < 0 || interpolation > PLHIP_QUANTILE_LINEAR) return fail(PLHIP_ERR_INVALID, "bad interpolation");
+  if (!(quantile >= 0.0 && quantile <= 1.0)) {
+    if (values->dtype < 0 || values->dtype > PLHIP_F64) return fail(PLHIP_ERR_UNSUPPORTED_DTYPE, "unsupported dtype");
+    int rc = ensure_ctx();
+    if (rc) return rc;
+    const uint64_t G = (uint64_t)groups->n_groups;
+    plhip_result *R = new (std::nothrow) plhip_result();
+    if (!R) return fail(PLHIP_ERR_OOM, "host allocation failed");
+    R->n_rows = (int64_t)G; R->on_device = true; R->device = g_ctx.device;
+    ResultCol col;
+    col.dtype = values->dtype;
+    hipError_t e = hipMalloc(&col.values, (size_t)std::max<uint64_t>(G, 1) * dtype_width(col.dtype));
+    if (e == hipSuccess) e = hipMemsetAsync(col.values, 0, (size_t)std::max<uint64_t>(G, 1) * dtype_width(col.dtype), g_ctx.stream);
+    if (e == hipSuccess) e = hipMalloc((void **)&col.validity, (G / 64 + 1) * 8);
+    if (e == hipSuccess) e = hipMemsetAsync(col.validity, 0, (G / 64 + 1) * 8, g_ctx.stream);
+    R->cols.push_back(col);
+    if (e == hipSuccess) e = hipStreamSynchronize(g_ctx.stream);
+    if (e != hipSuccess) { delete R; return fail_hip(e, "hipMalloc(output)"); }
+    return finish_result(R, G, flags & PLHIP_FLAG_OUTPUT_DEVICE, out);
+  }
+  return agg_groups_impl(values, AGG_EXT_QUANTILE, groups, flags, quantile, interpolation, out);
+}
 
 int32_t plhip_result_pack_by_owner(const plhip_result_t *r, int32_t n_keys, uint64_t null_hash, int32_t n_parts, void *records,
                                    int64_t *counts) {

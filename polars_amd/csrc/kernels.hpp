@@ -90,11 +90,12 @@ struct AggExtArgs {
 };
 #define AGG_EXT_MEDIAN 9
 #define AGG_EXT_N_UNIQUE 10
+#define AGG_EXT_QUANTILE 11 // plhip_agg_groups_quantile only
 hipError_t median_temp_bytes(uint64_t n, uint64_t G, size_t *bytes);
 hipError_t launch_n_unique(const AggExtArgs &a, const uint32_t *offsets, const uint32_t *indices, uint64_t n, uint64_t G, uint64_t *codes_a,
                            uint64_t *codes_b, uint32_t *marks, void *temp, size_t temp_bytes, hipStream_t s);
-hipError_t launch_median(const AggExtArgs &a, const uint32_t *offsets, const uint32_t *indices, uint64_t n, uint64_t G, uint64_t *codes_a,
-                         uint64_t *codes_b, void *temp, size_t temp_bytes, hipStream_t s);
+hipError_t launch_quantile(const AggExtArgs &a, const uint32_t *offsets, const uint32_t *indices, uint64_t n, uint64_t G, uint64_t *codes_a,
+                           uint64_t *codes_b, void *temp, size_t temp_bytes, double q, int interp, hipStream_t s);
 void launch_agg_groups_ext(const AggExtArgs &a, const uint32_t *offsets, const uint32_t *indices, uint64_t G, bool wave, hipStream_t s);
 
 // sort strategy (sort_path.hip)

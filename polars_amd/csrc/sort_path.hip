@@ -227,10 +227,10 @@ hipError_t launch_sort_groups(const Plan &p, uint64_t *keys_a, uint64_t *keys_b,
   return hipGetLastError();
 }
 
-// ---- median over CSR groups (agg_median -> agg_quantile_generic(0.5, Linear), crates/polars-core/src/frame/group_by/
+// ---- median / quantile over CSR groups (agg_median -> agg_quantile_generic(0.5, Linear), crates/polars-core/src/frame/group_by/
 // aggregations/mod.rs:420-457 + dispatch.rs:98-113; quantile_idx / linear_interpol, chunked_array/ops/aggregate/
 // quantile.rs:19-54): the group's valid values sorted ascending (NaN last), float_idx = (m - 1) / 2, result =
-// lower + (float_idx - floor) * (upper - lower), in f32 for an f32 column and in f64 otherwise; no valid value -> null.
+// lower + (float_idx - floor) * (upper - lower) in f64 (an f32 column's answer is that, cast); no valid value -> null.
 // Values travel as order-preserving u64 codes of their f64 value in CSR order, nulls as the largest code, one
 // segmented radix sort (rocPRIM) orders every group, one thread per group picks the middle.
 namespace {
@@ -333,24 +333,34 @@ __global__ void __launch_bounds__(256) k_n_unique_finish(AggExtArgs A, const uin
   if (m == 3u) ((uint32_t *)A.out)[g] += 1u; // nulls and the largest value shared one code
   atomicOr((unsigned int *)A.out_validity + (g >> 5), 1u << (g & 31));
 }
-__global__ void __launch_bounds__(256) k_median(AggExtArgs A, const uint64_t *__restrict__ sorted, const uint32_t *__restrict__ offsets, uint64_t G) {
+// interp: QuantileInterpolOptions (crates/polars-arrow/src/kernels/rolling/no_nulls/mod.rs:70-77): 0 Nearest, 1 Lower, 2 Higher,
+// 3 Midpoint, 4 Linear.  quantile_idx (quantile.rs:19-44) counts in the sorted column with the nulls in front, so the
+// group's null count enters the index arithmetic exactly as there; everything is f64 and an f32 column's answer is
+// the f64 one cast (quantile.rs:231-246, 296-310).
+__global__ void __launch_bounds__(256) k_quantile(AggExtArgs A, const uint64_t *__restrict__ sorted, const uint32_t *__restrict__ offsets, uint64_t G,
+                                                  double q, int interp) {
+#pragma clang fp contract(off) // no fused multiply-adds: the reference's arithmetic rounds after every operation
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= G) return;
   const uint32_t b = offsets[g], e = offsets[g + 1];
   uint32_t lo = b, hi = e; // first null code of the segment
   while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sorted[mid] == ~0ull) hi = mid; else lo = mid + 1; }
-  const uint32_t m = lo - b;
+  const uint32_t m = lo - b, len = e - b;
+  const double nc = (double)(len - m);
   bool valid = m > 0;
   double r = 0.0;
   if (valid) {
-    const double float_idx = ((double)m - 1.0) * 0.5;
-    const uint32_t idx = (uint32_t)float_idx, top = (uint32_t)ceil(float_idx);
-    const double lower = f64_from_ordered(sorted[b + idx]), upper = f64_from_ordered(sorted[b + top]);
-    if (A.out_dtype == PLHIP_F32) {
-      const float lf = (float)lower, uf = (float)upper;
-      r = lf == uf ? lf : ((float)float_idx - (float)idx) * (uf - lf) + lf;
-    } else {
-      r = lower == upper ? lower : (float_idx - (double)idx) * (upper - lower) + lower;
+    const double float_idx = ((double)m - 1.0) * q + nc;
+    double base_f = interp == 0 ? (double)m * q + nc : (interp == 2 ? ceil(float_idx) : float_idx);
+    uint64_t base = (uint64_t)base_f; // `as usize`: truncation
+    if (base > (uint64_t)len - 1) base = (uint64_t)len - 1;
+    const uint64_t top = (uint64_t)ceil(float_idx);
+    const uint32_t idx = (uint32_t)(base - (uint64_t)(len - m)); // among the valid values
+    const double lower = f64_from_ordered(sorted[b + idx]);
+    r = lower;
+    if ((interp == 3 || interp == 4) && top != base) {
+      const double upper = f64_from_ordered(sorted[b + (idx + 1 < m ? idx + 1 : idx)]);
+      if (lower != upper) r = interp == 3 ? (lower + upper) / 2.0 : (float_idx - (double)base) * (upper - lower) + lower;
     }
   }
   if (A.out_dtype == PLHIP_F32) ((float *)A.out)[g] = (float)r;
@@ -364,15 +374,15 @@ hipError_t median_temp_bytes(uint64_t n, uint64_t G, size_t *bytes) {
                                             (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0, 64);
 }
 // codes_a / codes_b: n u64 each
-hipError_t launch_median(const AggExtArgs &a, const uint32_t *offsets, const uint32_t *indices, uint64_t n, uint64_t G, uint64_t *codes_a,
-                         uint64_t *codes_b, void *temp, size_t temp_bytes, hipStream_t s) {
+hipError_t launch_quantile(const AggExtArgs &a, const uint32_t *offsets, const uint32_t *indices, uint64_t n, uint64_t G, uint64_t *codes_a,
+                           uint64_t *codes_b, void *temp, size_t temp_bytes, double q, int interp, hipStream_t s) {
   if (!G) return hipSuccess;
   if (n) {
     hipLaunchKernelGGL(k_gather_ordered, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, indices, n, codes_a);
     hipError_t e = rocprim::segmented_radix_sort_keys(temp, temp_bytes, codes_a, codes_b, (unsigned int)n, (unsigned int)G, offsets, offsets + 1, 0, 64, s);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(k_median, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, s, a, codes_b, offsets, G);
+  hipLaunchKernelGGL(k_quantile, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, s, a, codes_b, offsets, G, q, interp);
   return hipGetLastError();
 }
 

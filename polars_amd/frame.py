@@ -216,7 +216,7 @@ class GroupBy:
     def count(self) -> DataFrame:
         return self._eager("count")
 
-    def _two_step(self, kind: str, suffix: str, ddof: int = 1) -> DataFrame:
+    def _two_step(self, kind: str, suffix: str, ddof: int = 1, quantile: float = 0.5, interpolation: str = "nearest") -> DataFrame:
         """The eager GroupBy's non-fused aggregations (group_by/mod.rs:498-662): groups first (GroupsProxy), then one
         agg_* per selected column over them; keys = each key column taken at the groups' first rows (keys_sliced,
         mod.rs:250-297); output names as fmt_group_by_column (mod.rs:889-909)."""
@@ -229,7 +229,10 @@ class GroupBy:
                 c.name = k
                 cols.append(c)
             for n in names:
-                c = agg_groups(self.df.get_column(n), kind, g, ddof=ddof)
+                if kind == "quantile":
+                    c = agg_groups_quantile(self.df.get_column(n), quantile, g, interpolation)
+                else:
+                    c = agg_groups(self.df.get_column(n), kind, g, ddof=ddof)
                 c.name = f"{n}_{suffix}"
                 cols.append(c)
         finally:
@@ -253,6 +256,12 @@ class GroupBy:
 
     def n_unique(self) -> DataFrame:
         return self._two_step("n_unique", "n_unique")
+
+    def quantile(self, quantile: float, interpolation: str = "nearest") -> DataFrame:
+        # GroupBy::quantile (group_by/mod.rs:602-630): errors outside [0, 1]; names `{name}_quantile_{q:.2}` (mod.rs:905)
+        if not 0.0 <= quantile <= 1.0:
+            raise _ffi.PlHipError(1, "ComputeError: `quantile` should be within 0.0 and 1.0")
+        return self._two_step("quantile", f"quantile_{quantile:.2f}", quantile=quantile, interpolation=interpolation)
 
 
 class LazyFrame:
@@ -441,6 +450,22 @@ def group_tuples(keys: Sequence[Column], sorted_: bool = False, location: int = 
     h = C.c_void_p()
     _ffi.check(_ffi.lib().plhip_group_tuples(karr, len(keys), int(sorted_), location, C.byref(h)))
     return Groups(h)
+
+
+INTERPOLATIONS = {"nearest": 0, "lower": 1, "higher": 2, "midpoint": 3, "linear": 4}
+
+
+def agg_groups_quantile(values: Column, quantile: float, groups: Groups, interpolation: str = "nearest") -> Column:
+    """Series::agg_quantile on GroupsProxy::Idx (dispatch.rs:115-140) through plhip_agg_groups_quantile."""
+    L = _ffi.lib()
+    h = C.c_void_p()
+    _ffi.check(L.plhip_agg_groups_quantile(C.byref(values.struct()), groups._h, float(quantile), INTERPOLATIONS[interpolation], 0, C.byref(h)))
+    try:
+        cs = _ffi.ColumnStruct()
+        _ffi.check(L.plhip_result_column(h, 0, C.byref(cs)))
+        return _host_column(f"{values.name}_quantile_{quantile:.2f}", cs)
+    finally:
+        L.plhip_result_free(h)
 
 
 def agg_groups(values: Column | None, kind: str, groups: Groups, ddof: int = 1) -> Column:

@@ -96,3 +96,39 @@ def test_agg_ext_known_answers(oracle):
     assert v.tolist() == [2, 3]
     v, _ = oracle.agg_ext(Column("c", np.array([0, 1, 0, 1, 0], dtype=np.int64), np.array([False, True, False, True, False])), "n_unique", g5)
     assert v.tolist() == [2, 2]
+
+
+def test_agg_quantile_known_answers(oracle):
+    """test_quantile, test_quantile_all_null, test_quantile_single_value, test_quantile_min_max (crates/polars-core/src/
+    chunked_array/ops/aggregate/mod.rs:696-944) with the column as one group, test_median (:639-660) and
+    test_group_by_shorthand_quantile (py-polars/tests/unit/operations/test_group_by.py:96-102)."""
+    from polars_amd.column import Column
+    from tests.util import QUANTILE_KNOWN, quantile_known_column
+
+    for data, table in QUANTILE_KNOWN:
+        col = quantile_known_column(data)
+        g = oracle.Groups([Column("g", np.zeros(len(data), dtype=np.int32))], True)
+        for interp, qs in table.items():
+            for q, want in qs.items():
+                v, m = oracle.agg_quantile(col, q, interp, g)
+                assert m.tolist() == [True] and v.dtype == np.float64 and v[0] == want, (data, interp, q, v[0])
+        v, m = oracle.agg_ext(col, "median", g)
+        assert v[0] == (3.0 if len(data) == 7 else 4.0)
+    g3 = oracle.Groups([Column("g", np.zeros(3, dtype=np.int32))], True)
+    g4 = oracle.Groups([Column("g", np.zeros(4, dtype=np.int32))], True)
+    g1 = oracle.Groups([Column("g", np.zeros(1, dtype=np.int32))], True)
+    for dt in (np.float32, np.int32, np.float64, np.int64):
+        for interp in oracle.INTERPOLATIONS:
+            v, m = oracle.agg_quantile(Column("x", np.zeros(3, dtype=dt), np.zeros(3, bool)), 0.9, interp, g3)
+            assert m.tolist() == [False]
+            v, m = oracle.agg_quantile(Column("x", np.ones(1, dtype=dt)), 0.5, interp, g1)
+            assert m.tolist() == [True] and v[0] == 1.0
+            c = Column("x", np.array([0, 1, 5, 1], dtype=dt), np.array([False, True, True, True]))
+            assert oracle.agg_quantile(c, 0.0, interp, g4)[0][0] == 1.0 and oracle.agg_quantile(c, 1.0, interp, g4)[0][0] == 5.0
+    g5 = oracle.Groups([Column("b", np.array([10, 10, 20, 20, 20], dtype=np.int32))], True)
+    v, m = oracle.agg_quantile(Column("a", np.array([1, 2, 3, 4, 5], dtype=np.int64)), 0.5, "nearest", g5)
+    assert v.tolist() == [2.0, 4.0]
+    v, m = oracle.agg_quantile(Column("c", np.array([0, 1, 0, 1, 0], dtype=np.int64), np.array([False, True, False, True, False])), 0.5, "nearest", g5)
+    assert v.tolist() == [1.0, 1.0] and m.all()
+    v, m = oracle.agg_quantile(Column("a", np.array([1, 2, 3, 4, 5], dtype=np.int64)), 1.5, "nearest", g5)
+    assert v.dtype == np.int64 and not m.any()  # aggregations/mod.rs:346-349

@@ -421,6 +421,46 @@ def test_group_by_shorthands_first_last_median():
     assert gb().n_unique().rows() == [(10, 2, 2), (20, 3, 2)]  # test_group_by.py:81: the nulls are one value
 
 
+def test_agg_groups_quantile(oracle):
+    """plhip_agg_groups_quantile against the reference's exact expectations (test_quantile, aggregate/mod.rs:789-944; the
+    column as one group) and against the oracle's restatement of quantile_idx / generic_quantile on random groups with
+    nulls: every interpolation, several quantiles, all value dtype classes; bit-exact (the arithmetic is a handful of
+    f64 operations in a fixed order).  test_group_by_shorthand_quantile (test_group_by.py:96-102) through the mirror."""
+    from tests.util import QUANTILE_KNOWN, quantile_known_column
+
+    for data, table in QUANTILE_KNOWN:
+        col = quantile_known_column(data)
+        g = pa.group_tuples([Column("g", np.zeros(len(data), dtype=np.int32))], True)
+        for interp, qs in table.items():
+            for q, want in qs.items():
+                got = pa.frame.agg_groups_quantile(col, q, g, interp)
+                assert got.to_numpy().dtype == np.float64 and got.to_list() == [want], (data, interp, q, got.to_list())
+    rng = np.random.default_rng(139)
+    for dt in (np.int32, np.uint64, np.float32, np.float64, np.int8):
+        for n, card in ((20000, 3000), (30000, 7)):
+            keys = [rand_col(rng, "k", np.int64, n, card=card)]
+            isf = np.dtype(dt).kind == "f"
+            v = rand_col(rng, "v", dt, n, null_frac=0.2, lo=None if isf else 0, hi=None if isf else 100)
+            g_o, g_p = oracle.Groups(keys, True), pa.group_tuples(keys, True)
+            for interp in oracle.INTERPOLATIONS:
+                for q in (0.0, 0.1, 0.5, 0.73, 1.0):
+                    wv, wm = oracle.agg_quantile(v, q, interp, g_o)
+                    got = pa.frame.agg_groups_quantile(v, q, g_p, interp)
+                    gv, gm = got.to_numpy(), got.valid_mask()
+                    gm = np.ones(len(gv), bool) if gm is None else gm
+                    assert gv.dtype == wv.dtype and np.array_equal(gm, wm), (dt, interp, q)
+                    assert np.array_equal(gv[gm].view(np.uint8), wv[wm].view(np.uint8)), (dt, interp, q)
+            wv, wm = oracle.agg_quantile(v, 1.5, "linear", g_o)
+            got = pa.frame.agg_groups_quantile(v, 1.5, g_p, "linear")
+            assert got.to_numpy().dtype == wv.dtype and not got.valid_mask().any()
+    df = pa.DataFrame({"a": np.array([1, 2, 3, 4, 5], dtype=np.int64), "b": np.array([10, 10, 20, 20, 20], dtype=np.int32),
+                       "c": [None, 1, None, 1, None]})
+    out = df.group_by("b", maintain_order=True).quantile(0.5)
+    assert out.columns == ["b", "a_quantile_0.50", "c_quantile_0.50"] and out.rows() == [(10, 2.0, 1.0), (20, 4.0, 1.0)]
+    with pytest.raises(pa.PlHipError):
+        df.group_by("b").quantile(1.5)
+
+
 def test_agg_groups_n_unique_edges(oracle):
     """agg_n_unique (dispatch.rs:82-107 over unique/mod.rs:136-171): test_group_by_agg_n_unique_floats (test_df.py:1726-1734:
     b = [1.0, 2.0 | 2.0] by a = [1, 1 | 3] -> [2, 1], f32 and f64); -0.0 == 0.0, every NaN counts; a value equal to the

@@ -154,3 +154,19 @@ def frame_to_np(df):
 
 def oracle_to_np(out):
     return [(v, None if m.all() else m) for _, v, m in out]
+
+
+# test_quantile (crates/polars-core/src/chunked_array/ops/aggregate/mod.rs:789-944): exact expectations
+QUANTILE_KNOWN = [
+    ([2, 1, None, 3, 5, None, 4], {
+        "nearest": {0.1: 1.0, 0.9: 5.0, 0.6: 4.0}, "lower": {0.1: 1.0, 0.9: 4.0, 0.6: 3.0}, "higher": {0.1: 2.0, 0.9: 5.0, 0.6: 4.0},
+        "midpoint": {0.1: 1.5, 0.9: 4.5, 0.6: 3.5}, "linear": {0.1: 1.4, 0.9: 4.6}}),
+    ([None, 7, 6, 2, 1, None, 3, 5, None, 4], {
+        "nearest": {0.1: 1.0, 0.9: 7.0, 0.6: 5.0}, "lower": {0.1: 1.0, 0.9: 6.0, 0.6: 4.0}, "higher": {0.1: 2.0, 0.9: 7.0, 0.6: 5.0},
+        "midpoint": {0.1: 1.5, 0.9: 6.5, 0.6: 4.5}, "linear": {0.1: 1.6, 0.9: 6.4, 0.6: 4.6}}),
+]
+
+
+def quantile_known_column(data):
+    from polars_amd.column import Column
+    return Column("a", np.array([0 if x is None else x for x in data], dtype=np.uint32), np.array([x is not None for x in data]))
