@@ -43,7 +43,7 @@ def algorithmic_bytes(n_rows, n_groups, key_cols, val_cols, out_widths):
     return b
 
 
-def cpu_baseline(tensors, wl, wide, budget_s=10.0):
+def cpu_baseline(tensors, wl, wide, gpu_frame, budget_s=10.0):
     """The oracle (C restatement of the reference algorithm: P = pow2 <= threads partitions, every thread scans
     all keys, per-group index lists, gather-fold aggregation, crates/polars-core/src/frame/group_by/hashing.rs:
     182-243 + aggregations/mod.rs) timed on this box's host cores: whole passes over the same rows for about
@@ -70,13 +70,48 @@ def cpu_baseline(tensors, wl, wide, budget_s=10.0):
     orc.lib()
     passes, t0 = 0, time.perf_counter()
     while True:
-        orc.group_by_agg(keys, vals, aggs, n_threads=threads)
+        want, _ = orc.group_by_agg(keys, vals, aggs, n_threads=threads)
         passes += 1
         dt = time.perf_counter() - t0
         if dt >= budget_s or passes >= 200:
             break
-    return {"value": n * passes / dt, "unit": "rows/s", "cores": threads, "kind": "port",
+    base = {"value": n * passes / dt, "unit": "rows/s", "cores": threads, "kind": "port",
             "sample": f"{passes} whole passes over the same {n} rows ({dt:.1f} s)"}
+    return base, parity_check(keys, vals, aggs, want, gpu_frame)
+
+
+def parity_check(keys, vals, aggs, want, gpu_frame):
+    """SURVEY.md section 8(d) "parity check in the bench": the timed configuration's GPU result (one more, untimed call,
+    copied to the host) against the oracle's on the same rows after the canonical sort on the keys: keys, integer
+    sums, counts and validity bit-exact, f64 within 1e-12 relative."""
+    import numpy as np
+
+    got = gpu_frame()
+    nk = len(keys)
+    if len(got) != len(want) or len(got[0][0]) != len(want[0][1]):
+        return {"ok": False, "why": f"shape: {len(got)} x {len(got[0][0])} vs {len(want)} x {len(want[0][1])}"}
+    og = np.lexsort([got[j][0] for j in reversed(range(nk))])
+    ow = np.lexsort([want[j][1] for j in reversed(range(nk))])
+    worst = 0.0
+    for j, ((gv, gm), (_, wv, wm)) in enumerate(zip(got, want)):
+        if gv.dtype != wv.dtype:
+            return {"ok": False, "why": f"column {j}: dtype {gv.dtype} vs {wv.dtype}"}
+        gv, wv = gv[og], wv[ow]
+        gm = np.ones(len(gv), bool) if gm is None else gm[og]
+        if not np.array_equal(gm, wm[ow]):
+            return {"ok": False, "why": f"column {j}: validity differs"}
+        a, b = gv[gm], wv[gm]
+        if gv.dtype.kind == "f" and j >= nk:
+            a, b = a.astype(np.float64), b.astype(np.float64)
+            fin = ~(np.isnan(a) & np.isnan(b))
+            rel = np.abs(a[fin] - b[fin]) / np.maximum(np.maximum(np.abs(a[fin]), np.abs(b[fin])), 1e-300)
+            worst = max(worst, float(rel.max()) if len(rel) else 0.0)
+            if worst > 1e-12:
+                return {"ok": False, "why": f"column {j}: f64 relative error {worst:.3e} > 1e-12"}
+        elif not np.array_equal(a, b):
+            return {"ok": False, "why": f"column {j}: integer / key values differ"}
+    return {"ok": True, "groups": int(len(og)), "columns": len(got), "f64_max_rel_err": worst, "f64_rtol": 1e-12,
+            "against": "oracle (C restatement), same rows, canonical key sort"}
 
 
 def measured_traffic(workload, n_rows):
@@ -233,7 +268,18 @@ def main():
                          "all_kernels_frac": abytes / (tot_avg * 1e-3) / 1e9 / HBM_PEAK_GBPS if tot_avg > 0 else 0.0},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(tensors, wl, wide)
+            def gpu_frame():  # the timed configuration once more, result copied to the host
+                handle, out = pa.group_by_agg_raw(keys, vals, agg_codes, 0, hint)
+                try:
+                    fr = []
+                    for cs in out:
+                        c = pa.frame._host_column("c", cs)
+                        fr.append((c.to_numpy().copy(), None if c.valid_mask() is None else c.valid_mask().copy()))
+                    return fr
+                finally:
+                    L.plhip_result_free(handle)
+
+            line["cpu_baseline"], line["parity"] = cpu_baseline(tensors, wl, wide, gpu_frame)
         print(json.dumps(line))
     if world > 1 or rehearse:
         dist.destroy_process_group()
