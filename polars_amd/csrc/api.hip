@@ -57,8 +57,14 @@ struct Ctx {
   // spins on its first 64-bit word instead of queueing a device-to-host copy and waiting for the stream
   uint32_t *host_sig = nullptr, *host_sig_dev = nullptr;
   uint32_t seq = 0;
+  bool hot_clean = false;  // the heavy-hitter words behind the flag block (FLAGS_HOT_OFF ..) are zero
   int timing_pending = 0; // 1: direct, 2: tilesort (S == 1), 3: tilesort + merge -- event times not read yet
 };
+
+// the flag block: 64 bytes of flags, then the single-level tile sort's heavy-hitter words (rows in long runs and done counters
+// per partition, fast.hpp FoldRunsArgs::self_hot); one allocation, never regrown
+constexpr size_t FLAGS_BYTES = 8192, FLAGS_HOT_OFF = 64, FLAGS_HOT_WORDS = 2 + 2 * ((1u << TS_MAX_PBITS) + 1);
+static_assert(FLAGS_HOT_OFF + FLAGS_HOT_WORDS * 4 <= FLAGS_BYTES, "flag block too small");
 
 thread_local Ctx g_ctx;
 
@@ -319,7 +325,7 @@ int dense_ids(const std::vector<KeyCol> &sub, int64_t n, Staging &st, KeyCol &ou
   const uint64_t cap = next_pow2(std::max<uint64_t>(2 * (uint64_t)n, 1024));
   plan_layout(K, cap + 2);
   HIP_TRY(c.table.reserve(table_bytes(K, cap + 2)));
-  HIP_TRY(c.flags.reserve(64));
+  HIP_TRY(c.flags.reserve(FLAGS_BYTES));
   HIP_TRY(c.slots.reserve((cap + 2) * 8));
   HIP_TRY(c.rank.reserve((cap + 2) * 4));
   void *ids = nullptr;
@@ -575,7 +581,7 @@ int estimate_groups(const Plan &P, uint64_t &g_est) {
   K.n_accs = 0;
   const uint64_t cap = 1u << 18;
   HIP_TRY(c.table.reserve(table_bytes(K, cap + 2)));
-  HIP_TRY(c.flags.reserve(64));
+  HIP_TRY(c.flags.reserve(FLAGS_BYTES));
   HIP_TRY(c.slots.reserve((cap + 2) * 8));
   TableRef t{(uint8_t *)c.table.p, cap, (uint32_t *)c.flags.p};
   plan_layout(K, cap + 2);
@@ -752,7 +758,7 @@ int ceil_log2(uint64_t x) { int b = 0; while ((1ull << b) < x) b++; return b; }
 int estimate_groups_sampled(const Plan &P, uint64_t &g_est) {
   Ctx &c = g_ctx;
   const int64_t n = P.n_rows;
-  HIP_TRY(c.flags.reserve(64));
+  HIP_TRY(c.flags.reserve(FLAGS_BYTES));
   uint32_t *dflags = (uint32_t *)c.flags.p;
   // 131 072 sampled keys resolve up to ~1e6 groups under the uniform model E[d] = G (1 - exp(-s / G)).  Two things
   // send the estimate back for a second, larger sample when the column is long enough for it to matter: a sample
@@ -823,7 +829,7 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
     if (w == 4) { keymode = 1; kxor = dk[0].dtype == PLHIP_I32 ? 0x80000000ull : 0ull; }
     if (w == 8) { keymode = 2; kxor = dk[0].dtype == PLHIP_I64 ? 0x8000000000000000ull : 0ull; }
   }
-  HIP_TRY(c.flags.reserve(64));
+  HIP_TRY(c.flags.reserve(FLAGS_BYTES));
   uint32_t *dflags = (uint32_t *)c.flags.p;
   (void)hipGetLastError(); // launches below are checked with hipGetLastError: start clean
 
@@ -905,8 +911,12 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
   DumpRef D{};
   D.cap = lslots;
   D.item_stride = fast_dump_stride(P, lslots, key_bytes);
-  HIP_TRY(c.dump.reserve(D.item_stride * n_items + 256));
-  HIP_TRY(c.hdr.reserve((size_t)n_items * sizeof(DumpHdr)));
+  // single level: partitions that hold a heavy hitter (or the null keys) are folded by several workgroups (fast.hpp, self_hot)
+  const bool hot_self = !direct && S == 1 && n_pg <= block && !getenv("PLHIP_NOHOT");
+  const uint32_t hot_extra = hot_self ? 256u : 0u; // chunks beyond the partitions' own (taken from a queue by workgroups that are done)
+  const size_t dump_items = hot_self ? (size_t)hot_extra + n_pg : n_items;
+  HIP_TRY(c.dump.reserve(D.item_stride * dump_items + 256));
+  HIP_TRY(c.hdr.reserve(dump_items * sizeof(DumpHdr)));
   D.base = (uint8_t *)c.dump.p;
   D.hdr = (DumpHdr *)c.hdr.p;
   PartOut O{};
@@ -939,6 +949,11 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
   OP.n_outs = (int)L.outs.size();
   if (!c.flags_clean) HIP_TRY(hipMemsetAsync(dflags, 0, 64, c.stream));
   c.flags_clean = false;
+  uint32_t *self_hot = (uint32_t *)((uint8_t *)dflags + FLAGS_HOT_OFF) + 2; // [-2] any, [-1] queue, rows[n_pg], done[n_pg]
+  if (hot_self) {
+    if (!c.hot_clean) HIP_TRY(hipMemsetAsync(self_hot - 2, 0, FLAGS_HOT_WORDS * 4, c.stream));
+    c.hot_clean = false;
+  }
   for (size_t i = 0; i < L.outs.size(); i++) {
     OutSpec o = L.outs[i];
     ResultCol col;
@@ -971,7 +986,9 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
     if ((e = hipGetLastError()) != hipSuccess) { delete R; return fail_hip(e, "k_fold_rows launch"); }
     c.strategy = "direct";
   } else {
-    launch_tile_sort(P, O, pbits, n_tiles, (uint32_t *)c.offs.p, keymode, kxor, key_bytes, c.stream);
+    // runs of 4x the mean length and more are added up per partition
+    TileSortLevel1 HL{nullptr, nullptr, 0u, 0u, hot_self ? self_hot : nullptr, 4u * (uint32_t)TS_TILE / np, 0u, hot_self ? self_hot - 2 : nullptr};
+    launch_tile_sort(P, O, pbits, n_tiles, (uint32_t *)c.offs.p, keymode, kxor, key_bytes, c.stream, &HL);
     if ((e = hipGetLastError()) != hipSuccess) { delete R; return fail_hip(e, "k_tile_sort launch"); }
     hipEventRecord(c.ev[4], c.stream);
     Plan P2 = P; // the fold pass reads the sorted copies
@@ -983,6 +1000,12 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
     A.D = D; A.flags = dflags; A.offs = (const uint32_t *)c.offs.p; A.lbits = lbits; A.np = np; A.w = w; A.n_pg = n_pg;
     A.has_null_pg = has_null_pg; A.S = S; A.n_tiles = n_tiles; A.pbits = pbits;
     A.host_sig = c.host_sig_dev; A.seq = seq;
+    if (hot_self) {
+      const char *dbg_hc = getenv("PLHIP_HOT_CHUNK"); // (tests: split at small sizes)
+      A.self_hot = self_hot; A.max_extra = hot_extra;
+      A.hot_chunk_rows = dbg_hc ? (uint32_t)std::max(256, atoi(dbg_hc)) : (uint32_t)std::max<int64_t>(8192, n / np / 4);
+      A.hot_min_rows = 4 * A.hot_chunk_rows;
+    }
     launch_fold_runs(P2, A, OP, key_bytes, block, c.stream);
     if ((e = hipGetLastError()) != hipSuccess) { delete R; return fail_hip(e, "k_fold_runs launch"); }
     c.strategy = "tilesort";
@@ -1003,7 +1026,11 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
     TableRef t{nullptr, 0, dflags};
     int rc = wait_signal(t, seq, fl);
     if (rc) { delete R; return rc; }
-    if (hipMemsetAsync(dflags, 0, 64, c.stream) == hipSuccess) c.flags_clean = true; // for the next query
+    // for the next query (the heavy-hitter words too: one memset)
+    if (hipMemsetAsync(dflags, 0, hot_self ? FLAGS_HOT_OFF + FLAGS_HOT_WORDS * 4 : 64, c.stream) == hipSuccess) {
+      c.flags_clean = true;
+      if (hot_self) c.hot_clean = true;
+    }
   } else { delete R; return fail_hip(e, "group-by kernels"); }
   c.timing_pending = direct ? 1 : (merged ? 3 : 2);
   if (fl[FLAG_OVERFLOW]) { delete R; return PLHIP_OK; } // estimate too low: the general path redoes the query
@@ -1096,7 +1123,7 @@ int run_two_level(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, uint64_t 
   HIP_TRY(c.part.reserve(bytes + 256));
   HIP_TRY(c.dump.reserve(bytes + 256));
   HIP_TRY(c.offs.reserve((size_t)(np2 + 2) * n_tiles2 * 4));
-  HIP_TRY(c.flags.reserve(64));
+  HIP_TRY(c.flags.reserve(FLAGS_BYTES));
   // heavy hitters (fast.hpp, HotState): leaves with >= hot_min rows in long runs are folded by several workgroups
   const bool hot_on = !getenv("PLHIP_T2_NOHOT") && n_items <= (1u << 22);
   const char *dbg_hc = getenv("PLHIP_T2_HOT_CHUNK"); // (tests: split at small sizes)
@@ -1170,7 +1197,7 @@ int run_two_level(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, uint64_t 
   P1.n_rows = (int64_t)n_pad;
   P1.keys[0].values = A.keys; P1.keys[0].validity = nullptr; P1.keys[0].boff = 0;
   for (int v = 0; v < P.n_vals; v++) { P1.vals[v].values = A.vals[v]; P1.vals[v].validity = A.valid[v]; P1.vals[v].boff = 0; P1.vals[v].valid_bytes = 1; }
-  TileSortLevel1 L1{pstart, totals, np1, pbits1, hot_rows, std::max<uint32_t>(128u, 16u * (uint32_t)TS_TILE / np2), 0u};
+  TileSortLevel1 L1{pstart, totals, np1, pbits1, hot_rows, std::max<uint32_t>(128u, 16u * (uint32_t)TS_TILE / np2), 0u, nullptr};
   if (hot_on) HIP_TRY(hipMemsetAsync(hot_rows, 0, (size_t)n_items * 4, c.stream));
   launch_tile_sort(P1, B, pbits2, n_tiles2, (uint32_t *)c.offs.p, key_bytes == 4 ? 1 : 2, 0ull, key_bytes, c.stream, &L1);
   if (hot_on) launch_hot_plan(hot_rows, (uint32_t)n_items, np2, pstart, hot_min, hot_chunk, max_extra, hot_state, c.stream);
@@ -1243,7 +1270,7 @@ int run_sorted(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, plhip_result
   HIP_TRY(c.rank.reserve(n4 + 256));
   HIP_TRY(c.sortkeys.reserve(temp_bytes));
   HIP_TRY(c.items.reserve(((size_t)n / 2048 + 2) * 4 + 256));
-  HIP_TRY(c.flags.reserve(64));
+  HIP_TRY(c.flags.reserve(FLAGS_BYTES));
   HIP_TRY(c.plans.reserve(sizeof(KeyGather)));
   uint32_t *dflags = (uint32_t *)c.flags.p;
   uint64_t *keys_a = (uint64_t *)c.table.p, *keys_b = (uint64_t *)((uint8_t *)c.table.p + n8);
@@ -1577,7 +1604,7 @@ int32_t group_by_agg_impl(const plhip_column_t *keys, int32_t n_keys, const plhi
     const uint64_t n_slots = cap + 2 + dense_cap;
     plan_layout(P, n_slots);
     HIP_TRY(c.table.reserve(table_bytes(P, n_slots)));
-    HIP_TRY(c.flags.reserve(64));
+    HIP_TRY(c.flags.reserve(FLAGS_BYTES));
     HIP_TRY(c.slots.reserve(n_slots * 8));
     T = TableRef{(uint8_t *)c.table.p, cap, (uint32_t *)c.flags.p};
     uint64_t *slots_dev = (uint64_t *)c.slots.p;
@@ -1744,7 +1771,7 @@ int32_t plhip_group_tuples(const plhip_column_t *keys, int32_t n_keys, int32_t s
     const uint64_t n_slots = cap + 2;
     plan_layout(P, n_slots);
     hipError_t e = c.table.reserve(table_bytes(P, n_slots));
-    if (e == hipSuccess) e = c.flags.reserve(64);
+    if (e == hipSuccess) e = c.flags.reserve(FLAGS_BYTES);
     if (e == hipSuccess) e = c.slots.reserve(n_slots * 8);
     if (e == hipSuccess) e = c.rank.reserve(n_slots * 4);
     if (e != hipSuccess) { delete Gp; return fail_hip(e, "group_tuples scratch"); }

@@ -83,7 +83,16 @@ struct FoldRunsArgs {
   const uint32_t *seg_start; // ... and segment s covers the tiles [seg_start[s], seg_start[s + 1]) / TS_TILE (nullptr: equal split)
   HotState *hot;              // disjoint only, may be nullptr: the split leaves (the grid then has max_extra workgroups behind the leaves')
   const uint32_t *hot_of_leaf; // [n_pg * S]: entry index + 1, 0 = an ordinary leaf
-  uint32_t max_extra, pad2;
+  uint32_t max_extra;          // extra workgroups behind the leaves' (both hot modes)
+  // single level (S == 1, one workgroup per partition, at most blockDim partitions): no plan kernel -- the workgroups plan
+  // for themselves from self_hot[0 .. n_pg) = rows in long runs per partition (k_tile_sort), self_hot[n_pg .. 2 n_pg) = done
+  // counters, self_hot[-2] = "some partition has long runs", self_hot[-1] = the queue of chunks, all zeroed by the host.  The
+  // chunks >= 1 are taken from the queue by workgroups that have finished their own partition (max_extra bounds their number).  A partition with >= hot_min_rows such rows is split into ceil(rows / hot_chunk_rows)
+  // chunks (<= HOT_MAX_CHUNKS, <= n_tiles); chunk 0 dumps into item max_extra + partition, chunk c >= 1 into item
+  // first_extra + c - 1 (first_extra = exclusive prefix of the extra chunks over the partitions).
+  uint32_t hot_min_rows;
+  uint32_t *self_hot;
+  uint32_t hot_chunk_rows, pad3;
 };
 
 struct MergeArgs {
@@ -111,6 +120,7 @@ struct TileSortLevel1 {
   uint32_t np1, pshift;       // pshift: hash bits consumed by level 1
   uint32_t *hot_rows;         // level 2, may be nullptr: [np1 << pbits] zeroed; runs of at least hot_run rows are added to their leaf's word
   uint32_t hot_run, pad;
+  uint32_t *hot_any;          // single level, may be nullptr: set to 1 when any long run was seen
 };
 // hot_rows[] (rows in long runs per leaf) -> H + hot_rows[] rewritten as entry index + 1 / 0.  A leaf is split when it has
 // at least min_rows such rows, into ceil(rows / chunk_rows) chunks (at most HOT_MAX_CHUNKS, at most its tiles).

@@ -614,7 +614,10 @@ __global__ void __launch_bounds__(TS_BLOCK) k_tile_sort(Plan P, PartOut O, uint3
   }
   lds_barrier();
   const uint32_t mine = tid < nh ? hist[tid] : 0;
-  if (!SCATTER && L1.hot_rows && tid < np && mine >= L1.hot_run) atomicAdd(&L1.hot_rows[l1p * np + tid], mine); // a heavy hitter's leaf
+  if (!SCATTER && L1.hot_rows && tid < nh && mine >= L1.hot_run) { // a heavy hitter's leaf (level 2: no null partition)
+    atomicAdd(&L1.hot_rows[l1p * np + tid], mine);
+    if (L1.hot_any) atomicOr(L1.hot_any, 1u);
+  }
   const uint32_t excl = block_scan_excl_lds(mine, tmp);
   if (tid < nh) {
     hist[tid] = excl;
@@ -698,15 +701,16 @@ __global__ void __launch_bounds__(TS_BLOCK) k_tile_sort(Plan P, PartOut O, uint3
 // together.  With one segment per group the workgroup writes the output columns itself.
 // ---------------------------------------------------------------------------------------------------------
 #define RUNS_NPRE 3
-// one compact dump (dump_table) -> the workgroup's LDS table; every thread of the workgroup calls it
+// one compact dump (dump_table) -> the workgroup's LDS table, by threads tid of nthreads (a wave per dump: several dumps in flight)
 template <typename KS>
-DEVINL void merge_dump(const Plan &P, uint8_t *sm, uint32_t lbits, uint32_t pshift, uint32_t *used, const DumpRef &D, uint32_t item) {
+DEVINL void merge_dump(const Plan &P, uint8_t *sm, uint32_t lbits, uint32_t pshift, uint32_t *used, const DumpRef &D, uint32_t item, uint32_t tid,
+                       uint32_t nthreads) {
   const uint32_t lcap = 1u << lbits, lslots = lcap + FP_EXTRA_SLOTS;
   KS *lkeys = (KS *)sm;
   const DumpHdr *H = &D.hdr[item];
   const uint32_t nh = H->n_hash, hs = H->has_sent, hn = H->has_null, n = nh + hs + hn;
   const uint8_t *base = D.base + (uint64_t)item * D.item_stride;
-  for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) {
+  for (uint32_t k = tid; k < n; k += nthreads) {
     uint32_t slot;
     if (k < nh) slot = ltab_slot<KS>(lkeys, lbits, pshift, used, ((const KS *)base)[k]);
     else if (k == nh && hs) { slot = lcap; used[0] = 1; }
@@ -817,16 +821,72 @@ __global__ void __launch_bounds__(1024) k_fold_runs(Plan P, FoldRunsArgs A, OutP
   __shared__ __align__(16) uint32_t sh[8];
   __shared__ __align__(16) uint32_t bk[136];
   const uint32_t lslots = lslots_of(A.lbits);
+  const uint32_t hot_any = A.self_hot ? A.self_hot[-2] : 0u; // (requested before the table is initialised, needed after it)
   if (threadIdx.x < 8) sh[threadIdx.x] = 0;
-  ltab_init<KS>(P, fsm, lslots);
+  // (an extra workgroup of the heavy-hitter split initialises its table only once it knows it has work)
+  const bool extra_wg = A.hot && blockIdx.x >= A.n_pg * A.S;
+  if (!extra_wg) ltab_init<KS>(P, fsm, lslots);
   __syncthreads();
   // Neighbouring partitions share the cache lines at their run boundaries.  Workgroups b, b + 8, b + 16, ...
   // are observed to land on one XCD, so they are given neighbouring partitions: the second reader of a line
   // then hits in that XCD's L2 instead of fetching it over the fabric again (speed only, never correctness).
-  uint32_t item = blockIdx.x;
-  const uint32_t n_main = A.hot ? A.n_pg * A.S : gridDim.x;
+  const bool self = A.self_hot != nullptr;
+  const uint32_t n_main = (A.hot || self) ? A.n_pg * A.S : gridDim.x;
+  // single level: A.self_hot[-2] != 0 says that some partition has long runs at all; then a workgroup that has finished its own
+  // partition takes chunks of the split ones from a queue (A.self_hot[-1]) until none is left -- no extra workgroups,
+  // nothing but one load when the keys are not skewed
+  uint32_t vitem = blockIdx.x, over_acc = 0;
+  for (;;) {
+  uint32_t item = vitem;
   uint32_t chunk = 0, chunks = 1, hidx = 0, hslot = 0; // a split leaf (HotState): this workgroup folds chunk `chunk` of `chunks`
-  if (item < n_main) {
+  uint32_t slot0 = 0;                                  // ... and chunk 0's dump item (chunk c >= 1: hslot + c)
+  if (self) { // single level: the workgroups plan for themselves (fast.hpp)
+    __shared__ __align__(16) uint32_t scan_tmp[16];
+    uint32_t chunk_rows = A.hot_chunk_rows, min_rows = A.hot_min_rows;
+    auto chunks_of = [&](uint32_t rows) -> uint32_t {
+      if (rows < min_rows) return 1u;
+      uint32_t c = (rows + chunk_rows - 1) / chunk_rows;
+      c = c < HOT_MAX_CHUNKS ? c : HOT_MAX_CHUNKS;
+      return c < A.n_tiles ? c : A.n_tiles;
+    };
+    bool extra = item >= n_main;
+    if (!extra) {
+      const uint32_t n8 = n_main & ~7u;
+      if (item < n8) item = (item & 7u) * (n8 >> 3) + (item >> 3);
+      if (hot_any) chunks = chunks_of(A.self_hot[item]);
+    }
+    if (extra || chunks > 1) { // (uniform over the workgroup)
+      const uint32_t t = threadIdx.x;
+      const uint32_t rows_t = t < n_main ? A.self_hot[t] : 0u;
+      uint32_t x = 0, excl = 0;
+      for (int round = 0; round < 8; round++) { // more chunks than extra workgroups: the thresholds double (the same in every workgroup)
+        x = chunks_of(rows_t) - 1u;
+        excl = block_scan_excl(x, scan_tmp);
+        if (t == blockDim.x - 1) sh[3] = excl + x;
+        __syncthreads();
+        const bool fits = sh[3] <= A.max_extra;
+        __syncthreads();
+        if (fits) break;
+        chunk_rows *= 2; min_rows *= 2;
+      }
+      if (!extra) chunks = chunks_of(A.self_hot[item]);
+      const bool acc = x > 0 && excl + x <= A.max_extra; // (a prefix, if eight doublings were not enough: the rest keep their one workgroup)
+      if (!extra) { if (t == item) { sh[5] = excl; sh[6] = acc ? 1u : 0u; } }
+      else { const uint32_t e = item - n_main; if (acc && excl <= e && e < excl + x) { sh[5] = excl; sh[6] = 1u; sh[7] = t; sh[3] = x + 1u; } }
+      __syncthreads();
+      if (extra) {
+        if (!sh[6]) break; // the queue is empty
+        chunks = sh[3]; chunk = item - n_main - sh[5] + 1u; item = sh[7];
+      } else if (!sh[6]) chunks = 1;
+      hslot = sh[5] - 1u; // chunk c >= 1 -> item first_extra + c - 1
+      slot0 = A.max_extra + item;
+      hidx = item;
+      __syncthreads();
+      if (threadIdx.x < 8 && threadIdx.x >= 3) sh[threadIdx.x] = 0;
+      if (extra) ltab_init<KS>(P, fsm, lslots);
+      __syncthreads();
+    }
+  } else if (item < n_main) {
     const uint32_t n8 = n_main & ~7u;
     if (item < n8) item = (item & 7u) * (n8 >> 3) + (item >> 3);
     if (A.hot) {
@@ -841,7 +901,10 @@ __global__ void __launch_bounds__(1024) k_fold_runs(Plan P, FoldRunsArgs A, OutP
     while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (A.hot->e[mid].first_extra <= e) lo = mid; else hi = mid; }
     hidx = lo; chunks = A.hot->e[lo].chunks; chunk = e - A.hot->e[lo].first_extra + 1; hslot = A.hot->e[lo].first_extra + lo;
     item = A.hot->e[lo].leaf;
+    ltab_init<KS>(P, fsm, lslots);
+    __syncthreads();
   }
+  if (!self) slot0 = hslot;
   // two-level pipeline: neighbouring sub-partitions of ONE level-1 partition (their runs are neighbours in memory) are neighbours here
   const uint32_t pg = A.disjoint ? item % A.n_pg : item / A.S, seg = A.disjoint ? item / A.n_pg : item % A.S;
   const bool null_pg = A.has_null_pg && pg == A.n_pg - 1;
@@ -899,10 +962,10 @@ __global__ void __launch_bounds__(1024) k_fold_runs(Plan P, FoldRunsArgs A, OutP
   if (A.S == 1 || A.disjoint) {
     bool emit = true;
     if (chunks > 1) { // a split leaf: every chunk dumps its table; the workgroup that finishes last merges them
-      dump_table<KS>(P, fsm, A.lbits, 0, sh, bk, list, A.D, hslot + chunk);
+      dump_table<KS>(P, fsm, A.lbits, 0, sh, bk, list, A.D, chunk ? hslot + chunk : slot0);
       __threadfence(); // the dump is visible device-wide before this chunk counts as done
       __syncthreads();
-      if (threadIdx.x == 0) sh[4] = atomicAdd(&A.hot->e[hidx].done, 1u);
+      if (threadIdx.x == 0) sh[4] = atomicAdd(self ? &A.self_hot[n_main + hidx] : &A.hot->e[hidx].done, 1u);
       __syncthreads();
       emit = sh[4] == chunks - 1;
       if (emit) {
@@ -912,14 +975,26 @@ __global__ void __launch_bounds__(1024) k_fold_runs(Plan P, FoldRunsArgs A, OutP
         if (threadIdx.x < 8) sh[threadIdx.x] = threadIdx.x == 2 ? over : 0u;
         ltab_init<KS>(P, fsm, lslots);
         __syncthreads();
-        for (uint32_t c = 0; c < chunks; c++) merge_dump<KS>(P, fsm, A.lbits, A.pbits, sh, A.D, hslot + c);
+        for (uint32_t c = wave; c < chunks; c += nw) merge_dump<KS>(P, fsm, A.lbits, A.pbits, sh, A.D, c ? hslot + c : slot0, lane, 64u); // a wave per dump
         __syncthreads();
         if (sh[2] && threadIdx.x == 0) A.flags[FLAG_OVERFLOW] = 1;
       }
     }
     if (emit) emit_table<KS>(P, fsm, A.lbits, sh, bk, list, O, A.flags, A.out_cap);
-    publish_done(A.flags, sh, A.host_sig, A.seq);
-  } else dump_table<KS>(P, fsm, A.lbits, 0, sh, bk, list, A.D, item);
+    if (!hot_any) { publish_done(A.flags, sh, A.host_sig, A.seq); return; }
+  } else { dump_table<KS>(P, fsm, A.lbits, 0, sh, bk, list, A.D, item); return; }
+  // the next chunk from the queue (self mode with skewed keys only)
+  __syncthreads();
+  over_acc |= sh[2];
+  if (threadIdx.x == 0) sh[3] = atomicAdd(&A.self_hot[-1], 1u);
+  __syncthreads();
+  vitem = n_main + sh[3];
+  __syncthreads();
+  if (threadIdx.x < 8) sh[threadIdx.x] = 0;
+  __syncthreads();
+  }
+  if (threadIdx.x == 0 && over_acc) sh[2] = 1;
+  publish_done(A.flags, sh, A.host_sig, A.seq);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1207,7 +1282,7 @@ void launch_fold_rows(const Plan &p, const FoldRowsArgs &a, int key_bytes, bool 
 
 void launch_tile_sort(const Plan &p, const PartOut &o, uint32_t pbits, uint32_t n_tiles, uint32_t *offs, int keymode, uint64_t kxor,
                       int key_bytes, hipStream_t s, const TileSortLevel1 *lvl1, bool scatter) {
-  const TileSortLevel1 l1 = lvl1 ? *lvl1 : TileSortLevel1{nullptr, nullptr, 0u, 0u, nullptr, 0u, 0u};
+  const TileSortLevel1 l1 = lvl1 ? *lvl1 : TileSortLevel1{nullptr, nullptr, 0u, 0u, nullptr, 0u, 0u, nullptr};
   static bool once = false;
   if (!once) {
     allow_big_lds(k_tile_sort<uint32_t, false>); allow_big_lds(k_tile_sort<uint64_t, false>);

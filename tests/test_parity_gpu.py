@@ -982,6 +982,33 @@ def test_two_levels_skew_falls_back(oracle):
     check_parity(oracle, keys, values, [(0, "sum"), (0, "count"), (0, "max")], "tilesort2", what="two levels skew")
 
 
+@pytest.mark.parametrize("key_dtype", [np.int32, np.int64])
+def test_tile_sort_hot_partitions_are_split(oracle, monkeypatch, key_dtype):
+    """Single-level tile sort under skew: a partition that holds a heavy hitter -- or the null keys, db-benchmark's NA
+    variant -- is folded by several workgroups that plan for themselves from the per-partition long-run counts and whose
+    dumps the last finisher merges (fast.hpp, FoldRunsArgs::self_hot).  A lowered chunk size splits several partitions at
+    oracle size; every accumulator kind, nullable values; then the same query with the split switched off."""
+    monkeypatch.setenv("PLHIP_HOT_CHUNK", "1024")
+    rng = np.random.default_rng(149)
+    n = 600_000
+    k = rng.integers(0, 20_000, n).astype(key_dtype)
+    u = rng.random(n)
+    k[u < 0.25] = 7
+    k[(u >= 0.25) & (u < 0.35)] = 12345
+    k[(u >= 0.35) & (u < 0.38)] = -3
+    km = rng.random(n) > 0.06
+    keys = [Column("k", k, km)]
+    values = [Column("a", rng.integers(-1000, 1000, n).astype(np.int64)), rand_col(rng, "b", np.float64, n, null_frac=0.1)]
+    aggs = [(0, "sum"), (1, "mean"), (0, "min"), (1, "max"), (0, "count"), (1, "sum")]
+    check_parity(oracle, keys, values, aggs, "tilesort", what="hot partitions split")
+    assert pa.last_strategy() == "tilesort"
+    check_parity(oracle, [Column("k", k)], values, aggs, "auto", what="hot partitions split, no null keys")
+    monkeypatch.delenv("PLHIP_HOT_CHUNK")
+    check_parity(oracle, keys, values, aggs, "tilesort", what="hot partitions, default chunk size")
+    monkeypatch.setenv("PLHIP_NOHOT", "1")
+    check_parity(oracle, keys, values, aggs, "tilesort", what="hot partitions, one workgroup each")
+
+
 def test_two_levels_hot_leaves_are_split(oracle, monkeypatch):
     """Heavy hitters in the two-level pipeline: leaves with many rows are folded by several workgroups whose tables the
     last one merges (fast.hpp, HotState).  A lowered chunk size makes a dozen leaves split at a size the oracle
