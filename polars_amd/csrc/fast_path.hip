@@ -710,31 +710,51 @@ DEVINL void merge_dump(const Plan &P, uint8_t *sm, uint32_t lbits, uint32_t pshi
   const DumpHdr *H = &D.hdr[item];
   const uint32_t nh = H->n_hash, hs = H->has_sent, hn = H->has_null, n = nh + hs + hn;
   const uint8_t *base = D.base + (uint64_t)item * D.item_stride;
-  for (uint32_t k = tid; k < n; k += nthreads) {
-    uint32_t slot;
-    if (k < nh) slot = ltab_slot<KS>(lkeys, lbits, pshift, used, ((const KS *)base)[k]);
-    else if (k == nh && hs) { slot = lcap; used[0] = 1; }
-    else { slot = lcap + 1; used[1] = 1; }
-    if (slot == ~0u) continue; // (table full: used[2] is set, the query is redone)
+  constexpr int U = 4; // entries in flight per thread: the loads of a batch are independent
+  for (uint32_t k0 = tid; k0 < n; k0 += nthreads * U) {
+    uint32_t k[U], slot[U];
+    KS key[U];
+    bool lv[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      k[u] = k0 + (uint32_t)u * nthreads;
+      lv[u] = k[u] < n;
+      key[u] = lv[u] && k[u] < nh ? ((const KS *)base)[k[u]] : (KS)0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      slot[u] = 0;
+      if (!lv[u]) continue;
+      if (k[u] < nh) slot[u] = ltab_slot<KS>(lkeys, lbits, pshift, used, key[u]);
+      else if (k[u] == nh && hs) { slot[u] = lcap; used[0] = 1; }
+      else { slot[u] = lcap + 1; used[1] = 1; }
+      if (slot[u] == ~0u) { lv[u] = false; slot[u] = 0; } // (table full: used[2] is set, the query is redone)
+    }
     uint32_t loff = al8(lslots * (uint32_t)sizeof(KS));
     uint64_t goff = al16((uint64_t)D.cap * sizeof(KS));
     for (int a = 0; a < P.n_accs; a++) {
       const AccSpec Ac = P.accs[a];
-      const uint64_t part = Ac.width == 8 ? ((const uint64_t *)(base + goff))[k] : (uint64_t)((const uint32_t *)(base + goff))[k];
-      uint8_t *p = sm + loff + slot * Ac.width;
+      uint64_t part[U];
+#pragma unroll
+      for (int u = 0; u < U; u++)
+        part[u] = !lv[u] ? Ac.init : (Ac.width == 8 ? ((const uint64_t *)(base + goff))[k[u]] : (uint64_t)((const uint32_t *)(base + goff))[k[u]]);
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (!lv[u] || part[u] == Ac.init) continue; // identity: nothing to fold
+        uint8_t *p = sm + loff + slot[u] * Ac.width;
+        switch (Ac.op) {
+          case ACC_ADD_U64: atomicAdd((unsigned long long *)p, (unsigned long long)part[u]); break;
+          case ACC_ADD_F64: atomicAdd((double *)p, __longlong_as_double((long long)part[u])); break;
+          case ACC_MIN_I64: atomicMin((long long *)p, (long long)part[u]); break;
+          case ACC_MAX_I64: atomicMax((long long *)p, (long long)part[u]); break;
+          case ACC_MIN_U64: atomicMin((unsigned long long *)p, (unsigned long long)part[u]); break;
+          case ACC_MAX_U64: atomicMax((unsigned long long *)p, (unsigned long long)part[u]); break;
+          case ACC_CNT_ALL: case ACC_CNT_VALID: atomicAdd((unsigned int *)p, (unsigned int)part[u]); break;
+          case ACC_FIRST_ROW: atomicMin((unsigned int *)p, (unsigned int)part[u]); break;
+        }
+      }
       loff += al8(lslots * Ac.width);
       goff += al16((uint64_t)D.cap * Ac.width);
-      if (part == Ac.init) continue; // identity: nothing to fold
-      switch (Ac.op) {
-        case ACC_ADD_U64: atomicAdd((unsigned long long *)p, (unsigned long long)part); break;
-        case ACC_ADD_F64: atomicAdd((double *)p, __longlong_as_double((long long)part)); break;
-        case ACC_MIN_I64: atomicMin((long long *)p, (long long)part); break;
-        case ACC_MAX_I64: atomicMax((long long *)p, (long long)part); break;
-        case ACC_MIN_U64: atomicMin((unsigned long long *)p, (unsigned long long)part); break;
-        case ACC_MAX_U64: atomicMax((unsigned long long *)p, (unsigned long long)part); break;
-        case ACC_CNT_ALL: case ACC_CNT_VALID: atomicAdd((unsigned int *)p, (unsigned int)part); break;
-        case ACC_FIRST_ROW: atomicMin((unsigned int *)p, (unsigned int)part); break;
-      }
     }
   }
 }
