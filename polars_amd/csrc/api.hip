@@ -1269,7 +1269,8 @@ int run_sorted(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, plhip_result
   HIP_TRY(c.part.reserve(2 * n4));
   HIP_TRY(c.rank.reserve(n4 + 256));
   HIP_TRY(c.sortkeys.reserve(temp_bytes));
-  HIP_TRY(c.items.reserve(((size_t)n / 2048 + 2) * 4 + 256));
+  // long_count, long_list, then (launch_fold_sorted) a done counter and the combined states per long run
+  HIP_TRY(c.items.reserve(256 + ((size_t)n / 2048 + 2) * (8 + (size_t)std::max(P.n_accs, 1) * 8) + 64));
   HIP_TRY(c.flags.reserve(FLAGS_BYTES));
   HIP_TRY(c.plans.reserve(sizeof(KeyGather)));
   uint32_t *dflags = (uint32_t *)c.flags.p;

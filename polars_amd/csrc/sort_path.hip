@@ -110,13 +110,17 @@ __global__ void __launch_bounds__(SP_BLOCK) k_fold_sorted(Plan P, OutPlan O, con
                                                           const uint64_t *__restrict__ skeys, const uint32_t *__restrict__ rows,
                                                           const uint32_t *__restrict__ offsets, uint64_t G,
                                                           uint32_t *__restrict__ long_list, uint32_t *__restrict__ long_count,
-                                                          const uint32_t *__restrict__ gmap) {
+                                                          const uint32_t *__restrict__ gmap, uint32_t *__restrict__ long_done,
+                                                          uint64_t *__restrict__ long_part) {
   extern __shared__ __align__(16) uint64_t sst[]; // [n_accs][SP_BLOCK]
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= G) return;
   const uint32_t b = offsets[g], e = offsets[g + 1];
-  if (e - b >= SP_LONG) {
-    long_list[atomicAdd(long_count, 1u)] = (uint32_t)g;
+  if (e - b >= SP_LONG) { // queued, with the combined state of its chunks at the identities
+    const uint32_t li = atomicAdd(long_count, 1u);
+    long_list[li] = (uint32_t)g;
+    long_done[li] = 0u;
+    for (int a = 0; a < P.n_accs; a++) long_part[(uint64_t)li * P.n_accs + a] = P.accs[a].init;
     return;
   }
   // accumulators are ordered by source column: every value row is gathered ONCE and serves all of them
@@ -165,37 +169,82 @@ __global__ void __launch_bounds__(SP_BLOCK) k_fold_sorted(Plan P, OutPlan O, con
   emit_run(P, O, KG, sst, threadIdx.x, skeys ? skeys[b] : 0ull, rows[b], gmap ? gmap[g] : g); // gmap: stable (first-row) order
 }
 
-// one workgroup per long run: lanes stride the index list, partial states are combined in a fixed tree
+// Long runs.  Many of them: one workgroup per run (lanes stride the index list, partial states are combined in a fixed
+// tree).  Few (a heavy hitter: at most SP_FEW_LONG runs): every run is cut into chunks of SP_LCHUNK rows that the
+// workgroups share round-robin; a chunk's states go into the run's combined state with one global atomic per
+// accumulator, and the chunk that finishes last writes the output row (f64 sums then add up in completion order).
+#define SP_LCHUNK 16384u
+#define SP_FEW_LONG 64u
+DEVINL void combine_global(const AccSpec &a, uint64_t *p, uint64_t state) {
+  switch (a.op) {
+    case ACC_ADD_U64: case ACC_CNT_ALL: case ACC_CNT_VALID: atomicAdd((unsigned long long *)p, (unsigned long long)state); break;
+    case ACC_ADD_F64: atomicAdd((double *)p, __longlong_as_double((long long)state)); break;
+    case ACC_MIN_I64: atomicMin((long long *)p, (long long)state); break;
+    case ACC_MAX_I64: atomicMax((long long *)p, (long long)state); break;
+    case ACC_MIN_U64: case ACC_FIRST_ROW: atomicMin((unsigned long long *)p, (unsigned long long)state); break;
+    case ACC_MAX_U64: atomicMax((unsigned long long *)p, (unsigned long long)state); break;
+  }
+}
 __global__ void __launch_bounds__(SP_BLOCK) k_fold_sorted_long(Plan P, OutPlan O, const KeyGather *__restrict__ KG,
                                                                const uint64_t *__restrict__ skeys, const uint32_t *__restrict__ rows,
                                                                const uint32_t *__restrict__ offsets,
                                                                const uint32_t *__restrict__ long_list, const uint32_t *__restrict__ long_count,
-                                                               const uint32_t *__restrict__ gmap) {
+                                                               const uint32_t *__restrict__ gmap, uint32_t *__restrict__ long_done,
+                                                               uint64_t *__restrict__ long_part) {
   extern __shared__ __align__(16) uint64_t sst[]; // [n_accs][SP_BLOCK]
-  for (uint32_t li = blockIdx.x; li < *long_count; li += gridDim.x) {
+  __shared__ uint32_t s_last;
+  const uint32_t count = *long_count;
+  const bool few = count <= SP_FEW_LONG;
+  uint32_t base = 0; // few: chunks of the runs before this one
+  for (uint32_t li = few ? 0u : blockIdx.x; li < count; li += few ? 1u : gridDim.x) {
     const uint64_t g = long_list[li];
     const uint32_t b = offsets[g], e = offsets[g + 1];
-    for (int a = 0; a < P.n_accs; a++) {
-      const AccSpec A = P.accs[a];
-      uint64_t st = A.init;
-      for (uint32_t i = b + threadIdx.x; i < e; i += SP_BLOCK) {
-        uint64_t operand;
-        if (acc_operand(P, A, (int64_t)rows[i], operand)) fold_local(A, st, operand);
-      }
-      uint64_t *col = sst + a * SP_BLOCK;
-      col[threadIdx.x] = st;
-      __syncthreads();
-      for (uint32_t off = SP_BLOCK / 2; off > 0; off >>= 1) {
-        if (threadIdx.x < off) {
-          uint64_t mine = col[threadIdx.x];
-          fold_local(A, mine, col[threadIdx.x + off]);
-          col[threadIdx.x] = mine;
+    const uint32_t C = few ? (e - b + SP_LCHUNK - 1) / SP_LCHUNK : 1u;
+    for (uint32_t c = few ? (blockIdx.x + gridDim.x - base % gridDim.x) % gridDim.x : 0u; c < C; c += gridDim.x) {
+      const uint32_t cb = few ? b + c * SP_LCHUNK : b, ce = few ? (e - cb > SP_LCHUNK ? cb + SP_LCHUNK : e) : e;
+      for (int a = 0; a < P.n_accs; a++) {
+        const AccSpec A = P.accs[a];
+        uint64_t st = A.init;
+        for (uint32_t i0 = cb + threadIdx.x; i0 < ce; i0 += 4 * SP_BLOCK) { // four gathers in flight
+          uint32_t r[4];
+          bool ok[4];
+          uint64_t operand[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) { const uint32_t i = i0 + (uint32_t)k * SP_BLOCK; ok[k] = i < ce; r[k] = rows[ok[k] ? i : cb]; }
+#pragma unroll
+          for (int k = 0; k < 4; k++) ok[k] = acc_operand(P, A, (int64_t)r[k], operand[k]) && ok[k];
+#pragma unroll
+          for (int k = 0; k < 4; k++) if (ok[k]) fold_local(A, st, operand[k]);
         }
+        uint64_t *col = sst + a * SP_BLOCK;
+        col[threadIdx.x] = st;
         __syncthreads();
+        for (uint32_t off = SP_BLOCK / 2; off > 0; off >>= 1) {
+          if (threadIdx.x < off) {
+            uint64_t mine = col[threadIdx.x];
+            fold_local(A, mine, col[threadIdx.x + off]);
+            col[threadIdx.x] = mine;
+          }
+          __syncthreads();
+        }
       }
+      if (threadIdx.x == 0) {
+        bool emit = true;
+        if (C > 1) {
+          for (int a = 0; a < P.n_accs; a++) combine_global(P.accs[a], &long_part[(uint64_t)li * P.n_accs + a], sst[a * SP_BLOCK]);
+          __threadfence();
+          emit = atomicAdd(&long_done[li], 1u) == C - 1;
+          if (emit) {
+            __threadfence();
+            for (int a = 0; a < P.n_accs; a++)
+              sst[a * SP_BLOCK] = __hip_atomic_load(&long_part[(uint64_t)li * P.n_accs + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        if (emit) emit_run(P, O, KG, sst, 0, skeys ? skeys[b] : 0ull, rows[b], gmap ? gmap[g] : g);
+      }
+      __syncthreads();
     }
-    if (threadIdx.x == 0) emit_run(P, O, KG, sst, 0, skeys ? skeys[b] : 0ull, rows[b], gmap ? gmap[g] : g);
-    __syncthreads();
+    base += C;
   }
 }
 
@@ -446,10 +495,14 @@ hipError_t launch_stable_order(const uint32_t *rows, const uint32_t *offsets, ui
 void launch_fold_sorted(const Plan &p, const OutPlan &o, const KeyGather *kg_dev, const uint64_t *skeys, const uint32_t *rows,
                         const uint32_t *offsets, uint64_t G, uint32_t *long_list, uint32_t *long_count, hipStream_t s, const uint32_t *gmap) {
   if (!G) return;
+  // behind the list: a done counter per long run, then its combined accumulator states (the caller sized the buffer)
+  const uint64_t max_runs = (uint64_t)p.n_rows / SP_LONG + 2;
+  uint32_t *long_done = long_list + max_runs;
+  uint64_t *long_part = (uint64_t *)(((uintptr_t)(long_done + max_runs) + 7) & ~(uintptr_t)7);
   const size_t lds = (size_t)(p.n_accs ? p.n_accs : 1) * SP_BLOCK * 8;
   hipLaunchKernelGGL(k_fold_sorted, dim3((unsigned)((G + SP_BLOCK - 1) / SP_BLOCK)), dim3(SP_BLOCK), lds, s, p, o, kg_dev, skeys, rows, offsets, G,
-                     long_list, long_count, gmap);
+                     long_list, long_count, gmap, long_done, long_part);
   const uint64_t max_long = (uint64_t)p.n_rows / SP_LONG + 1;
   hipLaunchKernelGGL(k_fold_sorted_long, dim3((unsigned)(max_long < 4096 ? max_long : 4096)), dim3(SP_BLOCK), lds, s, p, o, kg_dev, skeys, rows,
-                     offsets, long_list, long_count, gmap);
+                     offsets, long_list, long_count, gmap, long_done, long_part);
 }

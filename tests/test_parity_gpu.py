@@ -1009,6 +1009,27 @@ def test_tile_sort_hot_partitions_are_split(oracle, monkeypatch, key_dtype):
     check_parity(oracle, keys, values, aggs, "tilesort", what="hot partitions, one workgroup each")
 
 
+def test_sort_strategy_long_runs_are_split(oracle):
+    """The sort strategy under skew: a few long runs (a heavy hitter, the null keys) are cut into chunks that the
+    workgroups share, combined with global atomics, the last chunk writes the row (sort_path.hip, k_fold_sorted_long);
+    every accumulator kind, nullable key and values, unordered and in stable order; then more than 64 long runs (one
+    workgroup per run)."""
+    rng = np.random.default_rng(151)
+    n = 700_000
+    k = rng.integers(0, 50_000, n).astype(np.int64)
+    u = rng.random(n)
+    k[u < 0.3] = 7
+    k[(u >= 0.3) & (u < 0.4)] = -12345
+    keys = [Column("k", k, rng.random(n) > 0.05)]
+    values = [Column("a", rng.integers(-1000, 1000, n).astype(np.int64)), rand_col(rng, "b", np.float64, n, null_frac=0.1)]
+    aggs = [(0, "sum"), (1, "mean"), (0, "min"), (1, "max"), (0, "count"), (1, "sum"), (1, "min")]
+    check_parity(oracle, keys, values, aggs, "sort", what="long runs split")
+    assert pa.last_strategy() == "sort"
+    check_parity(oracle, keys, values, aggs, "sort", maintain_order=True, what="long runs split, stable order")
+    keys = [Column("k", rng.integers(0, 100, n).astype(np.int32))]  # 100 runs of ~7 000 rows
+    check_parity(oracle, keys, values, aggs, "sort", what="many long runs")
+
+
 def test_two_levels_hot_leaves_are_split(oracle, monkeypatch):
     """Heavy hitters in the two-level pipeline: leaves with many rows are folded by several workgroups whose tables the
     last one merges (fast.hpp, HotState).  A lowered chunk size makes a dozen leaves split at a size the oracle
