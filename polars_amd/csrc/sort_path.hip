@@ -24,6 +24,7 @@ namespace {
 
 #define SP_BLOCK 256
 #define SP_LONG 2048 // runs at least this long go to the per-workgroup kernel
+#define SP_HUGE 131072u // ... and runs at least this long are shared by several workgroups
 
 __global__ void __launch_bounds__(256) k_pack_rows(Plan P, uint64_t *__restrict__ keys, uint32_t *__restrict__ rows) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -111,16 +112,20 @@ __global__ void __launch_bounds__(SP_BLOCK) k_fold_sorted(Plan P, OutPlan O, con
                                                           const uint32_t *__restrict__ offsets, uint64_t G,
                                                           uint32_t *__restrict__ long_list, uint32_t *__restrict__ long_count,
                                                           const uint32_t *__restrict__ gmap, uint32_t *__restrict__ long_done,
-                                                          uint64_t *__restrict__ long_part) {
+                                                          uint64_t *__restrict__ long_part, uint32_t max_runs) {
   extern __shared__ __align__(16) uint64_t sst[]; // [n_accs][SP_BLOCK]
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= G) return;
   const uint32_t b = offsets[g], e = offsets[g + 1];
-  if (e - b >= SP_LONG) { // queued, with the combined state of its chunks at the identities
-    const uint32_t li = atomicAdd(long_count, 1u);
-    long_list[li] = (uint32_t)g;
-    long_done[li] = 0u;
-    for (int a = 0; a < P.n_accs; a++) long_part[(uint64_t)li * P.n_accs + a] = P.accs[a].init;
+  if (e - b >= SP_HUGE) { // queued from the list's far end, with the combined state of its chunks at the identities
+    const uint32_t hi = atomicAdd(long_count + 1, 1u);
+    long_list[max_runs - 1 - hi] = (uint32_t)g;
+    long_done[hi] = 0u;
+    for (int a = 0; a < P.n_accs; a++) long_part[(uint64_t)hi * P.n_accs + a] = P.accs[a].init;
+    return;
+  }
+  if (e - b >= SP_LONG) {
+    long_list[atomicAdd(long_count, 1u)] = (uint32_t)g;
     return;
   }
   // accumulators are ordered by source column: every value row is gathered ONCE and serves all of them
@@ -169,12 +174,11 @@ __global__ void __launch_bounds__(SP_BLOCK) k_fold_sorted(Plan P, OutPlan O, con
   emit_run(P, O, KG, sst, threadIdx.x, skeys ? skeys[b] : 0ull, rows[b], gmap ? gmap[g] : g); // gmap: stable (first-row) order
 }
 
-// Long runs.  Many of them: one workgroup per run (lanes stride the index list, partial states are combined in a fixed
-// tree).  Few (a heavy hitter: at most SP_FEW_LONG runs): every run is cut into chunks of SP_LCHUNK rows that the
+// Long runs (>= SP_LONG rows): one workgroup per run (lanes stride the index list, partial states are combined in a
+// fixed tree).  Huge runs (>= SP_HUGE: a heavy hitter, the null keys) are cut into chunks of SP_LCHUNK rows that the
 // workgroups share round-robin; a chunk's states go into the run's combined state with one global atomic per
 // accumulator, and the chunk that finishes last writes the output row (f64 sums then add up in completion order).
 #define SP_LCHUNK 16384u
-#define SP_FEW_LONG 64u
 DEVINL void combine_global(const AccSpec &a, uint64_t *p, uint64_t state) {
   switch (a.op) {
     case ACC_ADD_U64: case ACC_CNT_ALL: case ACC_CNT_VALID: atomicAdd((unsigned long long *)p, (unsigned long long)state); break;
@@ -185,62 +189,67 @@ DEVINL void combine_global(const AccSpec &a, uint64_t *p, uint64_t state) {
     case ACC_MAX_U64: atomicMax((unsigned long long *)p, (unsigned long long)state); break;
   }
 }
+// rows [cb, ce) of the sorted index list -> sst[a * SP_BLOCK] for every accumulator a (all threads of the workgroup)
+DEVINL void reduce_rows(const Plan &P, const uint32_t *__restrict__ rows, uint64_t *sst, uint32_t cb, uint32_t ce) {
+  for (int a = 0; a < P.n_accs; a++) {
+    const AccSpec A = P.accs[a];
+    uint64_t st = A.init;
+    for (uint32_t i0 = cb + threadIdx.x; i0 < ce; i0 += 4 * SP_BLOCK) { // four gathers in flight
+      uint32_t r[4];
+      bool ok[4];
+      uint64_t operand[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) { const uint32_t i = i0 + (uint32_t)k * SP_BLOCK; ok[k] = i < ce; r[k] = rows[ok[k] ? i : cb]; }
+#pragma unroll
+      for (int k = 0; k < 4; k++) ok[k] = acc_operand(P, A, (int64_t)r[k], operand[k]) && ok[k];
+#pragma unroll
+      for (int k = 0; k < 4; k++) if (ok[k]) fold_local(A, st, operand[k]);
+    }
+    uint64_t *col = sst + a * SP_BLOCK;
+    col[threadIdx.x] = st;
+    __syncthreads();
+    for (uint32_t off = SP_BLOCK / 2; off > 0; off >>= 1) {
+      if (threadIdx.x < off) {
+        uint64_t mine = col[threadIdx.x];
+        fold_local(A, mine, col[threadIdx.x + off]);
+        col[threadIdx.x] = mine;
+      }
+      __syncthreads();
+    }
+  }
+}
 __global__ void __launch_bounds__(SP_BLOCK) k_fold_sorted_long(Plan P, OutPlan O, const KeyGather *__restrict__ KG,
                                                                const uint64_t *__restrict__ skeys, const uint32_t *__restrict__ rows,
                                                                const uint32_t *__restrict__ offsets,
                                                                const uint32_t *__restrict__ long_list, const uint32_t *__restrict__ long_count,
                                                                const uint32_t *__restrict__ gmap, uint32_t *__restrict__ long_done,
-                                                               uint64_t *__restrict__ long_part) {
+                                                               uint64_t *__restrict__ long_part, uint32_t max_runs) {
   extern __shared__ __align__(16) uint64_t sst[]; // [n_accs][SP_BLOCK]
-  __shared__ uint32_t s_last;
-  const uint32_t count = *long_count;
-  const bool few = count <= SP_FEW_LONG;
-  uint32_t base = 0; // few: chunks of the runs before this one
-  for (uint32_t li = few ? 0u : blockIdx.x; li < count; li += few ? 1u : gridDim.x) {
+  const uint32_t count = long_count[0], n_huge = long_count[1];
+  for (uint32_t li = blockIdx.x; li < count; li += gridDim.x) {
     const uint64_t g = long_list[li];
     const uint32_t b = offsets[g], e = offsets[g + 1];
-    const uint32_t C = few ? (e - b + SP_LCHUNK - 1) / SP_LCHUNK : 1u;
-    for (uint32_t c = few ? (blockIdx.x + gridDim.x - base % gridDim.x) % gridDim.x : 0u; c < C; c += gridDim.x) {
-      const uint32_t cb = few ? b + c * SP_LCHUNK : b, ce = few ? (e - cb > SP_LCHUNK ? cb + SP_LCHUNK : e) : e;
-      for (int a = 0; a < P.n_accs; a++) {
-        const AccSpec A = P.accs[a];
-        uint64_t st = A.init;
-        for (uint32_t i0 = cb + threadIdx.x; i0 < ce; i0 += 4 * SP_BLOCK) { // four gathers in flight
-          uint32_t r[4];
-          bool ok[4];
-          uint64_t operand[4];
-#pragma unroll
-          for (int k = 0; k < 4; k++) { const uint32_t i = i0 + (uint32_t)k * SP_BLOCK; ok[k] = i < ce; r[k] = rows[ok[k] ? i : cb]; }
-#pragma unroll
-          for (int k = 0; k < 4; k++) ok[k] = acc_operand(P, A, (int64_t)r[k], operand[k]) && ok[k];
-#pragma unroll
-          for (int k = 0; k < 4; k++) if (ok[k]) fold_local(A, st, operand[k]);
-        }
-        uint64_t *col = sst + a * SP_BLOCK;
-        col[threadIdx.x] = st;
-        __syncthreads();
-        for (uint32_t off = SP_BLOCK / 2; off > 0; off >>= 1) {
-          if (threadIdx.x < off) {
-            uint64_t mine = col[threadIdx.x];
-            fold_local(A, mine, col[threadIdx.x + off]);
-            col[threadIdx.x] = mine;
-          }
-          __syncthreads();
-        }
-      }
+    reduce_rows(P, rows, sst, b, e);
+    if (threadIdx.x == 0) emit_run(P, O, KG, sst, 0, skeys ? skeys[b] : 0ull, rows[b], gmap ? gmap[g] : g);
+    __syncthreads();
+  }
+  uint32_t base = 0; // chunks of the huge runs before this one
+  for (uint32_t hi = 0; hi < n_huge; hi++) {
+    const uint64_t g = long_list[max_runs - 1 - hi];
+    const uint32_t b = offsets[g], e = offsets[g + 1];
+    const uint32_t C = (e - b + SP_LCHUNK - 1) / SP_LCHUNK;
+    for (uint32_t c = (blockIdx.x + gridDim.x - base % gridDim.x) % gridDim.x; c < C; c += gridDim.x) {
+      const uint32_t cb = b + c * SP_LCHUNK, ce = e - cb > SP_LCHUNK ? cb + SP_LCHUNK : e;
+      reduce_rows(P, rows, sst, cb, ce);
       if (threadIdx.x == 0) {
-        bool emit = true;
-        if (C > 1) {
-          for (int a = 0; a < P.n_accs; a++) combine_global(P.accs[a], &long_part[(uint64_t)li * P.n_accs + a], sst[a * SP_BLOCK]);
+        for (int a = 0; a < P.n_accs; a++) combine_global(P.accs[a], &long_part[(uint64_t)hi * P.n_accs + a], sst[a * SP_BLOCK]);
+        __threadfence();
+        if (atomicAdd(&long_done[hi], 1u) == C - 1) { // the last chunk of the run
           __threadfence();
-          emit = atomicAdd(&long_done[li], 1u) == C - 1;
-          if (emit) {
-            __threadfence();
-            for (int a = 0; a < P.n_accs; a++)
-              sst[a * SP_BLOCK] = __hip_atomic_load(&long_part[(uint64_t)li * P.n_accs + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
+          for (int a = 0; a < P.n_accs; a++)
+            sst[a * SP_BLOCK] = __hip_atomic_load(&long_part[(uint64_t)hi * P.n_accs + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          emit_run(P, O, KG, sst, 0, skeys ? skeys[b] : 0ull, rows[b], gmap ? gmap[g] : g);
         }
-        if (emit) emit_run(P, O, KG, sst, 0, skeys ? skeys[b] : 0ull, rows[b], gmap ? gmap[g] : g);
       }
       __syncthreads();
     }
@@ -501,8 +510,8 @@ void launch_fold_sorted(const Plan &p, const OutPlan &o, const KeyGather *kg_dev
   uint64_t *long_part = (uint64_t *)(((uintptr_t)(long_done + max_runs) + 7) & ~(uintptr_t)7);
   const size_t lds = (size_t)(p.n_accs ? p.n_accs : 1) * SP_BLOCK * 8;
   hipLaunchKernelGGL(k_fold_sorted, dim3((unsigned)((G + SP_BLOCK - 1) / SP_BLOCK)), dim3(SP_BLOCK), lds, s, p, o, kg_dev, skeys, rows, offsets, G,
-                     long_list, long_count, gmap, long_done, long_part);
+                     long_list, long_count, gmap, long_done, long_part, (uint32_t)max_runs);
   const uint64_t max_long = (uint64_t)p.n_rows / SP_LONG + 1;
   hipLaunchKernelGGL(k_fold_sorted_long, dim3((unsigned)(max_long < 4096 ? max_long : 4096)), dim3(SP_BLOCK), lds, s, p, o, kg_dev, skeys, rows,
-                     offsets, long_list, long_count, gmap, long_done, long_part);
+                     offsets, long_list, long_count, gmap, long_done, long_part, (uint32_t)max_runs);
 }
