@@ -942,19 +942,35 @@ __global__ void __launch_bounds__(1024) k_fold_runs(Plan P, FoldRunsArgs A, OutP
   constexpr int RUNS_B = SH::STATIC ? 8 : 4; // tiles per wave batch
   const int keymode = sizeof(KS) == 4 ? 1 : 2; // the sorted copies hold packed keys of sizeof(KS) bytes
   // lanes 0..B-1 hold the run bounds of the wave's next batch of tiles (fetched one batch ahead)
-  uint32_t t = t0 + wave * RUNS_B;
+  // A chunk of a split leaf has few tiles with long runs: a wave then takes ONE tile per batch and cuts its run into
+  // RUNS_B segments (the batch elements), so that all waves work and a 2 000-row run takes 4 trips instead of 32.
+  const bool cut = chunks > 1 && (t1 - t0) * 2u <= nw * (uint32_t)RUNS_B;
+  const uint32_t TB = cut ? 1u : (uint32_t)RUNS_B; // tiles per wave batch
+  uint32_t t = t0 + wave * TB;
   uint32_t st = 0, len = 0;
-  if (lane < RUNS_B && t + lane < t1) { st = o0[t + lane]; len = o1[t + lane] - st; }
+  if (lane < TB && t + lane < t1) { st = o0[t + lane]; len = o1[t + lane] - st; }
   while (t < t1) {
-    const uint32_t tn = t + nw * RUNS_B;
+    const uint32_t tn = t + nw * TB;
     uint32_t stn = 0, lenn = 0;
-    if (lane < RUNS_B && tn + lane < t1) { stn = o0[tn + lane]; lenn = o1[tn + lane] - stn; }
+    if (lane < TB && tn + lane < t1) { stn = o0[tn + lane]; lenn = o1[tn + lane] - stn; }
     uint32_t s_[RUNS_B], n_[RUNS_B], maxlen = 0;
+    if (cut) {
+      const uint32_t st0 = (uint32_t)__builtin_amdgcn_readlane((int)st, 0) + t * (uint32_t)TS_TILE;
+      const uint32_t len0 = (uint32_t)__builtin_amdgcn_readlane((int)len, 0), sg = (len0 + RUNS_B - 1) / RUNS_B;
+#pragma unroll
+      for (int b = 0; b < RUNS_B; b++) {
+        const uint32_t off = (uint32_t)b * sg;
+        s_[b] = st0 + (off < len0 ? off : 0u);
+        n_[b] = off < len0 ? (len0 - off < sg ? len0 - off : sg) : 0u;
+        maxlen = n_[b] > maxlen ? n_[b] : maxlen;
+      }
+    } else {
 #pragma unroll
     for (int b = 0; b < RUNS_B; b++) {
       s_[b] = (uint32_t)__builtin_amdgcn_readlane((int)st, b) + (t + b) * (uint32_t)TS_TILE;
       n_[b] = (uint32_t)__builtin_amdgcn_readlane((int)len, b);
       maxlen = n_[b] > maxlen ? n_[b] : maxlen;
+    }
     }
     // dead lanes still look their (clamped) row's key up: an empty run must not point them at another
     // partition's rows, so it borrows the start of a run of this batch that has rows
