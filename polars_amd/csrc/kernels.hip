@@ -384,11 +384,28 @@ __global__ void __launch_bounds__(256) k_agg_groups(Plan P, OutPlan O, const uin
   for (int a = 0; a < 4; a++) st[a] = a < P.n_accs ? P.accs[a].init : 0;
   if (live) {
     const uint32_t b = offsets[g], e = offsets[g + 1];
-    for (uint32_t i = b + (WAVE ? lane : 0); i < e; i += (WAVE ? 64 : 1)) {
-      const int64_t row = indices[i];
-      for (int a = 0; a < P.n_accs && a < 4; a++) {
-        uint64_t operand;
-        if (acc_operand(P, P.accs[a], row, operand)) acc_fold_local(P.accs[a], st[a], operand);
+    if (WAVE) { // four gathers in flight per lane; a lane still folds its rows i, i + 64, i + 128, ... in that order
+      for (uint32_t i0 = b + lane; i0 < e; i0 += 256) {
+        int64_t row[4];
+        bool ok[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const uint32_t i = i0 + 64u * (uint32_t)k; ok[k] = i < e; row[k] = indices[ok[k] ? i : b]; }
+        for (int a = 0; a < P.n_accs && a < 4; a++) {
+          uint64_t operand[4];
+          bool v[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) v[k] = acc_operand(P, P.accs[a], row[k], operand[k]) && ok[k];
+#pragma unroll
+          for (int k = 0; k < 4; k++) if (v[k]) acc_fold_local(P.accs[a], st[a], operand[k]);
+        }
+      }
+    } else {
+      for (uint32_t i = b; i < e; i++) {
+        const int64_t row = indices[i];
+        for (int a = 0; a < P.n_accs && a < 4; a++) {
+          uint64_t operand;
+          if (acc_operand(P, P.accs[a], row, operand)) acc_fold_local(P.accs[a], st[a], operand);
+        }
       }
     }
   }
