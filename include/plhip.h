@@ -230,6 +230,30 @@ int32_t plhip_group_by_agg_opts(const plhip_column_t *keys, int32_t n_keys, cons
                                 int32_t n_values, const plhip_agg_t *aggs, int32_t n_aggs, uint32_t flags,
                                 const plhip_options_t *opts, plhip_result_t **out);
 
+/* plhip_group_by_agg_opts for callers that cannot allocate: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  NO counterpart in the reference (there every aggregation allocates its output
+ * Series); it exists for those callers only.  It calls no hipMalloc / hipFree / allocating routine: inputs and
+ * outputs are the caller's device buffers, and everything the kernels need beyond them (flag block, dump headers,
+ * the compact table dumps k_fold_rows hands to k_merge_emit) lives in one static device array of
+ * PLHIP_NOALLOC_SCRATCH_BYTES per GPU, resolved with hipGetSymbolAddress when plhip_init binds the thread's device.
+ *   - plhip_init must have been called on the calling thread (it creates the stream and the pinned signal word);
+ *   - exactly one key column; keys / values device-resident; flags: 0 or PLHIP_FLAG_PARTIAL;
+ *   - n_groups_hint >= 1 is required (an upper bound on the groups, e.g. a Categorical key's category count), and the
+ *     groups must fit the DIRECT strategy (one LDS table, roughly <= 5 000 groups) within the scratch limit: anything
+ *     larger is rejected with PLHIP_ERR_INVALID and a message that names the limit;
+ *   - out_cols[n_out_cols] = the frame plhip_group_by_agg_opts would return (key column, then one column per
+ *     aggregation; two for MEAN under PLHIP_FLAG_PARTIAL), as caller-allocated DEVICE buffers: dtype = the output
+ *     dtype, offset 0, length = CAPACITY in rows, validity = a bitmap of (length / 64 + 1) * 8 bytes where the column
+ *     can be null (a nullable key, MEAN / MIN / MAX of a nullable column), ignored elsewhere.  The rows written = *n_groups
+ *     (group order unspecified, as in the reference); more groups than the smallest capacity -> PLHIP_ERR_COMPUTE.
+ * All calls on one GPU share that GPU's array, which keeps the last call's contents (the entry point clears what must
+ * start at zero): calls that overlap on one GPU race -- serialise them. */
+#define PLHIP_NOALLOC_SCRATCH_BYTES (40u << 20)
+int32_t plhip_group_by_agg_noalloc(const plhip_column_t *keys, int32_t n_keys, const plhip_column_t *values,
+                                   int32_t n_values, const plhip_agg_t *aggs, int32_t n_aggs, uint32_t flags,
+                                   int64_t n_groups_hint, const plhip_column_t *out_cols, int32_t n_out_cols,
+                                   int64_t *n_groups);
+
 /* ---- result frame accessors ------------------------------------------------------------------- */
 
 int64_t plhip_result_num_rows(const plhip_result_t *r);    /* number of groups */

@@ -19,6 +19,11 @@
 #include "fast.hpp"
 #include "kernels.hpp"
 
+// Scratch of plhip_group_by_agg_noalloc (flag block, dump headers, table dumps): a file-scope device array, so that the
+// entry point never calls hipMalloc.  Every GPU the library runs on holds its own copy until the process ends.  In host
+// code this NAME is only a stand-in for hipGetSymbolAddress (resolve_scratch below): kernels, memsets and copies get the
+// resolved device pointer, never the name.
+static __device__ __align__(256) unsigned char scratch[PLHIP_NOALLOC_SCRATCH_BYTES];
 
 // ---------------------------------------------------------------------------------------------------------
 // per-thread context
@@ -59,6 +64,7 @@ struct Ctx {
   uint32_t seq = 0;
   bool hot_clean = false;  // the heavy-hitter words behind the flag block (FLAGS_HOT_OFF ..) are zero
   int timing_pending = 0; // 1: direct, 2: tilesort (S == 1), 3: tilesort + merge -- event times not read yet
+  uint8_t *na_scratch = nullptr; // device address of this GPU's static scratch array (plhip_group_by_agg_noalloc)
 };
 
 // the flag block: 64 bytes of flags, then the single-level tile sort's heavy-hitter words (rows in long runs and done counters
@@ -82,6 +88,7 @@ int fail_hip(hipError_t e, const char *what) {
   } while (0)
 
 void resolve_timing();
+int resolve_scratch(int dev, uint8_t **p);
 
 int ensure_ctx() {
   Ctx &c = g_ctx;
@@ -104,6 +111,7 @@ int ensure_ctx() {
   HIP_TRY(hipHostMalloc((void **)&c.host_sig, 64, hipHostMallocMapped | hipHostMallocCoherent));
   memset(c.host_sig, 0, 64);
   HIP_TRY(hipHostGetDevicePointer((void **)&c.host_sig_dev, c.host_sig, 0));
+  { const int rs = resolve_scratch(dev, &c.na_scratch); if (rs) return rs; } // `dev` is current
   c.device = dev;
   return PLHIP_OK;
 }
@@ -807,6 +815,43 @@ int estimate_groups_sampled(const Plan &P, uint64_t &g_est) {
   return PLHIP_OK;
 }
 
+// Shape of the DIRECT strategy (row slices -> per-workgroup LDS tables -> merge): ok = the groups fit one LDS table.
+struct DirectShape {
+  bool ok = false;
+  uint32_t lbits = 0, block = 1024, n_items = 0, mbits = 0;
+  int64_t rows_per_item = 0;
+};
+DirectShape plan_direct(const Plan &P, uint64_t g_est, int key_bytes, int64_t n, int cus) {
+  DirectShape D;
+  const size_t LDS_MAX = 136 * 1024; // fast_path.hip allows 140 KB of dynamic LDS per workgroup
+  // sparse tables (<= 1/8 full when LDS allows) keep most probes at the home slot
+  // densest table accepted: 3/4 full (one pass at 2 500 groups and load 0.61 measured 0.081 ms against 0.136 ms
+  // for the three-pass tile sort, scripts/sweep_groups.py)
+  const uint64_t min_slots = (4 * g_est + 2) / 3 + 2;
+  uint32_t lb = (uint32_t)std::max(6, ceil_log2(min_slots));
+  if (lb > 15 || fast_table_bytes(P, lb, key_bytes) > LDS_MAX) return D;
+  D.ok = true;
+  while (lb < 15 && (1ull << lb) < 8 * g_est && fast_table_bytes(P, lb + 1, key_bytes) <= 64 * 1024) lb++;
+  D.lbits = lb;
+  // the fold kernel holds ~112 VGPRs: 4 waves per SIMD = 1024 threads per CU, as few workgroups as the
+  // table size allows (each workgroup dumps its table once)
+  const size_t tb = fast_table_bytes(P, D.lbits, key_bytes);
+  // pre-instantiated shapes need < 64 VGPRs (8 waves per SIMD), the run-time shape ~112 (4 waves per SIMD)
+  const bool st = fast_shape_id(P) >= 0;
+  int wg_per_cu;
+  // few, large workgroups: every workgroup initialises and dumps a table of its own
+  if (tb <= 72 * 1024 && st) { D.block = 1024; wg_per_cu = 2; }
+  else if (tb <= 72 * 1024) { D.block = 512; wg_per_cu = 2; }
+  else { D.block = 1024; wg_per_cu = 1; }
+  const int64_t step = (int64_t)D.block * (st ? 8 : 4); // rows one workgroup folds per loop trip
+  const int64_t items = std::max<int64_t>(1, std::min<int64_t>((int64_t)cus * wg_per_cu, (n + step - 1) / step));
+  D.rows_per_item = ((n + items - 1) / items + step - 1) / step * step;
+  D.n_items = (uint32_t)((n + D.rows_per_item - 1) / D.rows_per_item);
+  const uint64_t entries = (uint64_t)D.n_items * std::min<uint64_t>(g_est, 1ull << D.lbits);
+  while (D.mbits < FP_MAX_MBITS && (entries >> D.mbits) > 4096) D.mbits++;
+  return D;
+}
+
 // The LDS-only pipeline (fast_path.hip).  Sets `handled` when it produced the result; otherwise the caller
 // runs the general path (stable order, wide key tuples, tiny inputs, more groups than one partition level
 // brings into LDS, or a cardinality estimate that turned out too low).
@@ -846,20 +891,9 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
   // ---- shape of the pipeline -----------------------------------------------------------------------------
   const int cus = plhip_num_cus();
   const size_t LDS_MAX = 136 * 1024; // fast_path.hip allows 140 KB of dynamic LDS per workgroup
-  bool direct = false;
-  uint32_t lbits = 0, block = 1024;
-  {
-    // sparse tables (<= 1/8 full when LDS allows) keep most probes at the home slot
-    // densest table accepted: 3/4 full (one pass at 2 500 groups and load 0.61 measured 0.081 ms against 0.136 ms
-    // for the three-pass tile sort, scripts/sweep_groups.py)
-    const uint64_t min_slots = (4 * g_est + 2) / 3 + 2;
-    uint32_t lb = (uint32_t)std::max(6, ceil_log2(min_slots));
-    if (lb <= 15 && fast_table_bytes(P, lb, key_bytes) <= LDS_MAX) {
-      direct = true;
-      while (lb < 15 && (1ull << lb) < 8 * g_est && fast_table_bytes(P, lb + 1, key_bytes) <= 64 * 1024) lb++;
-      lbits = lb;
-    }
-  }
+  const DirectShape DS = plan_direct(P, g_est, key_bytes, n, cus);
+  bool direct = DS.ok;
+  uint32_t lbits = DS.lbits, block = 1024;
   if (strategy == PLHIP_STRATEGY_TILESORT) direct = false;
   if (strategy == PLHIP_STRATEGY_DIRECT && !direct) return PLHIP_OK;
   uint32_t pbits = 8, np = 1u << pbits; // 9 when that is what brings the groups of a partition into LDS
@@ -867,23 +901,8 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
   int64_t rows_per_item = 0;
   const uint32_t n_tiles = (uint32_t)((n + TS_TILE - 1) / TS_TILE);
   if (direct) {
-    // the fold kernel holds ~112 VGPRs: 4 waves per SIMD = 1024 threads per CU, as few workgroups as the
-    // table size allows (each workgroup dumps its table once)
-    const size_t tb = fast_table_bytes(P, lbits, key_bytes);
-    // pre-instantiated shapes need < 64 VGPRs (8 waves per SIMD), the run-time shape ~112 (4 waves per SIMD)
-    const bool st = fast_shape_id(P) >= 0;
-    int wg_per_cu;
-    // few, large workgroups: every workgroup initialises and dumps a table of its own
-    if (tb <= 72 * 1024 && st) { block = 1024; wg_per_cu = 2; }
-    else if (tb <= 72 * 1024) { block = 512; wg_per_cu = 2; }
-    else { block = 1024; wg_per_cu = 1; }
-    const int64_t step = (int64_t)block * (st ? 8 : 4); // rows one workgroup folds per loop trip
-    int64_t items = std::max<int64_t>(1, std::min<int64_t>((int64_t)cus * wg_per_cu, (n + step - 1) / step));
-    rows_per_item = ((n + items - 1) / items + step - 1) / step * step;
-    n_items = (uint32_t)((n + rows_per_item - 1) / rows_per_item);
+    block = DS.block; rows_per_item = DS.rows_per_item; n_items = DS.n_items; mbits = DS.mbits;
     S = n_items;
-    const uint64_t entries = (uint64_t)n_items * std::min<uint64_t>(g_est, 1ull << lbits);
-    while (mbits < FP_MAX_MBITS && (entries >> mbits) > 4096) mbits++;
   } else {
     // groups per hash partition, with head-room for the sampling error and uneven partitions
     const double slack = groups_hint > 0 ? 1.12 : 1.3; // a hint is a bound: only the partitions' unevenness is left
@@ -1040,6 +1059,121 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
   return finish_result(R, G, flags, out);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// plhip_group_by_agg_noalloc: the DIRECT strategy for callers that cannot allocate (HIP graph capture, tight
+// serving loops, harnesses that forbid hipMalloc).  Everything the kernels need beyond the caller's inputs and
+// outputs -- the flag block, the dump headers and the compact table dumps that k_fold_rows hands to k_merge_emit --
+// lives in ONE file-scope device array.  Host code never passes the array's name to a kernel: the name is a
+// host-side stand-in; the device address comes from hipGetSymbolAddress, once per device (each GPU holds its
+// own copy at its own address), and that pointer is what kernels, memsets and copies get.
+// ---------------------------------------------------------------------------------------------------------
+std::mutex g_scratch_mu;
+uint8_t *g_scratch_ptr[64] = {nullptr}; // per device
+
+// with `dev` current: the device address of this GPU's copy of scratch[]
+int resolve_scratch(int dev, uint8_t **p) {
+  if (dev < 0 || dev >= 64) return fail(PLHIP_ERR_INVALID, "device id out of range");
+  std::lock_guard<std::mutex> g(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    void *q = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&q, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !q) return fail_hip(e == hipSuccess ? hipErrorInvalidSymbol : e, "hipGetSymbolAddress(scratch)");
+    g_scratch_ptr[dev] = (uint8_t *)q;
+  }
+  *p = g_scratch_ptr[dev];
+  return PLHIP_OK;
+}
+
+int run_direct_noalloc(Lowered &L, const std::vector<DevCol> &dk, int64_t groups_hint, const plhip_column_t *out_cols, int32_t n_out_cols,
+                       int64_t *n_groups_out) {
+  Ctx &c = g_ctx;
+  Plan &P = L.P;
+  const int64_t n = P.n_rows;
+  if ((int)L.outs.size() != n_out_cols)
+    return fail(PLHIP_ERR_SHAPE_MISMATCH, "the query has " + std::to_string(L.outs.size()) + " output columns, the caller passed " + std::to_string(n_out_cols));
+  int64_t cap_rows = INT64_MAX;
+  for (int i = 0; i < n_out_cols; i++) {
+    const plhip_column_t &oc = out_cols[i];
+    const OutSpec &o = L.outs[i];
+    if (oc.location != PLHIP_DEVICE || oc.offset != 0 || oc.length < 0 || (oc.length > 0 && !oc.values))
+      return fail(PLHIP_ERR_INVALID, "output columns must be device buffers (offset 0, length = capacity in rows)");
+    if (oc.dtype != (int32_t)o.dtype) return fail(PLHIP_ERR_SHAPE_MISMATCH, "output column " + std::to_string(i) + " has the wrong dtype");
+    if (o.validity && !oc.validity) return fail(PLHIP_ERR_INVALID, "output column " + std::to_string(i) + " can hold nulls: it needs a validity bitmap");
+    cap_rows = std::min<int64_t>(cap_rows, oc.length);
+  }
+  if (n == 0) { *n_groups_out = 0; return PLHIP_OK; }
+  order_accs_by_source(L);
+  const int key_bytes = packed_key_bytes(P, dk);
+  int keymode = 0;
+  uint64_t kxor = 0;
+  if (!dk[0].validity) {
+    const int w = dtype_width(dk[0].dtype);
+    if (w == 4) { keymode = 1; kxor = dk[0].dtype == PLHIP_I32 ? 0x80000000ull : 0ull; }
+    if (w == 8) { keymode = 2; kxor = dk[0].dtype == PLHIP_I64 ? 0x8000000000000000ull : 0ull; }
+  }
+  const uint64_t g_est = (uint64_t)std::max<int64_t>(1, std::min<int64_t>(groups_hint, n));
+  const DirectShape DS = plan_direct(P, g_est, key_bytes, n, plhip_num_cus());
+  if (!DS.ok) return fail(PLHIP_ERR_INVALID, "plhip_group_by_agg_noalloc: " + std::to_string(g_est) + " groups do not fit one LDS table (the DIRECT strategy); use plhip_group_by_agg_opts");
+  const uint32_t lslots = (1u << DS.lbits) + 66;
+  // scratch layout: flag block | dump headers | dumps
+  DumpRef D{};
+  D.cap = lslots;
+  D.item_stride = fast_dump_stride(P, lslots, key_bytes);
+  const size_t off_hdr = FLAGS_BYTES, off_dump = (off_hdr + (size_t)DS.n_items * sizeof(DumpHdr) + 255) & ~(size_t)255;
+  const size_t need = off_dump + (size_t)D.item_stride * DS.n_items + 256;
+  if (need > (size_t)PLHIP_NOALLOC_SCRATCH_BYTES)
+    return fail(PLHIP_ERR_INVALID, "plhip_group_by_agg_noalloc: the query needs " + std::to_string(need) + " bytes of scratch, the static buffer holds " +
+                                       std::to_string((size_t)PLHIP_NOALLOC_SCRATCH_BYTES) + "; use plhip_group_by_agg_opts");
+  uint8_t *sp = c.na_scratch; // the device address (hipGetSymbolAddress), never the array's name
+  uint32_t *dflags = (uint32_t *)sp;
+  D.hdr = (DumpHdr *)(sp + off_hdr);
+  D.base = sp + off_dump;
+  const uint64_t out_cap = (uint64_t)std::min<int64_t>(cap_rows, (int64_t)((uint64_t)lslots << DS.mbits));
+  (void)hipGetLastError();
+  // the array keeps the last call's contents: what must start at zero is cleared here (the dumps and their headers
+  // are written whole by k_fold_rows before k_merge_emit reads them)
+  HIP_TRY(hipMemsetAsync(dflags, 0, 64, c.stream));
+  OutPlan OP{};
+  OP.n_outs = n_out_cols;
+  for (int i = 0; i < n_out_cols; i++) {
+    OutSpec o = L.outs[i];
+    o.values = (uint8_t *)out_cols[i].values;
+    o.validity = o.validity ? (uint8_t *)out_cols[i].validity : nullptr;
+    if (o.validity) HIP_TRY(hipMemsetAsync(o.validity, 0, (size_t)(out_cols[i].length / 64 + 1) * 8, c.stream));
+    OP.outs[i] = o;
+  }
+  if (++c.seq == 0) c.seq = 1;
+  const uint32_t seq = c.seq;
+  bool quad = true;
+  auto aligned = [](const uint8_t *p, int wd) { return ((uintptr_t)p % (size_t)(4 * wd)) == 0; };
+  if (keymode && !aligned(dk[0].values, dtype_width(dk[0].dtype))) quad = false;
+  for (int v = 0; v < P.n_vals; v++) if (!aligned(P.vals[v].values, dtype_width((int)P.vals[v].dtype))) quad = false;
+  hipEventRecord(c.ev[1], c.stream);
+  FoldRowsArgs A{};
+  A.D = D; A.flags = dflags; A.rows_per_item = DS.rows_per_item; A.kxor = kxor; A.lbits = DS.lbits; A.keymode = keymode; A.mbits = DS.mbits;
+  launch_fold_rows(P, A, key_bytes, quad, DS.n_items, DS.block, c.stream);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail_hip(e, "k_fold_rows launch");
+  hipEventRecord(c.ev[5], c.stream);
+  MergeArgs M{};
+  M.D = D; M.flags = dflags; M.out_cap = out_cap; M.lbits = DS.lbits; M.S = DS.n_items; M.mbits = DS.mbits; M.pshift = 0u;
+  M.host_sig = c.host_sig_dev; M.seq = seq;
+  launch_merge_emit(P, M, OP, key_bytes, 1u, 1024, c.stream);
+  if ((e = hipGetLastError()) != hipSuccess) return fail_hip(e, "k_merge_emit launch");
+  hipEventRecord(c.ev[2], c.stream);
+  uint32_t fl[16] = {0};
+  TableRef t{nullptr, 0, dflags};
+  const int rc = wait_signal(t, seq, fl);
+  c.flags_clean = false;
+  if (rc) return rc;
+  c.timing_pending = 1;
+  c.strategy = "direct";
+  if (fl[FLAG_OVERFLOW])
+    return fail(PLHIP_ERR_COMPUTE, "plhip_group_by_agg_noalloc: more groups than n_groups_hint promised, or than the output buffers hold");
+  *n_groups_out = (int64_t)fl[FLAG_NGROUPS];
+  return PLHIP_OK;
+}
 
 // Two partition levels (DESIGN.md "TILESORT2"): more groups than 512 LDS tables hold.  Level 1 = the radix
 // partition of the general path (k_part_hist / scan / plan / scatter) into tile-aligned, partition-contiguous
@@ -1476,6 +1610,41 @@ int32_t plhip_group_by_agg_opts(const plhip_column_t *keys, int32_t n_keys, cons
     R->n_rows = (int64_t)count;
   }
   return rc;
+}
+
+int32_t plhip_group_by_agg_noalloc(const plhip_column_t *keys, int32_t n_keys, const plhip_column_t *values, int32_t n_values,
+                                   const plhip_agg_t *aggs, int32_t n_aggs, uint32_t flags, int64_t n_groups_hint,
+                                   const plhip_column_t *out_cols, int32_t n_out_cols, int64_t *n_groups) {
+  if (!n_groups || !out_cols) return fail(PLHIP_ERR_INVALID, "NULL pointer");
+  *n_groups = 0;
+  if (n_keys != 1 || !keys) return fail(PLHIP_ERR_INVALID, "plhip_group_by_agg_noalloc takes exactly one key column");
+  if (n_values < 0 || n_values > PLHIP_MAX_VALS || (n_values > 0 && !values)) return fail(PLHIP_ERR_INVALID, "bad value columns");
+  if (n_aggs < 0 || (n_aggs > 0 && !aggs)) return fail(PLHIP_ERR_INVALID, "bad aggregation list");
+  if (flags & ~(uint32_t)PLHIP_FLAG_PARTIAL) return fail(PLHIP_ERR_INVALID, "plhip_group_by_agg_noalloc accepts PLHIP_FLAG_PARTIAL only");
+  if (n_groups_hint < 1) return fail(PLHIP_ERR_INVALID, "plhip_group_by_agg_noalloc needs n_groups_hint (an upper bound on the groups): sampling would allocate");
+  const int64_t n = keys[0].length;
+  for (int i = 0; i < n_values; i++)
+    if (values[i].length != n) return fail(PLHIP_ERR_SHAPE_MISMATCH, "series used as keys should have the same length as the dataframe");
+  if (n > 0xFFFFFFFFll) return fail(PLHIP_ERR_COMPUTE, "more than u32::MAX rows (IdxSize is u32)");
+  if (keys[0].location != PLHIP_DEVICE) return fail(PLHIP_ERR_INVALID, "plhip_group_by_agg_noalloc takes device-resident columns (staging would allocate)");
+  for (int i = 0; i < n_values; i++)
+    if (values[i].location != PLHIP_DEVICE) return fail(PLHIP_ERR_INVALID, "plhip_group_by_agg_noalloc takes device-resident columns (staging would allocate)");
+  Ctx &c = g_ctx;
+  // the stream, the pinned signal word and the scratch address are set up by plhip_init: nothing is created here
+  if (c.device < 0 || !c.na_scratch) return fail(PLHIP_ERR_INVALID, "plhip_group_by_agg_noalloc: call plhip_init on this thread first");
+  HIP_TRY(hipSetDevice(c.device));
+  resolve_timing();
+  Staging st; // (device columns: nothing is staged, nothing owned)
+  std::vector<DevCol> dk(1), dv(n_values);
+  int rc;
+  if ((rc = stage_column(keys[0], dk[0], st, c.stream))) return rc;
+  for (int i = 0; i < n_values; i++) if ((rc = stage_column(values[i], dv[i], st, c.stream))) return rc;
+  Lowered L{};
+  L.P.n_rows = n;
+  L.n_out_keys = 1;
+  if ((rc = build_keys(L.P, dk, st, L.KG))) return rc; // single key: no measuring pass, no allocation
+  if ((rc = build_aggs(L, dv, aggs, n_aggs, flags))) return rc;
+  return run_direct_noalloc(L, dk, n_groups_hint, out_cols, n_out_cols, n_groups);
 }
 
 int32_t group_by_agg_impl(const plhip_column_t *keys, int32_t n_keys, const plhip_column_t *values,
