@@ -137,6 +137,7 @@ def main():
     ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default 1e7; c3: 1e8)")
     ap.add_argument("--strategy", default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dense", action="store_true", help="do not declare a single Categorical key's codes dense (PLHIP_FLAG_KEYS_DENSE)")
     ap.add_argument("--no-hint", action="store_true",
                     help="do not pass the category count of categorical keys (id1..id3) as n_groups_hint")
     args = ap.parse_args()
@@ -164,7 +165,7 @@ def main():
     keys_n, vals_n, aggs, wide = wl
     n = args.rows or (100_000_000 if args.workload == "c3" else 10_000_000)
     tensors = h2oai.generate(n, seed=108 + rank, device=dev, wide=wide, columns=keys_n + vals_n)
-    cols = h2oai.to_columns(tensors, wide)
+    cols = h2oai.to_columns(tensors, wide, n=n)
     keys = [cols[k] for k in keys_n]
     vals = [cols[v] for v in vals_n]
     agg_codes = [(ci, _ffi.AGG_NAMES[kind]) for ci, kind in aggs]
@@ -178,6 +179,8 @@ def main():
         for k in keys_n:
             hint *= 100 if k in ("id1", "id2") else max(n // 100, 1)
         hint = min(hint, n)
+    # a single Categorical key: its codes index the tables directly (group_tuples_perfect, perfect.rs:190-227)
+    qflags = _ffi.FLAG_KEYS_DENSE if (hint and len(keys) == 1 and keys[0].n_categories is not None and not args.no_dense) else 0
 
     if world > 1 or rehearse:
         from polars_amd import distributed as pdist
@@ -193,13 +196,13 @@ def main():
         varr = (_ffi.ColumnStruct * len(vals))(*[v.struct() for v in vals])
         aarr = (_ffi.AggStruct * len(agg_codes))(*[_ffi.AggStruct(c, k) for c, k in agg_codes])
         opts = _ffi.OptionsStruct(C.sizeof(_ffi.OptionsStruct), int(hint))
-        handle0, out_cols = pa.group_by_agg_raw(keys, vals, agg_codes, _ffi.FLAG_OUTPUT_DEVICE, hint)
+        handle0, out_cols = pa.group_by_agg_raw(keys, vals, agg_codes, _ffi.FLAG_OUTPUT_DEVICE | qflags, hint)
         widths = [_ffi.code_np_dtype(cs.dtype).itemsize for cs in out_cols]
         L.plhip_result_free(handle0)
 
         def step():
             handle = C.c_void_p()
-            _ffi.check(L.plhip_group_by_agg_opts(karr, len(keys), varr, len(vals), aarr, len(agg_codes), _ffi.FLAG_OUTPUT_DEVICE,
+            _ffi.check(L.plhip_group_by_agg_opts(karr, len(keys), varr, len(vals), aarr, len(agg_codes), _ffi.FLAG_OUTPUT_DEVICE | qflags,
                                                  C.byref(opts), C.byref(handle)))
             g = L.plhip_result_num_rows(handle)  # the result frame stays in HBM; its row count is on the host
             L.plhip_result_free(handle)
@@ -269,7 +272,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             def gpu_frame():  # the timed configuration once more, result copied to the host
-                handle, out = pa.group_by_agg_raw(keys, vals, agg_codes, 0, hint)
+                handle, out = pa.group_by_agg_raw(keys, vals, agg_codes, qflags, hint)
                 try:
                     fr = []
                     for cs in out:

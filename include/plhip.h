@@ -120,6 +120,15 @@ typedef struct plhip_agg {
                                         trusts the flag: unsorted input yields one output row per run.  Ignored
                                         with more than one key. */
 
+#define PLHIP_FLAG_KEYS_DENSE 16u    /* the (single, u32) key column holds the physical codes of a Categorical with a local
+                                        rev-map: every valid code is < plhip_options_t::n_groups_hint (the rev-map's
+                                        length).  The codes then index the tables directly -- no hashing, no probing, the
+                                        null key in the last slot -- as group_tuples_perfect does (crates/polars-core/src/
+                                        frame/group_by/perfect.rs:24-185, 190-227; taken for Categorical keys,
+                                        into_groups.rs via CategoricalChunked::group_tuples_perfect).  Codes that never
+                                        occur produce no group.  A code outside the promise costs time, never
+                                        correctness: the hashed strategies redo the query. */
+
 /* strategy override, PLHIP_STRATEGY env var or plhip_set_strategy(): mirrors the reference's
  * POLARS_NO_PARTITION / POLARS_FORCE_PARTITION switches
  * (crates/polars-lazy/src/physical_plan/executors/group_by_partitioned.rs:167-186). */
@@ -134,8 +143,11 @@ typedef enum plhip_strategy {
                                     falls back to the strategies above otherwise */
   PLHIP_STRATEGY_SORT = 6,       /* radix sort of (packed key, row), run boundaries, one fold per run: any number of
                                     groups up to all-unique keys, immune to skew */
-  PLHIP_STRATEGY_TILESORT2 = 7   /* two partition levels (radix partition, then the tile sort inside every partition),
+  PLHIP_STRATEGY_TILESORT2 = 7,  /* two partition levels (radix partition, then the tile sort inside every partition),
                                     one LDS table per leaf: more groups than TILESORT's 512 tables hold */
+  PLHIP_STRATEGY_DENSE = 8       /* dense Categorical codes (PLHIP_FLAG_KEYS_DENSE) index LDS tables directly: code ranges x
+                                    row slices, one pass over the rows, no exchange; AUTO takes it whenever the flag is set
+                                    and the tables fit (<= 8 code ranges of one CU's LDS) */
 } plhip_strategy_t;
 
 /* Optional knowledge the caller has about the query.  struct_size = sizeof(plhip_options_t). */

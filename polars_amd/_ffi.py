@@ -33,8 +33,9 @@ FLAG_MAINTAIN_ORDER = 1
 FLAG_OUTPUT_DEVICE = 2
 FLAG_KEYS_SORTED = 8
 FLAG_PARTIAL = 4
+FLAG_KEYS_DENSE = 16
 
-STRATEGIES = {"auto": 0, "global": 1, "lds": 2, "partitioned": 3, "direct": 4, "tilesort": 5, "sort": 6, "tilesort2": 7}
+STRATEGIES = {"auto": 0, "global": 1, "lds": 2, "partitioned": 3, "direct": 4, "tilesort": 5, "sort": 6, "tilesort2": 7, "dense": 8}
 
 STATUS_NAMES = {
     0: "OK", 1: "ComputeError", 2: "ShapeMismatch", 3: "OutOfMemory", 4: "UnsupportedDtype", 5: "HipError",

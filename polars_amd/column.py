@@ -55,6 +55,7 @@ class Column:
                  dtype: int | None = None, packed: bool = False):
         self.name = name
         self.sorted_flag = None  # 'ascending' | 'descending': see set_sorted
+        self.n_categories = None  # see set_categories
         if _is_torch(values):
             if values.dim() != 1 or not values.is_contiguous():
                 raise _ffi.PlHipError(6, "column buffers must be 1-D and contiguous")
@@ -111,6 +112,16 @@ class Column:
         single group-by key with the flag takes the sorted fast path (into_groups.rs:142-150).  Like the
         reference, nobody checks the claim."""
         self.sorted_flag = "descending" if descending else "ascending"
+        return self
+
+    def set_categories(self, n_categories: int) -> "Column":
+        """Declares the column the physical u32 codes of a Categorical with a local rev-map of `n_categories` entries:
+        every valid code is < n_categories.  A single group-by key with this knowledge takes the dense-code path, the
+        counterpart of group_tuples_perfect (crates/polars-core/src/frame/group_by/perfect.rs:190-227).  A code outside
+        the promise costs time, never correctness."""
+        if self.dtype != _ffi.U32:
+            raise _ffi.PlHipError(4, "categorical codes are u32")
+        self.n_categories = int(n_categories)
         return self
 
     def struct(self) -> _ffi.ColumnStruct:

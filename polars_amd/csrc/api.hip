@@ -11,11 +11,13 @@
 #include <cstdlib>
 #include <cstddef>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
 
 #include "../../include/plhip.h"
+#include "dense.hpp"
 #include "fast.hpp"
 #include "kernels.hpp"
 
@@ -508,6 +510,7 @@ int env_strategy() {
   if (!strcmp(e, "tilesort")) return PLHIP_STRATEGY_TILESORT;
   if (!strcmp(e, "sort")) return PLHIP_STRATEGY_SORT;
   if (!strcmp(e, "tilesort2")) return PLHIP_STRATEGY_TILESORT2;
+  if (!strcmp(e, "dense")) return PLHIP_STRATEGY_DENSE;
   return PLHIP_STRATEGY_AUTO;
 }
 
@@ -566,7 +569,8 @@ int wait_signal(TableRef t, uint32_t seq, uint32_t *out8) {
 void resolve_timing() {
   Ctx &c = g_ctx;
   if (!c.timing_pending) return;
-  const bool direct = c.timing_pending == 1, merged = c.timing_pending != 2;
+  const bool dense = c.timing_pending == 4;
+  const bool direct = c.timing_pending == 1 || dense, merged = c.timing_pending != 2;
   c.timing_pending = 0;
   if (hipEventSynchronize(merged ? c.ev[2] : c.ev[5]) != hipSuccess) { (void)hipGetLastError(); return; }
   hipEventElapsedTime(&c.total_ms, c.ev[1], merged ? c.ev[2] : c.ev[5]);
@@ -574,7 +578,7 @@ void resolve_timing() {
   if (!direct) hipEventElapsedTime(&c.k_ms[0], c.ev[1], c.ev[4]);
   hipEventElapsedTime(&c.k_ms[1], direct ? c.ev[1] : c.ev[4], c.ev[5]);
   if (merged) hipEventElapsedTime(&c.k_ms[2], c.ev[5], c.ev[2]);
-  const char *names[3] = {"k_tile_sort", direct ? "k_fold_rows" : "k_fold_runs", "k_merge_emit"};
+  const char *names[3] = {"k_tile_sort", dense ? "k_dense_fold" : (direct ? "k_fold_rows" : "k_fold_runs"), dense ? "k_dense_merge" : "k_merge_emit"};
   int dom = 0;
   for (int i = 1; i < 3; i++) if (c.k_ms[i] > c.k_ms[dom]) dom = i;
   c.dom_ms = c.k_ms[dom]; c.dom_kernel = names[dom]; c.part_ms = c.k_ms[0]; c.agg_ms = c.k_ms[1];
@@ -1175,6 +1179,205 @@ int run_direct_noalloc(Lowered &L, const std::vector<DevCol> &dk, int64_t groups
   return PLHIP_OK;
 }
 
+// The dense-code path (dense_path.hip, dense.hpp): group_tuples_perfect's idea (crates/polars-core/src/frame/group_by/perfect.rs:
+// 24-185, 190-227) -- a Categorical key's physical codes ARE the group indices -- on LDS tables.  Taken when the caller
+// declares the single u32 key column dense (PLHIP_FLAG_KEYS_DENSE: codes < n_groups_hint = the rev-map's length).  A code
+// outside the promise raises the overflow flag and the hashed strategies redo the query: time, never correctness.
+int run_dense(const Lowered &L0, const std::vector<DevCol> &dk, uint32_t flags, int64_t groups_hint, bool forced, plhip_result_t **out, bool &handled) {
+  handled = false;
+  Ctx &c = g_ctx;
+  const int64_t n = L0.P.n_rows;
+  if ((flags & PLHIP_FLAG_MAINTAIN_ORDER) || L0.KG.enabled || L0.first_acc >= 0) return PLHIP_OK;
+  if (!L0.P.single_key || dk[0].dtype != PLHIP_U32 || groups_hint < 1 || groups_hint > 0x7FFFFFF0ll) return PLHIP_OK;
+  if (n < 1 || (!forced && n < (1 << 15))) return PLHIP_OK;
+  if (((uintptr_t)dk[0].values & 15u) != 0) return PLHIP_OK; // the row loop reads aligned quads
+  for (int v = 0; v < L0.P.n_vals; v++)
+    if (((uintptr_t)L0.P.vals[v].values % (size_t)(4 * dtype_width((int)L0.P.vals[v].dtype))) != 0) return PLHIP_OK;
+  Lowered L = L0; // (a count is added below: the hashed strategies keep the query as it was lowered)
+  Plan &P = L.P;
+  const int cnt_acc = add_acc(P, ACC_CNT_ALL, CONV_NONE, -1, 4, 0); // a code that never occurs is not a group
+  if (cnt_acc < 0) return PLHIP_OK;
+  order_accs_by_source(L);
+  DenseArgs A{};
+  A.hint = (uint32_t)groups_hint; A.n_slots = A.hint + 1u;
+  // ---- parts: one per value column; the group count rides with the cheapest one ----------------------------------
+  int part_of_val[PLHIP_MAX_VALS];
+  for (int v = 0; v < P.n_vals; v++) part_of_val[v] = -1;
+  uint32_t row_bytes[DENSE_MAX_PARTS] = {0};
+  bool has_valued_acc = false;
+  for (int a = 0; a < P.n_accs; a++) {
+    const int src = P.accs[a].src;
+    if (src < 0) continue;
+    has_valued_acc = true;
+    if (part_of_val[src] < 0) {
+      if (A.n_parts >= DENSE_MAX_PARTS) return PLHIP_OK;
+      part_of_val[src] = (int)A.n_parts;
+      A.part[A.n_parts].src = src;
+      row_bytes[A.n_parts] = 4u + (uint32_t)dtype_width((int)P.vals[src].dtype);
+      A.n_parts++;
+    }
+  }
+  if (!has_valued_acc) { A.part[0].src = -1; row_bytes[0] = 4u; A.n_parts = 1; }
+  int cheapest = 0;
+  for (uint32_t p = 1; p < A.n_parts; p++) if (row_bytes[p] < row_bytes[cheapest]) cheapest = (int)p;
+  auto narrow32 = [&](int a) { // an integer sum may live in 32 bits when every output that reads it wraps in 32 bits anyway
+    if (P.accs[a].op != ACC_ADD_U64) return false;
+    bool used = false;
+    for (auto &o : L.outs) {
+      if (o.kind == OUT_KEY) continue;
+      if (o.acc == a) { used = true; if (o.kind != OUT_SUM_INT || dtype_width((int)o.dtype) != 4) return false; }
+    }
+    return used;
+  };
+  for (int a = 0; a < P.n_accs; a++) {
+    const int src = P.accs[a].src;
+    const uint32_t op = P.accs[a].op;
+    if (op == ACC_FIRST_ROW) return PLHIP_OK;
+    DensePart &D = A.part[src < 0 ? cheapest : part_of_val[src]];
+    if (D.n_accs >= DENSE_MAX_PART_ACCS) return PLHIP_OK;
+    D.acc[D.n_accs] = (uint8_t)a;
+    D.lw[D.n_accs] = (op == ACC_CNT_ALL || op == ACC_CNT_VALID || narrow32(a)) ? 4 : 8;
+    D.n_accs++;
+  }
+  A.cnt_acc = 0;
+  for (int a = 0; a < P.n_accs; a++) if (P.accs[a].op == ACC_CNT_ALL) A.cnt_acc = (uint32_t)a;
+  // ---- ranges: the largest part's arrays cut into pieces of one CU's LDS ------------------------------------------
+  const size_t LDS_CAP = 160 * 1024 - 512;
+  uint32_t state_max = 0;
+  for (uint32_t p = 0; p < A.n_parts; p++) {
+    uint32_t st = 0;
+    for (uint32_t i = 0; i < A.part[p].n_accs; i++) st += A.part[p].lw[i];
+    state_max = std::max(state_max, st);
+  }
+  const char *dbg_r = getenv("PLHIP_DENSE_R");
+  uint32_t R = (uint32_t)(((uint64_t)A.n_slots * state_max + LDS_CAP - 1) / LDS_CAP);
+  if (dbg_r) R = std::max<uint32_t>(R, (uint32_t)atoi(dbg_r));
+  for (;; R++) {
+    if (R > DENSE_MAX_RANGES) return PLHIP_OK; // too many groups: every row would be read R times
+    A.gpr = (((A.n_slots + R - 1) / R) + 3u) & ~3u;
+    if ((uint64_t)A.gpr * state_max + 16 * DENSE_MAX_PART_ACCS <= LDS_CAP && (uint64_t)(R - 1) * A.gpr < A.n_slots) break;
+    if ((uint64_t)(R - 1) * A.gpr >= A.n_slots && (uint64_t)A.gpr * state_max + 16 * DENSE_MAX_PART_ACCS <= LDS_CAP) { R = (A.n_slots + A.gpr - 1) / A.gpr; break; }
+  }
+  A.R = R;
+  // a handful of groups in ONE range: the hashed DIRECT strategy is as fast there (one LDS table either way) and its merge is
+  // cheaper than adding up a partial array per workgroup (measured, q1 at 1e7 rows: 0.062 against 0.070 ms per query)
+  if (!forced && R == 1 && A.n_slots <= 4096) return PLHIP_OK;
+  size_t lds_bytes = 0;
+  for (uint32_t p = 0; p < A.n_parts; p++) {
+    DensePart &D = A.part[p];
+    uint32_t lo = 0;
+    uint64_t dof = 0;
+    for (uint32_t i = 0; i < D.n_accs; i++) {
+      D.loff[i] = lo; lo += (A.gpr * D.lw[i] + 15u) & ~15u;
+      D.doff[i] = (uint32_t)dof; dof += ((uint64_t)R * A.gpr * D.lw[i] + 15u) & ~15ull;
+    }
+    if (dof > 0xFFFFFFFFull) return PLHIP_OK;
+    D.slice_stride = (dof + 255) & ~255ull;
+    lds_bytes = std::max<size_t>(lds_bytes, lo);
+    // straight-line kinds (no validity on the value column)
+    D.kind = DENSE_KIND_RT;
+    if (D.src >= 0 && !P.vals[D.src].validity) {
+      const uint32_t vd = P.vals[D.src].dtype;
+      const bool i4 = vd == PLHIP_I32 || vd == PLHIP_U32;
+      auto is = [&](uint32_t i, uint32_t op, uint32_t lw) { return P.accs[D.acc[i]].op == op && D.lw[i] == lw; };
+      if (i4 && D.n_accs == 2 && is(0, ACC_CNT_ALL, 4) && is(1, ACC_ADD_U64, 4)) D.kind = DENSE_KIND_CNT_SUM32;
+      else if (i4 && D.n_accs == 1 && is(0, ACC_ADD_U64, 4)) D.kind = DENSE_KIND_SUM32;
+      else if (vd == PLHIP_F64 && D.n_accs == 1 && is(0, ACC_ADD_F64, 8)) D.kind = DENSE_KIND_SUMF64;
+    }
+  }
+  if (lds_bytes > LDS_CAP) return PLHIP_OK;
+  // ---- workgroups: per XCD `slots` of them, cut into groups of R (the R ranges of one row slice) ------------------
+  const int cus = plhip_num_cus();
+  A.xcds = 8;
+  const uint32_t wg_per_cu = lds_bytes <= 76 * 1024 ? 2u : 1u;
+  const char *dbg_slots = getenv("PLHIP_DENSE_SLOTS");
+  const uint32_t slots = dbg_slots ? (uint32_t)atoi(dbg_slots) : (uint32_t)std::max(1, cus / 8) * wg_per_cu;
+  // group slots: every XCD lane holds slots / R of them; they are dealt to the parts in proportion to the bytes a part
+  // reads per row, so that every workgroup streams about the same number of bytes
+  const uint32_t n_gs = (slots / R) * A.xcds;
+  if (n_gs < A.n_parts) return PLHIP_OK;
+  uint32_t nsl[DENSE_MAX_PARTS];
+  for (uint32_t p = 0; p < A.n_parts; p++) nsl[p] = 1;
+  if (getenv("PLHIP_DENSE_EQ")) for (uint32_t p = 0; p < A.n_parts; p++) row_bytes[p] = 8;
+  for (uint32_t gi = A.n_parts; gi < n_gs; gi++) { // the next slot goes to the part with the most bytes per slice
+    uint32_t best = 0;
+    for (uint32_t p = 1; p < A.n_parts; p++)
+      if ((uint64_t)row_bytes[p] * nsl[best] > (uint64_t)row_bytes[best] * nsl[p]) best = p;
+    nsl[best]++;
+  }
+  // small inputs: no more slices than whole batches
+  const int64_t batches = (n + DENSE_BATCH - 1) / DENSE_BATCH;
+  uint32_t slot = 0;
+  uint64_t dump_bytes = 0;
+  for (uint32_t p = 0; p < A.n_parts; p++) {
+    DensePart &D = A.part[p];
+    D.n_slices = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(nsl[p], batches));
+    D.slot0 = slot;
+    slot += D.n_slices;
+    const int64_t per = (n + D.n_slices - 1) / D.n_slices;
+    D.rows_per_slice = (per + DENSE_BATCH - 1) / DENSE_BATCH * DENSE_BATCH;
+    if ((uint64_t)D.rows_per_slice * 8u >= 0xFFFFFFFFull) return PLHIP_OK; // the row loop addresses a slice with 32-bit byte offsets
+    D.dump_off = dump_bytes;
+    dump_bytes += D.slice_stride * D.n_slices;
+  }
+  const uint32_t q = ((slot + A.xcds - 1) / A.xcds) * R; // positions per XCD lane
+  const uint32_t n_wgs = q * A.xcds;
+  HIP_TRY(c.dump.reserve(dump_bytes + 256));
+  HIP_TRY(c.flags.reserve(FLAGS_BYTES));
+  A.dump = (uint8_t *)c.dump.p;
+  uint32_t *dflags = (uint32_t *)c.flags.p;
+  A.flags = dflags;
+  const uint64_t out_cap = A.n_slots;
+  // ---- outputs --------------------------------------------------------------------------------------------------
+  std::unique_ptr<plhip_result> R_(new (std::nothrow) plhip_result());
+  if (!R_) return fail(PLHIP_ERR_OOM, "host allocation failed");
+  R_->on_device = true; R_->device = c.device;
+  OutPlan OP{};
+  OP.n_outs = (int)L.outs.size();
+  (void)hipGetLastError();
+  if (!c.flags_clean) HIP_TRY(hipMemsetAsync(dflags, 0, 64, c.stream));
+  c.flags_clean = false;
+  for (size_t i = 0; i < L.outs.size(); i++) {
+    OutSpec o = L.outs[i];
+    ResultCol col;
+    col.dtype = (int)o.dtype;
+    hipError_t e = g_pool.get((size_t)out_cap * dtype_width((int)o.dtype), &col.values, &col.vcap);
+    if (e == hipSuccess && o.validity) {
+      e = g_pool.get((size_t)(out_cap / 64 + 2) * 8, (void **)&col.validity, &col.bcap);
+      if (e == hipSuccess) e = hipMemsetAsync(col.validity, 0, (size_t)(out_cap / 64 + 2) * 8, c.stream);
+    }
+    R_->cols.push_back(col);
+    if (e != hipSuccess) return fail_hip(e, "hipMalloc(output)");
+    o.values = (uint8_t *)col.values; o.validity = col.validity;
+    OP.outs[i] = o;
+  }
+  if (++c.seq == 0) c.seq = 1;
+  const uint32_t seq = c.seq;
+  hipEventRecord(c.ev[1], c.stream);
+  launch_dense_fold(P, A, n_wgs, lds_bytes, c.stream);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail_hip(e, "k_dense_fold launch");
+  hipEventRecord(c.ev[5], c.stream);
+  launch_dense_merge(P, A, OP, out_cap, c.host_sig_dev, seq, c.stream);
+  if ((e = hipGetLastError()) != hipSuccess) return fail_hip(e, "k_dense_merge launch");
+  hipEventRecord(c.ev[2], c.stream);
+  uint32_t fl[16] = {0};
+  TableRef t{nullptr, 0, dflags};
+  const int rc = wait_signal(t, seq, fl);
+  if (rc) return rc;
+  if (hipMemsetAsync(dflags, 0, 64, c.stream) == hipSuccess) c.flags_clean = true;
+  c.timing_pending = 4;
+  c.strategy = "dense";
+  if (getenv("PLHIP_DENSE_VERBOSE"))
+    fprintf(stderr, "dense: parts %u R %u gpr %u lds %zu B wgs %u dump %llu B slices %u %u kinds %u %u\n", A.n_parts, R, A.gpr, lds_bytes, n_wgs,
+            (unsigned long long)dump_bytes, A.part[0].n_slices, A.part[1].n_slices, A.part[0].kind, A.part[1].kind);
+  if (fl[FLAG_OVERFLOW]) return PLHIP_OK; // a code outside the promise: the hashed path redoes the query
+  const uint64_t G = fl[FLAG_NGROUPS];
+  R_->n_rows = (int64_t)G;
+  handled = true;
+  return finish_result(R_.release(), G, flags, out);
+}
+
 // Two partition levels (DESIGN.md "TILESORT2"): more groups than 512 LDS tables hold.  Level 1 = the radix
 // partition of the general path (k_part_hist / scan / plan / scatter) into tile-aligned, partition-contiguous
 // copies; level 2 = the tile sort inside every level-1 partition on the next hash bits; then one LDS table per
@@ -1516,7 +1719,7 @@ int32_t plhip_init(int32_t device_id) {
 const char *plhip_last_error(void) { return g_ctx.err.c_str(); }
 
 int32_t plhip_set_strategy(int32_t strategy) {
-  if (strategy < 0 || strategy > PLHIP_STRATEGY_TILESORT2) return fail(PLHIP_ERR_INVALID, "bad strategy");
+  if (strategy < 0 || strategy > PLHIP_STRATEGY_DENSE) return fail(PLHIP_ERR_INVALID, "bad strategy");
   g_ctx.forced_strategy = strategy;
   return PLHIP_OK;
 }
@@ -1682,12 +1885,20 @@ int32_t group_by_agg_impl(const plhip_column_t *keys, int32_t n_keys, const plhi
   Plan &P = L.P;
 
   // ---- strategy ------------------------------------------------------------------------------------
-  int strategy = c.forced_strategy > 0 ? c.forced_strategy : env_strategy();
+  int strategy = c.forced_strategy >= 0 ? c.forced_strategy : env_strategy();
   if ((flags & PLHIP_FLAG_KEYS_SORTED) && n_keys == 1 && n > 0) { // into_groups.rs:142-150: the flag wins over every hash path
     bool handled = false;
     if ((rc = run_sorted(L, dk, flags, out, handled, true))) return rc;
     if (handled) return PLHIP_OK;
   }
+  if ((flags & PLHIP_FLAG_KEYS_DENSE) && (strategy == PLHIP_STRATEGY_AUTO || strategy == PLHIP_STRATEGY_DENSE)) {
+    int64_t hint = 0;
+    if (opts && opts->struct_size >= offsetof(plhip_options_t, n_groups_hint) + sizeof(int64_t)) hint = opts->n_groups_hint;
+    bool handled = false;
+    if ((rc = run_dense(L, dk, flags, hint, strategy == PLHIP_STRATEGY_DENSE, out, handled))) return rc;
+    if (handled) return PLHIP_OK;
+  }
+  if (strategy == PLHIP_STRATEGY_DENSE) strategy = PLHIP_STRATEGY_AUTO; // (not declared dense, or declined: the hashed strategies)
   if (strategy == PLHIP_STRATEGY_AUTO || strategy == PLHIP_STRATEGY_DIRECT || strategy == PLHIP_STRATEGY_TILESORT) {
     int64_t hint = 0;
     if (opts && opts->struct_size >= offsetof(plhip_options_t, n_groups_hint) + sizeof(int64_t)) hint = opts->n_groups_hint;

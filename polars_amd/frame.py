@@ -312,7 +312,8 @@ class _LazyAgg:
 # the one place that calls the C ABI
 # ---------------------------------------------------------------------------------------------------
 def set_strategy(name: str) -> None:
-    """'auto' | 'global' | 'lds' | 'partitioned' (POLARS_FORCE_PARTITION / POLARS_NO_PARTITION analogue)."""
+    """'auto' | 'global' | 'lds' | 'partitioned' | 'direct' | 'tilesort' | 'tilesort2' | 'sort' | 'dense'
+    (POLARS_FORCE_PARTITION / POLARS_NO_PARTITION analogue)."""
     _ffi.check(_ffi.lib().plhip_set_strategy(_ffi.STRATEGIES[name]))
 
 
@@ -396,7 +397,11 @@ def _execute(df: DataFrame, by: list[str], exprs: list[Expr], maintain_order: bo
     flags = (_ffi.FLAG_MAINTAIN_ORDER if maintain_order else 0) | extra_flags
     if len(keys) == 1 and keys[0].sorted_flag is not None:  # IsSorted flag on the key: the sorted fast path
         flags |= _ffi.FLAG_KEYS_SORTED
-    handle, cols = group_by_agg_raw(keys, vals, aggs, flags, slice_=slice_)
+    hint = 0
+    if len(keys) == 1 and keys[0].n_categories is not None:  # a Categorical's codes: the dense-code path (perfect.rs:190-227)
+        flags |= _ffi.FLAG_KEYS_DENSE
+        hint = keys[0].n_categories
+    handle, cols = group_by_agg_raw(keys, vals, aggs, flags, hint, slice_=slice_)
     try:
         out = DataFrame([_host_column(nm, cs) for nm, cs in zip(names, cols)])
     finally:

@@ -41,13 +41,17 @@ def generate(n: int, k: int = 100, seed: int = 108, device="cuda:0", wide: bool 
     return out
 
 
-def to_columns(tensors: dict, wide: bool = False) -> dict[str, Column]:
-    """id1..id3 are categorical in the reference harness: their physical type is u32 (the i32 buffer is
-    passed with a u32 dtype code; codes are positive so the bits are identical)."""
+def to_columns(tensors: dict, wide: bool = False, k: int = 100, n: int | None = None) -> dict[str, Column]:
+    """id1..id3 are Categorical in the reference harness (run_h2oai_benchmark.py:21-35): what reaches the group-by is
+    their physical u32 code column plus the rev-map, whose length -- K, K, N/K categories -- the engine knows
+    without touching the data.  The codes are 0-based (`id - 1`, rewritten IN PLACE in `tensors` so that whoever
+    checks the result sees the same column; the i32 buffer is passed with a u32 dtype code, the bits are identical)."""
     cols = {}
     for name, t in tensors.items():
-        dt = None
         if not wide and name in ("id1", "id2", "id3"):
-            dt = _ffi.U32
-        cols[name] = Column(name, t, dtype=dt)
+            t.sub_(1)
+            ncat = k if name in ("id1", "id2") else max((n if n is not None else t.numel()) // k, 1)
+            cols[name] = Column(name, t, dtype=_ffi.U32).set_categories(ncat)
+        else:
+            cols[name] = Column(name, t)
     return cols
