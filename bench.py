@@ -1,13 +1,15 @@
 """bench.py — db-benchmark-shaped hash group-by on MI355X: rows/s + fraction of the HBM roofline.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload q3|q1|q5|c3] [--rows R]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload q3|q1|q5|c3|c5] [--rows R] [--total-rows T] [--na]
 
 A "step" is one pass of the hot path (plhip_group_by_agg_opts through the C ABI) over one batch of synthetic
 rows that is already resident in HBM, up to and including the device-resident result frame and its row count
 on the host.  Default workload = BASELINE.json configs[1]: db-benchmark q3, sum(v1), mean(v3) by id3,
-1e7 rows, 1e5 groups, one MI355X.  For N > 1 every rank holds its own shard of that size (weak scaling): local
-partial aggregation, ONE all-to-all of the partial records (RCCL), regroup on the owner rank
-(polars_amd/distributed.py).  Rank 0 prints ONE JSON line.
+1e7 rows, 1e5 groups, one MI355X.  Other workloads: q1 / q5 (configs[0], [1]), c3 (configs[2]: 1e8 rows, three i64
+keys, i64 sum/min/max + f64 sum/mean + count), c5 (configs[4]: 1e9 rows, 1e8 ids, skewed; see skewed_keys()).
+For N > 1 every rank holds its own shard (weak scaling: --rows per GPU; strong scaling = configs[3]: --total-rows T
+gives every rank T / N rows): local partial aggregation, ONE all-to-all of the partial records (RCCL), regroup on the
+owner rank (polars_amd/distributed.py).  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -27,7 +29,34 @@ WORKLOADS = {
     "q3": (["id3"], ["v1", "v3"], [(0, "sum"), (1, "mean")], False),
     "q5": (["id6"], ["v1", "v2", "v3"], [(0, "sum"), (1, "sum"), (2, "sum")], False),
     "c3": (["id1", "id2", "id3"], ["v1", "v3"], [(0, "sum"), (0, "min"), (0, "max"), (1, "sum"), (1, "mean"), (0, "count")], True),
+    # one skewed i64 key, f64 sum/mean + i64 sum/min/max + count
+    "c5": (["k"], ["v3", "v1"], [(0, "sum"), (0, "mean"), (1, "sum"), (1, "min"), (1, "max"), (0, "count")], True),
 }
+DEFAULT_ROWS = {"c3": 100_000_000, "c5": 1_000_000_000}
+C5_IDS_PER_ROW = 0.1  # 1e8 ids at 1e9 rows
+
+
+def skewed_keys(n, ids, seed, device):
+    """BASELINE config 5's keys (the exact sampler): with probability 1/2 a Zipf(s = 1.1) draw by inverse CDF,
+    X = floor(U^(-1/(s-1))) = floor(U^-10) (P(X >= k) = k^-0.1: the top key holds ~6.7 % of these draws), folded onto the
+    ids as (X - 1) mod ids; otherwise a uniform id, so that (nearly) every id occurs.  torch.Generator(seed) on the
+    device: u (f64) for the Zipf draw, a f32 coin, u (f64) for the uniform id, then v3 (f64 uniform * 100) and v1
+    (int64 in 1..5), in this order."""
+    import torch
+
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    u = torch.rand(n, device=device, dtype=torch.float64, generator=g).clamp_min(1e-300)
+    z = torch.floor(u.pow(-10.0)).clamp_max(float(ids) * 1e6)
+    del u
+    coin = torch.rand(n, device=device, generator=g) < 0.5
+    uni = torch.floor(torch.rand(n, device=device, dtype=torch.float64, generator=g) * ids)
+    k = torch.where(coin, (z - 1) % ids, uni).to(torch.int64)
+    del z, coin, uni
+    v3 = torch.rand(n, device=device, dtype=torch.float64, generator=g) * 100
+    v1 = torch.randint(1, 6, (n,), device=device, dtype=torch.int64, generator=g)
+    return {"k": k, "v3": v3, "v1": v1}
+
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy kernel reaches
 
 
@@ -43,41 +72,91 @@ def algorithmic_bytes(n_rows, n_groups, key_cols, val_cols, out_widths):
     return b
 
 
-def cpu_baseline(tensors, wl, wide, gpu_frame, budget_s=10.0):
+def _host_columns(cols):
+    """Device columns -> host columns (values + bool mask) for the oracle."""
+    import numpy as np
+
+    from polars_amd.column import Column
+
+    out = []
+    for c in cols:
+        a = c.to_numpy()
+        out.append(Column(c.name, np.ascontiguousarray(a), c.valid_mask()))
+    return out
+
+
+def cpu_baseline(tensors, keys, vals, aggs, gpu_frame, budget_s=10.0):
     """The oracle (C restatement of the reference algorithm: P = pow2 <= threads partitions, every thread scans
     all keys, per-group index lists, gather-fold aggregation, crates/polars-core/src/frame/group_by/hashing.rs:
     182-243 + aggregations/mod.rs) timed on this box's host cores: whole passes over the same rows for about
     `budget_s` seconds."""
-    import numpy as np
-
     from oracle import oracle as orc
-    from polars_amd import _ffi
-    from polars_amd.column import Column
 
-    keys_n, vals_n, aggs, _ = wl
-    host = {k: v.cpu().numpy() for k, v in tensors.items()}
-
-    def mk(name):
-        a = host[name]
-        if not wide and name in ("id1", "id2", "id3"):
-            a = a.view(np.uint32)
-        return Column(name, a)
-
-    keys = [mk(k) for k in keys_n]
-    vals = [mk(v) for v in vals_n]
+    hk, hv = _host_columns(keys), _host_columns(vals)
     threads = min(os.cpu_count() or 1, 16)  # the box's CPU share for one GPU
-    n = len(keys[0])
+    n = len(hk[0])
     orc.lib()
     passes, t0 = 0, time.perf_counter()
     while True:
-        want, _ = orc.group_by_agg(keys, vals, aggs, n_threads=threads)
+        want, _ = orc.group_by_agg(hk, hv, aggs, n_threads=threads)
         passes += 1
         dt = time.perf_counter() - t0
         if dt >= budget_s or passes >= 200:
             break
-    base = {"value": n * passes / dt, "unit": "rows/s", "cores": threads, "kind": "port",
+    base = {"value": n * passes / dt, "unit": "rows/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
             "sample": f"{passes} whole passes over the same {n} rows ({dt:.1f} s)"}
-    return base, parity_check(keys, vals, aggs, want, gpu_frame)
+    return base, parity_check(hk, hv, aggs, want, gpu_frame)
+
+
+def cpu_baseline_sample(tensors, keys_n, vals_n, aggs, gpu_frame, sample_rows=50_000_000):
+    """Workloads beyond 1e8 rows (config 5): the oracle is timed on the first `sample_rows` rows (a bounded sample of the
+    same columns), and the GPU result of the FULL input is checked through size-independent properties:
+    counts add up to N, the integer checksum of sums is exact, the f64 checksum within 1e-9, one row per distinct key."""
+    import numpy as np
+    import torch
+
+    from oracle import oracle as orc
+    from polars_amd.column import Column
+
+    n = tensors[keys_n[0]].numel()
+    m = min(n, sample_rows)
+    hk = [Column(k, tensors[k][:m].cpu().numpy()) for k in keys_n]
+    hv = [Column(v, tensors[v][:m].cpu().numpy()) for v in vals_n]
+    threads = min(os.cpu_count() or 1, 16)
+    orc.lib()
+    t0 = time.perf_counter()
+    orc.group_by_agg(hk, hv, aggs, n_threads=threads)
+    dt = time.perf_counter() - t0
+    base = {"value": m / dt, "unit": "rows/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
+            "sample": f"one pass over the first {m} of {n} rows ({dt:.1f} s)"}
+    got = gpu_frame()
+    nk = len(keys_n)
+    checks = {}
+    for j, (ci, kind) in enumerate(aggs):
+        col = got[nk + j][0]
+        src = tensors[vals_n[ci]]
+        if kind == "count":
+            checks["counts_add_up_to_n"] = int(col.astype(np.int64).sum()) == n
+        elif kind == "sum" and src.dtype in (torch.int64, torch.int32):
+            checks["integer_checksum_exact"] = int(col.astype(np.int64).sum()) == int(src.sum().item())
+        elif kind == "sum":
+            tot = float(src.sum().item())
+            checks["f64_checksum_1e-9"] = abs(float(col.sum()) - tot) <= 1e-9 * abs(tot)
+    distinct = int(torch.unique(tensors[keys_n[0]]).numel()) if nk == 1 else None
+    if distinct is not None:
+        checks["one_row_per_distinct_key"] = len(got[0][0]) == distinct and len(np.unique(got[0][0])) == distinct
+    return base, {"ok": all(checks.values()), "properties": checks, "groups": int(len(got[0][0])),
+                  "against": "size-independent properties of the full input (the oracle would need minutes at this size)"}
+
+
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def parity_check(keys, vals, aggs, want, gpu_frame):
@@ -114,32 +193,39 @@ def parity_check(keys, vals, aggs, want, gpu_frame):
             "against": "oracle (C restatement), same rows, canonical key sort"}
 
 
-def measured_traffic(workload, n_rows):
-    """HBM bytes per launch of the dominant kernel from the rocprofv3 --pmc passes kept under profiles/
-    (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE); None if no such
-    measurement is on file for this workload."""
+def measured_traffic(workload, n_rows, strategy):
+    """HBM bytes of the WHOLE query (summed over its kernels, per launch) from the rocprofv3 --pmc passes kept under
+    profiles/ (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE; scripts/prof_summary.py
+    writes the entry together with the per-kernel figures); None if no such measurement is on file for this
+    workload and strategy."""
     f = ROOT / "profiles" / "traffic.json"
     if not f.exists():
-        return None
+        return None, None
     try:
-        t = json.loads(f.read_text()).get(f"{workload}:{n_rows}")
-        return t["hbm_bytes"] if t else None
-    except (ValueError, OSError):
-        return None
+        t = json.loads(f.read_text()).get(f"{workload}:{n_rows}:{strategy}")
+        if not t:
+            return None, None
+        return t["hbm_bytes"], {k: int(v["fetch_bytes"] + v["write_bytes"]) for k, v in t.get("kernels", {}).items()}
+    except (ValueError, OSError, KeyError):
+        return None, None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=0, help="default 200 (c3: 20, c5: 5)")
+    ap.add_argument("--warmup", type=int, default=-1, help="default 10 (c3: 3, c5: 1)")
     ap.add_argument("--workload", default="q3", choices=sorted(WORKLOADS))
-    ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default 1e7; c3: 1e8)")
+    ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default 1e7; c3: 1e8; c5: 1e9)")
+    ap.add_argument("--total-rows", type=int, default=0,
+                    help="strong scaling (BASELINE configs[3]): the job's rows, every rank gets total / N of them")
     ap.add_argument("--strategy", default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense", action="store_true", help="do not declare a single Categorical key's codes dense (PLHIP_FLAG_KEYS_DENSE)")
     ap.add_argument("--no-hint", action="store_true",
                     help="do not pass the category count of categorical keys (id1..id3) as n_groups_hint")
+    ap.add_argument("--na", action="store_true", help="db-benchmark's NA variant (groupby-datagen.R:30-44): 5 %% of the distinct key values "
+                                                      "nulled, 5 %% NA values, as validity bitmaps")
     args = ap.parse_args()
 
     import torch
@@ -163,9 +249,18 @@ def main():
 
     wl = WORKLOADS[args.workload]
     keys_n, vals_n, aggs, wide = wl
-    n = args.rows or (100_000_000 if args.workload == "c3" else 10_000_000)
-    tensors = h2oai.generate(n, seed=108 + rank, device=dev, wide=wide, columns=keys_n + vals_n)
-    cols = h2oai.to_columns(tensors, wide, n=n)
+    strong = args.total_rows > 0
+    n = args.total_rows // world if strong else (args.rows or DEFAULT_ROWS.get(args.workload, 10_000_000))
+    job_rows = n * world  # the generator's N: key cardinalities (N / K ids) follow the JOB's size under strong scaling
+    steps = args.steps or {"c3": 20, "c5": 5}.get(args.workload, 200)
+    warmup = args.warmup if args.warmup >= 0 else {"c3": 3, "c5": 1}.get(args.workload, 10)
+    if args.workload == "c5":
+        tensors = skewed_keys(n, max(int((job_rows if strong else n) * C5_IDS_PER_ROW), 1), 108 + rank, dev)
+        cols = {k: pa.Column(k, t) for k, t in tensors.items()}
+    else:
+        tensors = h2oai.generate(n, seed=108 + rank, device=dev, wide=wide, columns=keys_n + vals_n, na=args.na,
+                                 n_for_ids=job_rows if strong else None)
+        cols = h2oai.to_columns(tensors, wide, n=job_rows if strong else n)
     keys = [cols[k] for k in keys_n]
     vals = [cols[v] for v in vals_n]
     agg_codes = [(ci, _ffi.AGG_NAMES[kind]) for ci, kind in aggs]
@@ -176,8 +271,8 @@ def main():
     hint = 0
     if not wide and not args.no_hint and all(k in ("id1", "id2", "id3") for k in keys_n):
         hint = 1
-        for k in keys_n:
-            hint *= 100 if k in ("id1", "id2") else max(n // 100, 1)
+        for k in keys:
+            hint *= k.n_categories
         hint = min(hint, n)
     # a single Categorical key: its codes index the tables directly (group_tuples_perfect, perfect.rs:190-227)
     qflags = _ffi.FLAG_KEYS_DENSE if (hint and len(keys) == 1 and keys[0].n_categories is not None and not args.no_dense) else 0
@@ -185,8 +280,10 @@ def main():
     if world > 1 or rehearse:
         from polars_amd import distributed as pdist
 
+        eng = pdist.HipEngine(dev)
+
         def step():
-            res = pdist.group_by_agg_sharded(keys, vals, aggs, device=dev, n_groups_hint=hint, force_exchange=rehearse)
+            res = pdist.group_by_agg_sharded(keys, vals, aggs, device=dev, engine=eng, n_groups_hint=hint, force_exchange=rehearse)
             return res[0].t.numel(), [_ffi.code_np_dtype(c.code).itemsize for c in res]
     else:
         import ctypes as C
@@ -214,18 +311,25 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     sync()
-    kernel_ms, dom_ms, parts, dom_names = [], [], [], []
+    kernel_ms, dom_ms, parts, dom_names, phases = [], [], [], [], []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         g, out_widths = step()
-        tot, dom, dom_name = pa.last_kernel_ms()  # HIP events on the library's own stream, recorded live
+        if world > 1 or rehearse:
+            # the sharded step makes several library calls: the engine kept the kernel times of the LOCAL partial pass
+            # (the pass over this rank's rows) and the wall time of every phase of the step
+            tot, dom, dom_name = eng.last_partial_kernel_ms
+            parts.append(eng.last_partial_breakdown)
+            phases.append(dict(eng.last_phase_ms))
+        else:
+            tot, dom, dom_name = pa.last_kernel_ms()  # HIP events on the library's own stream, recorded live
+            parts.append(pa.last_kernel_breakdown())
         kernel_ms.append(tot)
         dom_ms.append(dom)
         dom_names.append(dom_name)
-        parts.append(pa.last_kernel_breakdown())
     sync()
     dt = time.perf_counter() - t0
     groups_total = g
@@ -237,40 +341,49 @@ def main():
         dt, groups_total = float(tmax[0].item()), int(t[1].item())
 
     if rank == 0:
-        ms_per_step = dt / args.steps * 1e3
+        ms_per_step = dt / steps * 1e3
         total_rows = n * world
-        # the local pass of rank 0 (for N > 1: its partial aggregation, the dominant kernels of the step)
-        abytes = algorithmic_bytes(n, g, keys, vals, out_widths)
+        strategy = pa.last_strategy() if world == 1 and not rehearse else eng.last_partial_strategy
+        # the local pass of rank 0 (for N > 1: its partial aggregation over its n rows, the dominant kernels of the step)
+        g_local = g if world == 1 and not rehearse else eng.last_partial_groups
+        abytes = algorithmic_bytes(n, g_local, keys, vals, out_widths)
         dom_avg = sum(dom_ms) / len(dom_ms)
         tot_avg = sum(kernel_ms) / len(kernel_ms)
         achieved = abytes / (dom_avg * 1e-3) / 1e9 if dom_avg > 0 else 0.0
         dom_name = max(set(dom_names), key=dom_names.count)
+        traffic, traffic_kernels = measured_traffic(args.workload + ("_na" if args.na else ""), n, strategy)
+        acc_dtype = {"q1": "i32", "q3": "i32+f64", "q5": "i32+f64", "c3": "i64+f64", "c5": "i64+f64"}[args.workload]
         line = {
             "metric": "db-benchmark group-by rows/sec + % HBM roofline at 1/2/4/8 MI355X",
-            "value": total_rows / (dt / args.steps),
+            "value": total_rows / (dt / steps),
             "unit": "rows/s",
             "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
+            "steps": steps,
+            "warmup": warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
-            "dtype": "int64+f64",
+            "dtype": acc_dtype,
             "data": "synthetic",
-            "config": {"workload": f"db-benchmark {args.workload}: {', '.join(f'{k}({vals_n[c]})' for c, k in aggs)} by "
+            "config": {"workload": f"{'db-benchmark ' if args.workload[0] == 'q' else 'BASELINE config '}{args.workload}"
+                                   f"{' (NA variant)' if args.na else ''}: {', '.join(f'{k}({vals_n[c]})' for c, k in aggs)} by "
                                    f"{','.join(keys_n)}, {n} rows per GPU, {groups_total} groups",
-                       "strategy": pa.last_strategy(), "n_groups_hint": hint, "rows_per_gpu": n, "groups": int(groups_total),
-                       "exchange": "none" if world == 1 else "all_to_all_single of partial records (RCCL)"},
+                       "strategy": strategy, "n_groups_hint": hint, "dense_codes": bool(qflags), "rows_per_gpu": n, "groups": int(groups_total),
+                       "exchange": "none" if world == 1 and not rehearse else "all_to_all_single of partial records (RCCL)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(args.workload, n), "kernel": dom_name,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_by_kernel": traffic_kernels,
+                         "traffic_over_algorithmic": (traffic / abytes) if traffic else None, "kernel": dom_name,
                          "kernel_ms": dom_avg, "algorithmic_bytes": abytes,
                          "breakdown_ms": {k: sum(p[i] for p in parts) / len(parts) for i, k in
-                                          enumerate(("tile_sort", "fold", "merge_emit"))},
+                                          enumerate(("partition", "fold", "merge_emit"))},
                          "all_kernels_ms": tot_avg,
                          "all_kernels_frac": abytes / (tot_avg * 1e-3) / 1e9 / HBM_PEAK_GBPS if tot_avg > 0 else 0.0},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if phases:  # shuffle bytes and time reported separately
+            line["sharded_step_ms"] = {k: sum(p.get(k, 0.0) for p in phases) / len(phases) for k in phases[0]}
+            line["shuffle"] = {"bytes_sent_per_rank": eng.last_shuffle_bytes, "protocol": eng.last_protocol}
+        if world == 1 and not rehearse and not args.no_cpu_baseline:
             def gpu_frame():  # the timed configuration once more, result copied to the host
                 handle, out = pa.group_by_agg_raw(keys, vals, agg_codes, qflags, hint)
                 try:
@@ -282,7 +395,10 @@ def main():
                 finally:
                     L.plhip_result_free(handle)
 
-            line["cpu_baseline"], line["parity"] = cpu_baseline(tensors, wl, wide, gpu_frame)
+            if n <= 100_000_000:
+                line["cpu_baseline"], line["parity"] = cpu_baseline(tensors, keys, vals, aggs, gpu_frame)
+            else:
+                line["cpu_baseline"], line["parity"] = cpu_baseline_sample(tensors, keys_n, vals_n, aggs, gpu_frame)
         print(json.dumps(line))
     if world > 1 or rehearse:
         dist.destroy_process_group()

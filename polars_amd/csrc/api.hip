@@ -1201,6 +1201,8 @@ int run_dense(const Lowered &L0, const std::vector<DevCol> &dk, uint32_t flags, 
   DenseArgs A{};
   A.hint = (uint32_t)groups_hint; A.n_slots = A.hint + 1u;
   // ---- parts: one per value column; the group count rides with the cheapest one ----------------------------------
+  int cnt_acc_idx = 0;
+  for (int a = 0; a < P.n_accs; a++) if (P.accs[a].op == ACC_CNT_ALL) cnt_acc_idx = a;
   int part_of_val[PLHIP_MAX_VALS];
   for (int v = 0; v < P.n_vals; v++) part_of_val[v] = -1;
   uint32_t row_bytes[DENSE_MAX_PARTS] = {0};
@@ -1229,18 +1231,26 @@ int run_dense(const Lowered &L0, const std::vector<DevCol> &dk, uint32_t flags, 
     }
     return used;
   };
+  auto referenced = [&](int a) { // (a nullable column's valid count is lowered for every aggregation; SUM never reads it)
+    if (a == cnt_acc_idx) return true;
+    for (auto &o : L.outs) {
+      if (o.kind == OUT_KEY) continue;
+      if (o.acc == a || o.cnt_valid == a || o.cnt_all == a) return true;
+    }
+    return false;
+  };
   for (int a = 0; a < P.n_accs; a++) {
     const int src = P.accs[a].src;
     const uint32_t op = P.accs[a].op;
     if (op == ACC_FIRST_ROW) return PLHIP_OK;
+    if (!referenced(a)) continue;
     DensePart &D = A.part[src < 0 ? cheapest : part_of_val[src]];
     if (D.n_accs >= DENSE_MAX_PART_ACCS) return PLHIP_OK;
     D.acc[D.n_accs] = (uint8_t)a;
     D.lw[D.n_accs] = (op == ACC_CNT_ALL || op == ACC_CNT_VALID || narrow32(a)) ? 4 : 8;
     D.n_accs++;
   }
-  A.cnt_acc = 0;
-  for (int a = 0; a < P.n_accs; a++) if (P.accs[a].op == ACC_CNT_ALL) A.cnt_acc = (uint32_t)a;
+  A.cnt_acc = (uint32_t)cnt_acc_idx;
   // ---- ranges: the largest part's arrays cut into pieces of one CU's LDS ------------------------------------------
   const size_t LDS_CAP = 160 * 1024 - 512;
   uint32_t state_max = 0;
@@ -1252,11 +1262,13 @@ int run_dense(const Lowered &L0, const std::vector<DevCol> &dk, uint32_t flags, 
   const char *dbg_r = getenv("PLHIP_DENSE_R");
   uint32_t R = (uint32_t)(((uint64_t)A.n_slots * state_max + LDS_CAP - 1) / LDS_CAP);
   if (dbg_r) R = std::max<uint32_t>(R, (uint32_t)atoi(dbg_r));
+  const uint32_t rep = dk[0].validity ? 64u : 0u; // a nullable key: 64 replicas of the null slot behind a range's entries (dense_path.hip)
   for (;; R++) {
     if (R > DENSE_MAX_RANGES) return PLHIP_OK; // too many groups: every row would be read R times
     A.gpr = (((A.n_slots + R - 1) / R) + 3u) & ~3u;
-    if ((uint64_t)A.gpr * state_max + 16 * DENSE_MAX_PART_ACCS <= LDS_CAP && (uint64_t)(R - 1) * A.gpr < A.n_slots) break;
-    if ((uint64_t)(R - 1) * A.gpr >= A.n_slots && (uint64_t)A.gpr * state_max + 16 * DENSE_MAX_PART_ACCS <= LDS_CAP) { R = (A.n_slots + A.gpr - 1) / A.gpr; break; }
+    const bool fits = (uint64_t)(A.gpr + rep) * state_max + 16 * DENSE_MAX_PART_ACCS <= LDS_CAP;
+    if (fits && (uint64_t)(R - 1) * A.gpr < A.n_slots) break;
+    if (fits && (uint64_t)(R - 1) * A.gpr >= A.n_slots) { R = (A.n_slots + A.gpr - 1) / A.gpr; break; }
   }
   A.R = R;
   // a handful of groups in ONE range: the hashed DIRECT strategy is as fast there (one LDS table either way) and its merge is
@@ -1268,21 +1280,29 @@ int run_dense(const Lowered &L0, const std::vector<DevCol> &dk, uint32_t flags, 
     uint32_t lo = 0;
     uint64_t dof = 0;
     for (uint32_t i = 0; i < D.n_accs; i++) {
-      D.loff[i] = lo; lo += (A.gpr * D.lw[i] + 15u) & ~15u;
+      D.loff[i] = lo; lo += ((A.gpr + rep) * D.lw[i] + 15u) & ~15u;
       D.doff[i] = (uint32_t)dof; dof += ((uint64_t)R * A.gpr * D.lw[i] + 15u) & ~15ull;
     }
     if (dof > 0xFFFFFFFFull) return PLHIP_OK;
     D.slice_stride = (dof + 255) & ~255ull;
     lds_bytes = std::max<size_t>(lds_bytes, lo);
-    // straight-line kinds (no validity on the value column)
+    // straight-line kinds; validity bitmaps ride along when their bit offsets are multiples of 4 (a quad's bits in one byte)
     D.kind = DENSE_KIND_RT;
-    if (D.src >= 0 && !P.vals[D.src].validity) {
-      const uint32_t vd = P.vals[D.src].dtype;
+    D.pad0 = 0;
+    const bool kv_ok = !dk[0].validity || (dk[0].boff & 3) == 0;
+    if (D.src >= 0 && kv_ok && !getenv("PLHIP_DENSE_RT")) {
+      const ValSpec &V = P.vals[D.src];
+      const bool vv = V.validity != nullptr;
+      const uint32_t vd = V.dtype;
       const bool i4 = vd == PLHIP_I32 || vd == PLHIP_U32;
       auto is = [&](uint32_t i, uint32_t op, uint32_t lw) { return P.accs[D.acc[i]].op == op && D.lw[i] == lw; };
-      if (i4 && D.n_accs == 2 && is(0, ACC_CNT_ALL, 4) && is(1, ACC_ADD_U64, 4)) D.kind = DENSE_KIND_CNT_SUM32;
-      else if (i4 && D.n_accs == 1 && is(0, ACC_ADD_U64, 4)) D.kind = DENSE_KIND_SUM32;
-      else if (vd == PLHIP_F64 && D.n_accs == 1 && is(0, ACC_ADD_F64, 8)) D.kind = DENSE_KIND_SUMF64;
+      if (!vv || (!V.valid_bytes && (V.boff & 3) == 0)) {
+        if (i4 && D.n_accs == 2 && is(0, ACC_CNT_ALL, 4) && is(1, ACC_ADD_U64, 4)) D.kind = DENSE_KIND_CNT_SUM32;
+        else if (i4 && D.n_accs == 1 && is(0, ACC_ADD_U64, 4)) D.kind = DENSE_KIND_SUM32;
+        else if (vd == PLHIP_F64 && D.n_accs == 1 && is(0, ACC_ADD_F64, 8)) D.kind = DENSE_KIND_SUMF64;
+        else if (vd == PLHIP_F64 && vv && D.n_accs == 2 && is(0, ACC_CNT_VALID, 4) && is(1, ACC_ADD_F64, 8)) D.kind = DENSE_KIND_CNTV_SUMF64;
+        if (D.kind != DENSE_KIND_RT) D.pad0 = vv ? 1u : 0u;
+      }
     }
   }
   if (lds_bytes > LDS_CAP) return PLHIP_OK;

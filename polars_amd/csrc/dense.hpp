@@ -31,6 +31,7 @@ enum DenseKind : uint32_t {
   DENSE_KIND_CNT_SUM32 = 1, // 4-byte integer column: [CNT_ALL, ADD_U64 kept in 32 bits]      (q1, q3's v1 part)
   DENSE_KIND_SUMF64 = 2,    // f64 column: [ADD_F64]                                          (q3's v3 part)
   DENSE_KIND_SUM32 = 3,     // 4-byte integer column: [ADD_U64 kept in 32 bits]
+  DENSE_KIND_CNTV_SUMF64 = 4, // nullable f64 column: [CNT_VALID, ADD_F64]                     (mean of a nullable column)
 };
 
 struct DensePart {
@@ -42,7 +43,7 @@ struct DensePart {
   uint32_t n_accs;
   uint32_t n_slices; // row slices: one group slot (R workgroups on one XCD lane) each
   uint32_t slot0;    // the part's first group slot
-  uint32_t pad0;
+  uint32_t pad0;     // 1: the value column has a validity bitmap (straight-line kinds)
   uint32_t kind;     // DenseKind
   uint64_t dump_off;     // the part's partial arrays inside DenseArgs::dump
   uint64_t slice_stride; // bytes per slice there

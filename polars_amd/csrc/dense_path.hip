@@ -112,17 +112,21 @@ DEVINL void dense_process(const Plan &P, const DenseArgs &A, const DensePart &D,
     for (int b = 0; b < B; b++) {
       const bool isnull = KV && ((X.knull >> b) & 1u);
       if (!isnull && code[b] >= A.hint) { bad = 1; code[b] = 0xFFFFFFFFu; } // not a code of this rev-map: the caller's promise is broken
-      if (isnull) code[b] = A.hint;
+      // All null keys of the slice meet in ONE slot, and same-address LDS atomics serialise (~5 cycles a row: db-benchmark's
+      // NA variant took 0.40 ms instead of 0.06).  So every lane folds its null keys into a replica of that slot of its own
+      // (64 of them behind the range's `cnt` entries, conflict-free), and the replicas are added up before the dump.
+      if (isnull) code[b] = c0 + cnt + (threadIdx.x & 63u);
     }
   } else if (KV) { // a null key's code bits mean nothing: keep the row out of this range
 #pragma unroll
     for (int b = 0; b < B; b++) if ((X.knull >> b) & 1u) code[b] = 0xFFFFFFFFu;
   }
+  const uint32_t cnt_r = cnt + ((KV && is_last) ? 64u : 0u); // entries + the null slot's replicas
   uint32_t inm = 0;
 #pragma unroll
   for (int b = 0; b < B; b++) {
     rel[b] = code[b] - c0;
-    if (rel[b] < cnt) inm |= 1u << b;
+    if (rel[b] < cnt_r) inm |= 1u << b;
   }
   if (KIND == DENSE_KIND_CNT_SUM32) {
     uint8_t *t0 = tab + D.loff[0], *t1 = tab + D.loff[1];
@@ -179,81 +183,117 @@ DEVINL void dense_process(const Plan &P, const DenseArgs &A, const DensePart &D,
 // s_waitcnt vmcnt(N) before a buffer's first use (vmcnt retires in order), and an empty asm that ties the buffer's registers
 // to that wait.  Nothing else in the loop touches vector memory (LDS atomics count in lgkmcnt).
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-template <int VQ> // 16-byte loads per quad of rows of the value column: 1 (4-byte values) or 2 (8-byte values)
+// VQ: 16-byte loads per quad of rows of the value column: 1 (4-byte values) or 2 (8-byte values); kb / vb: the byte of the
+// key's / the value's validity bitmap that holds the quad's four bits (bitmap offsets are multiples of 4 here: host check)
+template <int VQ>
 struct DenseBuf {
   u32x4 k[2];
   u32x4 v[2 * VQ];
+  uint32_t kb[2], vb[2];
 };
 DEVINL u32x4 gload16(const uint8_t *sbase, uint32_t voff) {
   u32x4 v;
   asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
   return v;
 }
-template <int VQ>
-DEVINL void dense_issue(DenseBuf<VQ> &X, const uint8_t *kbase, const uint8_t *vbase, uint32_t row_in_slice) {
+DEVINL uint32_t gload1(const uint8_t *sbase, uint32_t voff) {
+  uint32_t v;
+  asm volatile("global_load_ubyte %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
+  return v;
+}
+struct DenseBases { // wave-uniform: the slice's first element of every stream, and the bit offsets of its first row
+  const uint8_t *k, *v, *kbm, *vbm;
+  uint32_t ksh0, vsh0; // 0 or 4
+};
+template <int VQ, bool KV, bool VV>
+DEVINL void dense_issue(DenseBuf<VQ> &X, const DenseBases &S, uint32_t row_in_slice) {
 #pragma unroll
   for (int g = 0; g < 2; g++) {
     const uint32_t q = row_in_slice + ((uint32_t)g * DENSE_BLOCK + threadIdx.x) * 4u; // first row of the lane's quad g
-    X.k[g] = gload16(kbase, q * 4u);
+    X.k[g] = gload16(S.k, q * 4u);
 #pragma unroll
-    for (int h = 0; h < VQ; h++) X.v[g * VQ + h] = gload16(vbase, q * (4u * VQ) + 16u * h);
+    for (int h = 0; h < VQ; h++) X.v[g * VQ + h] = gload16(S.v, q * (4u * VQ) + 16u * h);
+    if (KV) X.kb[g] = gload1(S.kbm, (S.ksh0 + q) >> 3);
+    if (VV) X.vb[g] = gload1(S.vbm, (S.vsh0 + q) >> 3);
   }
 }
 template <int N> DEVINL void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-template <int VQ>
+template <int VQ, bool KV, bool VV>
 DEVINL void dense_pin(DenseBuf<VQ> &X) {
 #pragma unroll
   for (int g = 0; g < 2; g++) { u32x4 t = X.k[g]; asm volatile("" : "+v"(t)::"memory"); X.k[g] = t; }
 #pragma unroll
   for (int g = 0; g < 2 * VQ; g++) { u32x4 t = X.v[g]; asm volatile("" : "+v"(t)::"memory"); X.v[g] = t; }
-}
-template <int KIND, int VQ>
-DEVINL void dense_fold_buf(const DenseArgs &A, const DensePart &D, uint8_t *tab, uint32_t c0, uint32_t cnt, bool is_last, const DenseBuf<VQ> &X,
-                           uint32_t &bad) {
-  uint8_t *t0 = tab + D.loff[0], *t1 = tab + D.loff[KIND == DENSE_KIND_CNT_SUM32 ? 1 : 0];
 #pragma unroll
   for (int g = 0; g < 2; g++) {
+    if (KV) { uint32_t t = X.kb[g]; asm volatile("" : "+v"(t)::"memory"); X.kb[g] = t; }
+    if (VV) { uint32_t t = X.vb[g]; asm volatile("" : "+v"(t)::"memory"); X.vb[g] = t; }
+  }
+}
+template <int KIND, int VQ, bool KV, bool VV>
+DEVINL void dense_fold_buf(const DenseArgs &A, const DensePart &D, uint8_t *tab, uint32_t c0, uint32_t cnt, bool is_last, const DenseBuf<VQ> &X,
+                           const DenseBases &S, uint32_t row_in_slice, uint32_t &bad) {
+  constexpr bool TWO = KIND == DENSE_KIND_CNT_SUM32 || KIND == DENSE_KIND_CNTV_SUMF64;
+  uint8_t *t0 = tab + D.loff[0], *t1 = tab + D.loff[TWO ? 1 : 0];
+  const uint32_t cnt_r = cnt + ((KV && is_last) ? 64u : 0u); // entries + the null slot's 64 replicas (dense_process)
+#pragma unroll
+  for (int g = 0; g < 2; g++) {
+    const uint32_t q = row_in_slice + ((uint32_t)g * DENSE_BLOCK + threadIdx.x) * 4u;
     const uint32_t key[4] = {X.k[g].x, X.k[g].y, X.k[g].z, X.k[g].w};
+    const uint32_t knull = KV ? ~(X.kb[g] >> ((S.ksh0 + q) & 4u)) & 0xFu : 0u;
+    const uint32_t vnull = VV ? ~(X.vb[g] >> ((S.vsh0 + q) & 4u)) & 0xFu : 0u;
     uint32_t rel[4];
 #pragma unroll
     for (int b = 0; b < 4; b++) {
       uint32_t code = key[b];
-      if (is_last && code >= A.hint) { bad = 1; code = 0xFFFFFFFFu; } // (uniform test) not a code of this rev-map
+      const bool isnull = KV && ((knull >> b) & 1u);
+      if (is_last) { // (uniform test)
+        if (!isnull && code >= A.hint) { bad = 1; code = 0xFFFFFFFFu; } // not a code of this rev-map
+        if (isnull) code = c0 + cnt + (threadIdx.x & 63u);              // the lane's replica of the null slot
+      } else if (isnull) code = 0xFFFFFFFFu;
       rel[b] = code - c0;
     }
-    if (KIND == DENSE_KIND_SUMF64) {
+    if (KIND == DENSE_KIND_SUMF64 || KIND == DENSE_KIND_CNTV_SUMF64) {
       const u32x4 a = X.v[2 * g], b2 = X.v[2 * g + 1];
       const double d[4] = {__hiloint2double((int)a.y, (int)a.x), __hiloint2double((int)a.w, (int)a.z), __hiloint2double((int)b2.y, (int)b2.x),
                            __hiloint2double((int)b2.w, (int)b2.z)};
 #pragma unroll
-      for (int b = 0; b < 4; b++) if (rel[b] < cnt) atomicAdd((double *)(t0 + rel[b] * 8u), d[b]);
+      for (int b = 0; b < 4; b++)
+        if (rel[b] < cnt_r && !((vnull >> b) & 1u)) {
+          if (KIND == DENSE_KIND_CNTV_SUMF64) atomicAdd((unsigned int *)(t0 + rel[b] * 4u), 1u);
+          atomicAdd((double *)(t1 + rel[b] * 8u), d[b]);
+        }
     } else {
       const uint32_t v[4] = {X.v[g].x, X.v[g].y, X.v[g].z, X.v[g].w};
 #pragma unroll
       for (int b = 0; b < 4; b++)
-        if (rel[b] < cnt) {
+        if (rel[b] < cnt_r) {
           if (KIND == DENSE_KIND_CNT_SUM32) atomicAdd((unsigned int *)(t0 + rel[b] * 4u), 1u);
-          atomicAdd((unsigned int *)(t1 + rel[b] * 4u), v[b]);
+          atomicAdd((unsigned int *)(t1 + rel[b] * 4u), ((vnull >> b) & 1u) ? 0u : v[b]); // a null adds nothing to a sum
         }
     }
   }
 }
-template <int KIND>
+template <int KIND, bool KV, bool VV>
 DEVINL uint32_t dense_fold_rows_fast(const Plan &P, const DenseArgs &A, const DensePart &D, uint8_t *tab, uint32_t c0, uint32_t cnt, bool is_last,
                                      int64_t row0, uint32_t nb, uint32_t &bad) {
-  constexpr int VQ = KIND == DENSE_KIND_SUMF64 ? 2 : 1;
-  constexpr int NL = 2 + 2 * VQ; // loads per batch
-  const uint8_t *kbase = P.keys[0].values + row0 * 4, *vbase = P.vals[D.src].values + row0 * (4 * VQ);
+  constexpr int VQ = (KIND == DENSE_KIND_SUMF64 || KIND == DENSE_KIND_CNTV_SUMF64) ? 2 : 1;
+  constexpr int NL = 2 + 2 * VQ + (KV ? 2 : 0) + (VV ? 2 : 0); // loads per batch
+  DenseBases S;
+  S.k = P.keys[0].values + row0 * 4; S.v = P.vals[D.src].values + row0 * (4 * VQ);
+  S.kbm = nullptr; S.vbm = nullptr; S.ksh0 = 0; S.vsh0 = 0;
+  if (KV) { const int64_t bit = P.keys[0].boff + row0; S.kbm = P.keys[0].validity + (bit >> 3); S.ksh0 = (uint32_t)bit & 7u; }
+  if (VV) { const int64_t bit = P.vals[D.src].boff + row0; S.vbm = P.vals[D.src].validity + (bit >> 3); S.vsh0 = (uint32_t)bit & 7u; }
   DenseBuf<VQ> b0, b1, b2;
-  if (nb > 0) dense_issue<VQ>(b0, kbase, vbase, 0u);
-  if (nb > 1) dense_issue<VQ>(b1, kbase, vbase, (uint32_t)DENSE_BATCH);
+  if (nb > 0) dense_issue<VQ, KV, VV>(b0, S, 0u);
+  if (nb > 1) dense_issue<VQ, KV, VV>(b1, S, (uint32_t)DENSE_BATCH);
 #define DENSE_STEP(CUR, NEXT)                                                                     \
   {                                                                                               \
-    if (t + 2 < nb) dense_issue<VQ>(NEXT, kbase, vbase, (t + 2) * (uint32_t)DENSE_BATCH);         \
+    if (t + 2 < nb) dense_issue<VQ, KV, VV>(NEXT, S, (t + 2) * (uint32_t)DENSE_BATCH);            \
     const uint32_t ahead = nb - 1 - t; /* batches issued behind this one */                       \
     if (ahead >= 2) wait_vm<2 * NL>(); else if (ahead == 1) wait_vm<NL>(); else wait_vm<0>();     \
-    dense_pin<VQ>(CUR);                                                                           \
-    dense_fold_buf<KIND, VQ>(A, D, tab, c0, cnt, is_last, CUR, bad);                              \
+    dense_pin<VQ, KV, VV>(CUR);                                                                   \
+    dense_fold_buf<KIND, VQ, KV, VV>(A, D, tab, c0, cnt, is_last, CUR, S, t * (uint32_t)DENSE_BATCH, bad); \
     ++t;                                                                                          \
   }
   uint32_t t = 0;
@@ -290,25 +330,15 @@ DEVINL void dense_fold_rows(const Plan &P, const DenseArgs &A, const DensePart &
       dense_load<KIND, 8, true, KV>(P, D, row, X);
       dense_process<KIND, 8, KV>(P, A, D, tab, c0, cnt, is_last, X, bad);
     }
-  } else if constexpr (!KV) {
-    t = dense_fold_rows_fast<KIND>(P, A, D, tab, c0, cnt, is_last, row0, nb, bad);
-  } else {
-    DenseRows<8> XA, XB;
-    if (t < nb) { mkrows(row0, row); dense_load<KIND, 8, true, KV>(P, D, row, XA); }
-    while (t < nb) {
-      if (t + 1 < nb) { mkrows(row0 + (int64_t)(t + 1) * DENSE_BATCH, row); dense_load<KIND, 8, true, KV>(P, D, row, XB); }
-      dense_process<KIND, 8, KV>(P, A, D, tab, c0, cnt, is_last, XA, bad);
-      if (++t >= nb) break;
-      if (t + 1 < nb) { mkrows(row0 + (int64_t)(t + 1) * DENSE_BATCH, row); dense_load<KIND, 8, true, KV>(P, D, row, XA); }
-      dense_process<KIND, 8, KV>(P, A, D, tab, c0, cnt, is_last, XB, bad);
-      ++t;
-    }
+  } else { // the straight-line kinds: hand-pipelined loads (bitmap offsets are multiples of 4: host check)
+    if (D.pad0) t = dense_fold_rows_fast<KIND, KV, true>(P, A, D, tab, c0, cnt, is_last, row0, nb, bad);
+    else t = dense_fold_rows_fast<KIND, KV, false>(P, A, D, tab, c0, cnt, is_last, row0, nb, bad);
   }
   for (int64_t r = row0 + (int64_t)nb * DENSE_BATCH + threadIdx.x; r < row1; r += DENSE_BLOCK) { // the slice's last rows: one per lane
     const uint32_t row1_[1] = {(uint32_t)r};
     DenseRows<1> X;
-    dense_load<KIND, 1, false, KV>(P, D, row1_, X);
-    dense_process<KIND, 1, KV>(P, A, D, tab, c0, cnt, is_last, X, bad);
+    dense_load<DENSE_KIND_RT, 1, false, KV>(P, D, row1_, X); // (one row per lane: the run-time form of every kind)
+    dense_process<DENSE_KIND_RT, 1, KV>(P, A, D, tab, c0, cnt, is_last, X, bad);
   }
 }
 
@@ -330,10 +360,11 @@ __global__ void __launch_bounds__(DENSE_BLOCK) k_dense_fold(Plan P, DenseArgs A)
   const uint32_t cnt = c0 < A.n_slots ? (A.n_slots - c0 < A.gpr ? A.n_slots - c0 : A.gpr) : 0u;
   const bool is_last = cnt != 0 && c0 + cnt == A.n_slots;
   if (threadIdx.x == 0) sh[0] = 0;
+  const uint32_t n_init = A.gpr + (KV ? 64u : 0u); // (a nullable key: 64 replicas of the null slot behind the entries, host-side layout)
   for (uint32_t i = 0; i < D.n_accs; i++) {
     const uint64_t init = P.accs[D.acc[i]].init;
-    if (D.lw[i] == 8) for (uint32_t j = threadIdx.x; j < A.gpr; j += DENSE_BLOCK) ((uint64_t *)(dsm + D.loff[i]))[j] = init;
-    else for (uint32_t j = threadIdx.x; j < A.gpr; j += DENSE_BLOCK) ((uint32_t *)(dsm + D.loff[i]))[j] = (uint32_t)init;
+    if (D.lw[i] == 8) for (uint32_t j = threadIdx.x; j < n_init; j += DENSE_BLOCK) ((uint64_t *)(dsm + D.loff[i]))[j] = init;
+    else for (uint32_t j = threadIdx.x; j < n_init; j += DENSE_BLOCK) ((uint32_t *)(dsm + D.loff[i]))[j] = (uint32_t)init;
   }
   __syncthreads();
   int64_t row0 = (int64_t)slice * D.rows_per_slice, row1 = row0 + D.rows_per_slice;
@@ -345,6 +376,7 @@ __global__ void __launch_bounds__(DENSE_BLOCK) k_dense_fold(Plan P, DenseArgs A)
       case DENSE_KIND_CNT_SUM32: dense_fold_rows<DENSE_KIND_CNT_SUM32, KV>(P, A, D, dsm, c0, cnt, is_last, row0, row1, bad); break;
       case DENSE_KIND_SUMF64: dense_fold_rows<DENSE_KIND_SUMF64, KV>(P, A, D, dsm, c0, cnt, is_last, row0, row1, bad); break;
       case DENSE_KIND_SUM32: dense_fold_rows<DENSE_KIND_SUM32, KV>(P, A, D, dsm, c0, cnt, is_last, row0, row1, bad); break;
+      case DENSE_KIND_CNTV_SUMF64: dense_fold_rows<DENSE_KIND_CNTV_SUMF64, KV>(P, A, D, dsm, c0, cnt, is_last, row0, row1, bad); break;
       default:
         if constexpr (RT) dense_fold_rows<DENSE_KIND_RT, KV>(P, A, D, dsm, c0, cnt, is_last, row0, row1, bad);
         break;
@@ -353,6 +385,14 @@ __global__ void __launch_bounds__(DENSE_BLOCK) k_dense_fold(Plan P, DenseArgs A)
   if (bad) sh[0] = 1;
   __syncthreads();
   if (sh[0] && threadIdx.x == 0) A.flags[FLAG_OVERFLOW] = 1; // a code outside [0, hint): the caller falls back to the hashed path
+  if (KV && is_last && threadIdx.x < D.n_accs) { // the null slot's replicas -> the slot itself (entry cnt - 1 of the last range)
+    const uint32_t i = threadIdx.x, op = P.accs[D.acc[i]].op, lw = D.lw[i];
+    uint8_t *arr = dsm + D.loff[i];
+    uint64_t acc = lw == 8 ? ((uint64_t *)arr)[cnt - 1] : (uint64_t)((uint32_t *)arr)[cnt - 1];
+    for (uint32_t r = 0; r < 64; r++) acc = dense_combine(op, acc, lw == 8 ? ((uint64_t *)arr)[cnt + r] : (uint64_t)((uint32_t *)arr)[cnt + r]);
+    if (lw == 8) ((uint64_t *)arr)[cnt - 1] = acc; else ((uint32_t *)arr)[cnt - 1] = (uint32_t)acc;
+  }
+  __syncthreads();
   // the range's arrays -> the slice's partial arrays (plain 16-byte stores)
   uint8_t *dslice = A.dump + D.dump_off + (uint64_t)slice * D.slice_stride;
   for (uint32_t i = 0; i < D.n_accs; i++) {

@@ -281,6 +281,10 @@ class HipEngine:
 
         from .frame import group_by_agg_raw
 
+        import time
+
+        from .frame import last_kernel_breakdown, last_kernel_ms, last_strategy
+
         L = _ffi.lib()
         nk = len(keys)
         schema = partial_schema(keys, vals, aggs)
@@ -289,9 +293,24 @@ class HipEngine:
         # RCCL moves device buffers; over gloo (rehearsals of several ranks on one GPU) they are staged through the host
         staged = dist.get_backend(group) == "gloo"
         self._sync_torch()
+        ph = self.last_phase_ms = {}
+        t0 = time.perf_counter()
+
+        def lap(name):
+            nonlocal t0
+            t1 = time.perf_counter()
+            ph[name] = ph.get(name, 0.0) + (t1 - t0) * 1e3
+            t0 = t1
+
         handle, cols = group_by_agg_raw(keys, vals, codes, _ffi.FLAG_PARTIAL | _ffi.FLAG_OUTPUT_DEVICE, hint)
+        # the kernel times of THIS call (the pass over the rank's rows): later library calls of the step overwrite them
+        self.last_partial_kernel_ms = last_kernel_ms()
+        self.last_partial_breakdown = last_kernel_breakdown()
+        self.last_partial_strategy = last_strategy()
+        lap("partial_pass")
         try:
             g = int(L.plhip_result_num_rows(handle))
+            self.last_partial_groups = g
             if g:  # the frame's layout is a property of the schema: every rank computes the same one
                 assert [(cs.dtype, bool(cs.validity)) for cs in cols] == schema, "partial frame does not match the schema"
             counts = (C.c_int64 * world)()
@@ -301,17 +320,23 @@ class HipEngine:
                 stride = int(L.plhip_slot_bytes(rec, slot_rows))
                 send = torch.empty(world * stride, dtype=torch.uint8, device=self.device)
                 _ffi.check(L.plhip_result_pack_slots(handle, nk, NULL_HASH, world, slot_rows, send.data_ptr(), counts))
+                lap("pack")
                 recv = torch.empty(world * stride, dtype=torch.uint8, device="cpu" if staged else self.device)
                 dist.all_to_all_single(recv, send.cpu() if staged else send, group=group)
                 if staged:
                     recv = recv.to(self.device)
                 hdr = recv.view(world, stride)[:, :16].cpu().numpy().view(np.uint64)  # the one host sync of the exchange
+                lap("exchange")
+                self.last_shuffle_bytes = int(world * stride)
+                self.last_protocol = "slots: one equal-split all_to_all_single"
                 if not hdr[:, 1].any():
                     rc = (C.c_int64 * world)(*[int(x) for x in hdr[:, 0]])
                     merged = self._merge_call(recv, schema, nk, aggs, hint, sum(rc), slots=(world, slot_rows, rc))
+                    lap("merge")
             if merged is None:  # no hint, or some rank's bucket overflowed its slot (all ranks saw the flag)
                 send = torch.empty((max(g, 1), rec), dtype=torch.uint8, device=self.device)
                 _ffi.check(L.plhip_result_pack_by_owner(handle, nk, NULL_HASH, world, send.data_ptr(), counts))
+                lap("pack")
                 sc = list(counts)
                 cdev = torch.device("cpu") if staged else self.device
                 send_counts = torch.tensor(sc, dtype=torch.int64, device=cdev)
@@ -323,10 +348,25 @@ class HipEngine:
                 dist.all_to_all_single(recv, send[:g].cpu() if staged else send[:g], output_split_sizes=rc, input_split_sizes=sc, group=group)
                 if staged:
                     recv = recv.to(self.device)
+                self._sync_torch()
+                lap("exchange")
+                self.last_shuffle_bytes = int(g * rec)
+                self.last_protocol = "counts all_to_all_single + variable all_to_all_single"
                 merged = self._merge_call(recv, schema, nk, aggs, hint, m)
+                lap("merge")
         finally:
             L.plhip_result_free(handle)
-        return self.finalize_frame(merged, keys, vals, aggs, names)
+        out = self.finalize_frame(merged, keys, vals, aggs, names)
+        lap("finalize")
+        return out
+
+    last_partial_kernel_ms = (0.0, 0.0, "")
+    last_partial_breakdown = (0.0, 0.0, 0.0)
+    last_partial_strategy = ""
+    last_partial_groups = 0
+    last_phase_ms: dict = {}
+    last_shuffle_bytes = 0
+    last_protocol = ""
 
     use_slots = True  # tests switch the slotted exchange off to cover the exact protocol
 

@@ -207,6 +207,7 @@ def test_arrow_offsets_and_partial_flag(oracle):
     vbuf = rng.integers(-9, 9, n + 8).astype(np.int32)
     import torch
 
+    pa.set_strategy("dense")  # (500 categories in one range: AUTO would leave this query to the hashed DIRECT strategy)
     for device in (False, True):
         for off in (0, 4, 3):  # device-resident columns: offset 4 keeps the 16-byte quads aligned, offset 3 does not -> declined
             kb = torch.from_numpy(kbuf.view(np.int32)).to("cuda:0") if device else kbuf
