@@ -930,6 +930,66 @@ def test_high_cardinality_properties(strategy):
     assert (s1[one] == mn[one]).all() and (mn[one] == mx[one]).all()
 
 
+def test_config3_full_size_properties():
+    """BASELINE configs[2] at its stated size: 1e8 rows, keys (id1, id2, id3) as i64, i64 sum/min/max + f64 sum/mean +
+    count, under AUTO.  The oracle needs minutes here, so the frame is checked through size-independent properties."""
+    import torch
+
+    n = 100_000_000
+    tensors, keys, vals, aggs, _ = _bench_frame("c3", n)
+    got = _run_raw(keys, vals, aggs, 0)
+    assert pa.last_strategy() in ("sort", "tilesort2", "leafsort")
+    k1, k2, k3 = (got[i][0] for i in range(3))
+    s1, mn, mx, s3, mean3, cnt = (got[3 + i][0] for i in range(6))
+    assert int(cnt.astype(np.int64).sum()) == n                                        # counts add up to N
+    assert int(s1.sum()) == int(tensors["v1"].sum().item())                            # checksum of integer sums: exact
+    tot3 = float(tensors["v3"].sum().item())
+    assert abs(float(s3.sum()) - tot3) <= 1e-9 * abs(tot3)                             # f64 checksum of sums
+    packed = (tensors["id1"] * 101 + tensors["id2"]) * (n // 100 + 1) + tensors["id3"]  # injective for this data
+    assert len(k1) == int(torch.unique(packed).numel())                                # one row per distinct key tuple
+    del packed
+    gp = (k1.astype(np.int64) * 101 + k2) * (n // 100 + 1) + k3
+    assert len(np.unique(gp)) == len(gp)                                               # and no tuple twice
+    assert (mn <= mx).all() and np.allclose(mean3 * cnt, s3, rtol=1e-12)
+    one = cnt == 1                                                                     # single-row groups: sum = min = max
+    assert (s1[one] == mn[one]).all() and (mn[one] == mx[one]).all()
+    assert int(mn.min()) == int(tensors["v1"].min().item()) and int(mx.max()) == int(tensors["v1"].max().item())
+
+
+def test_config5_full_size_properties():
+    """BASELINE configs[4] at its stated size: 1e9 rows, 1e8 ids, half Zipf(1.1) heavy hitters and half a uniform tail
+    (bench.skewed_keys, seed 108), f64 sum/mean + i64 sum/min/max + count under AUTO; size-independent properties."""
+    import torch
+
+    import bench
+
+    n, ids = 1_000_000_000, 100_000_000
+    dev = torch.device("cuda:0")
+    t = bench.skewed_keys(n, ids, 108, dev)
+    keys, vals = [Column("k", t["k"])], [Column("v3", t["v3"]), Column("v1", t["v1"])]
+    aggs = bench.WORKLOADS["c5"][2]
+    got = _run_raw(keys, vals, aggs, 0)
+    k = got[0][0]
+    s3, mean3, s1, mn, mx, cnt = (got[1 + i][0] for i in range(6))
+    assert int(cnt.astype(np.int64).sum()) == n
+    assert int(s1.sum()) == int(t["v1"].sum().item())
+    tot3 = float(t["v3"].sum().item())
+    assert abs(float(s3.sum()) - tot3) <= 1e-9 * abs(tot3)
+    uniq, ucnt = torch.unique(t["k"], return_counts=True)
+    assert len(k) == int(uniq.numel()) and len(np.unique(k)) == len(k)
+    order = np.argsort(k)
+    assert np.array_equal(k[order], uniq.cpu().numpy())                                # the keys themselves
+    assert np.array_equal(cnt[order].astype(np.int64), ucnt.cpu().numpy())             # and every group's length, exactly
+    del uniq, ucnt
+    assert (mn <= mx).all() and (mn >= 1).all() and (mx <= 5).all()
+    assert np.allclose(mean3 * cnt, s3, rtol=1e-12)
+    top = int(np.argmax(cnt))                                                          # the heaviest hitter: ~3.3e7 rows
+    hot = t["k"] == int(k[top])
+    assert int(cnt[top]) == int(hot.sum().item()) and int(s1[top]) == int(t["v1"][hot].sum().item())
+    ref = float(t["v3"][hot].sum().item())
+    assert abs(float(s3[top]) - ref) <= 1e-12 * abs(ref)
+
+
 def test_two_levels_vs_oracle_mid_size(oracle):
     """TILESORT2 against the oracle where the oracle still finishes in seconds: 6e6 rows, ~1.9e6 groups (beyond one
     partition level), a nullable i64 key, nullable f64 values; forced, and as AUTO's own choice."""
