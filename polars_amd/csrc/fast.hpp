@@ -93,6 +93,7 @@ struct FoldRunsArgs {
   uint32_t hot_min_rows;
   uint32_t *self_hot;
   uint32_t hot_chunk_rows, pad3;
+  const uint8_t *skip; // may be nullptr: [n_pg * S] leaves with skip[leaf] != 0 were folded by k_leaf_sort
 };
 
 struct MergeArgs {
@@ -107,6 +108,20 @@ struct MergeArgs {
   uint32_t seq;
   uint32_t pad;
 };
+
+// leaf_path.hip: the leaf kernel for the one-row-per-group regime (a wave sorts a leaf of <= 512 rows and folds its runs)
+struct LeafSortArgs {
+  const uint8_t *pkeys;      // packed keys of the level-2 sorted tiles (key_bytes each, < 2^55)
+  const uint32_t *offs;      // as FoldRunsArgs::offs
+  const uint32_t *seg_start; // first row of every level-1 partition (multiples of TS_TILE), [S + 1]
+  uint32_t n_pg, S, n_tiles, n_leaves; // leaf = seg * n_pg + pg
+  uint32_t *flags;           // [FLAG_NGROUPS] output-row cursor, [FLAG_OVERFLOW], [10] workgroups done, [11] leaves left over
+  uint8_t *handled;          // [n_leaves]: 1 = folded here, 0 = left to k_fold_runs
+  uint64_t out_cap;
+  uint32_t *host_sig;        // the last workgroup: word 2 = leaves left over, words 0-1 = seq << 32 | overflow << 31 | groups
+  uint32_t seq, pad;
+};
+void launch_leaf_sort(const Plan &p2, const LeafSortArgs &a, const OutPlan &o, int key_bytes, hipStream_t s);
 
 int fast_shape_id(const Plan &p); // index of the pre-instantiated shape the plan matches, or -1 (run-time shape)
 size_t fast_table_bytes(const Plan &p, uint32_t lbits, int key_bytes);  // LDS bytes of a fold / merge workgroup

@@ -845,6 +845,12 @@ __global__ void __launch_bounds__(1024) k_fold_runs(Plan P, FoldRunsArgs A, OutP
   if (threadIdx.x < 8) sh[threadIdx.x] = 0;
   // (an extra workgroup of the heavy-hitter split initialises its table only once it knows it has work)
   const bool extra_wg = A.hot && blockIdx.x >= A.n_pg * A.S;
+  if (A.skip && !A.self_hot && blockIdx.x < A.n_pg * A.S) { // two-level pipeline: the leaf may have been folded by k_leaf_sort already
+    uint32_t it = blockIdx.x;
+    const uint32_t n8s = (A.n_pg * A.S) & ~7u;
+    if (it < n8s) it = (it & 7u) * (n8s >> 3) + (it >> 3);
+    if (A.skip[it]) { __syncthreads(); publish_done(A.flags, sh, A.host_sig, A.seq); return; }
+  }
   if (!extra_wg) ltab_init<KS>(P, fsm, lslots);
   __syncthreads();
   // Neighbouring partitions share the cache lines at their run boundaries.  Workgroups b, b + 8, b + 16, ...

@@ -338,6 +338,14 @@ def group_by_agg_raw(keys: Sequence[Column], values: Sequence[Column], aggs: Seq
     """Thin call of plhip_group_by_agg.  Returns (handle, [ColumnStruct...]); the caller must
     plhip_result_free(handle).  Used by bench.py (device-resident outputs) and by _execute."""
     L = _ffi.lib()
+    # libplhip.so runs on its own stream: device-resident columns must be complete when it reads them, so whatever torch
+    # still has queued on its current stream (the kernels that produce these tensors) is waited for first
+    for c in list(keys) + list(values):
+        if c.location == _ffi.DEVICE and type(c.values).__module__.startswith("torch"):
+            import torch
+
+            torch.cuda.current_stream(c.values.device).synchronize()
+            break
     karr = (_ffi.ColumnStruct * max(1, len(keys)))(*[k.struct() for k in keys])
     varr = (_ffi.ColumnStruct * max(1, len(values)))(*[v.struct() for v in values])
     aarr = (_ffi.AggStruct * max(1, len(aggs)))(*[_ffi.AggStruct(c, k) for c, k in aggs])

@@ -111,7 +111,7 @@ def test_zz_fast_path_coverage():
     they must not decline the plain cases."""
     allowed = {"direct": ("multi-key", "stable", "card=None", "n=0"), "tilesort": ("multi-key", "stable", "card=None", "n=0"),
                "sort": ("n=0",), "tilesort2": ("multi-key", "stable", "card=None", "n=0")}
-    bad = [w for w, s, _ in FELL_BACK if not any(w.startswith(a) or a in w for a in allowed[s])]
+    bad = [w for w, s, r in FELL_BACK if not any(w.startswith(a) or a in w for a in allowed[s]) and not (s == "tilesort2" and r == "leafsort")]
     assert not bad, f"fast path declined: {sorted(bad)}"
 
 
@@ -910,11 +910,12 @@ def test_high_cardinality_properties(strategy):
     tensors, keys, vals, aggs, _ = _bench_frame("c3", n)
     pa.set_strategy(strategy)
     got = _run_raw(keys, vals, aggs, 0)
-    assert pa.last_strategy() == strategy
-    if strategy == "sort":  # nearly all-unique keys: AUTO's choice
+    # (forced two levels: with about one row per group their leaves go to the leaf sort kernel, reported as "leafsort")
+    assert pa.last_strategy() == (strategy if strategy == "sort" else "leafsort")
+    if strategy == "sort":  # nearly all-unique keys: AUTO takes the two levels with the leaf sort
         pa.set_strategy("auto")
         got = _run_raw(keys, vals, aggs, 0)
-        assert pa.last_strategy() == "sort"
+        assert pa.last_strategy() == "leafsort"
     k1, k2, k3 = (got[i][0] for i in range(3))
     s1, mn, mx, s3, mean3, cnt = (got[3 + i][0] for i in range(6))
     assert int(cnt.astype(np.int64).sum()) == n                                        # counts add up to N
@@ -970,6 +971,7 @@ def test_config5_full_size_properties():
     aggs = bench.WORKLOADS["c5"][2]
     got = _run_raw(keys, vals, aggs, 0)
     k = got[0][0]
+    assert len(k) > ids // 2, f"{len(k)} groups via {pa.last_strategy()}"
     s3, mean3, s1, mn, mx, cnt = (got[1 + i][0] for i in range(6))
     assert int(cnt.astype(np.int64).sum()) == n
     assert int(s1.sum()) == int(t["v1"].sum().item())
@@ -988,6 +990,30 @@ def test_config5_full_size_properties():
     assert int(cnt[top]) == int(hot.sum().item()) and int(s1[top]) == int(t["v1"][hot].sum().item())
     ref = float(t["v3"][hot].sum().item())
     assert abs(float(s3[top]) - ref) <= 1e-12 * abs(ref)
+
+
+@pytest.mark.parametrize("hot", [False, True], ids=["near_unique", "with_heavy_hitters"])
+def test_leaf_sort_vs_oracle(oracle, hot):
+    """The leaf kernel of the two-level pipeline for about one row per group (k_leaf_sort: a wave sorts a leaf and folds
+    its runs): three i64 keys, nearly all tuples distinct, a nullable f64 column; with heavy hitters some leaves exceed
+    the 512 rows a wave sorts and are left to k_fold_runs (which skips the leaves already folded)."""
+    rng = np.random.default_rng(91 + hot)
+    n = 3_000_000
+    k1 = rng.integers(1, 101, n).astype(np.int64)
+    k2 = rng.integers(-50, 50, n).astype(np.int64)
+    k3 = rng.integers(1, 30_001, n).astype(np.int64)
+    if hot:  # two tuples own 2 % and 0.5 % of the rows
+        h = rng.random(n)
+        k1[h < 0.02], k2[h < 0.02], k3[h < 0.02] = 7, -3, 11
+        sel = (h >= 0.02) & (h < 0.025)
+        k1[sel], k2[sel], k3[sel] = 99, 49, 29_999
+    keys = [Column("a", k1), Column("b", k2, rng.random(n) >= 0.01), Column("c", k3)]
+    values = [rand_col(rng, "v", np.int64, n, lo=-10**9, hi=10**9), rand_col(rng, "w", np.float64, n, null_frac=0.1)]
+    aggs = [(0, "sum"), (0, "min"), (0, "max"), (1, "sum"), (1, "mean"), (0, "count")]
+    check_parity(oracle, keys, values, aggs, "tilesort2", what=f"leaf sort hot={hot}")
+    assert pa.last_strategy() == "leafsort"
+    got = check_parity(oracle, keys, values, aggs, "auto", what=f"leaf sort under AUTO hot={hot}")
+    assert pa.last_strategy() == "leafsort" and got.height > n // 2
 
 
 def test_two_levels_vs_oracle_mid_size(oracle):
