@@ -16,8 +16,12 @@
  *     applies to both;
  *   - `location` says where the buffers live: host memory (the library stages them through pinned
  *     buffers) or device memory of the current HIP device (zero-copy; what bench.py uses);
- *   - all entry points are thread safe; calls that run concurrently on one device serialise on that
- *     device's stream pool;
+ *   - all entry points are thread safe.  Every host thread owns a context: the device it is bound to, a HIP stream
+ *     of its own, a grow-only workspace (about the largest query's working set) and its settings (strategy, last
+ *     error, timings are per thread).  Calls from different threads do NOT serialise: they run on their own streams
+ *     and the GPU interleaves them.  The only shared state is the pool of result buffers (locked, keyed by device)
+ *     and the static array of plhip_group_by_agg_noalloc (see there).  A thread's context is released when the
+ *     thread ends; plhip_release_workspace() gives the workspace back earlier;
  *   - there is NO CPU fallback: without a usable HIP device every compute entry point fails with
  *     PLHIP_ERR_NO_DEVICE.
  */
@@ -183,13 +187,26 @@ int32_t plhip_abi_version(void);
  * Reference analogue: the global rayon POOL (crates/polars-core/src/lib.rs:49-62). */
 int32_t plhip_init(int32_t device_id);
 
+/* Frees the calling thread's grow-only workspace (hash tables, partitioned copies, partial dumps: sized by the largest
+ * query the thread has run) and the pooled result buffers of its device.  The stream stays; the next call re-grows
+ * what it needs.  The reference analogue is dropping the per-thread hash tables at the end of a query
+ * (crates/polars-core/src/frame/group_by/hashing.rs:380-468 builds them per call); here they are kept between calls
+ * because hipMalloc costs more than a small query. */
+int32_t plhip_release_workspace(void);
+
+/* Result buffers currently pooled for `device_id` (diagnostic: the pool is keyed by device, a buffer of one GPU is
+ * never handed to a thread bound to another). */
+int64_t plhip_pooled_buffers(int32_t device_id);
+
 /* Message for the calling thread's last non-OK status ("" if none). Never NULL. */
 const char *plhip_last_error(void);
 
+/* Forces a strategy for the CALLING THREAD's later calls (the setting is per thread, like the context);
+ * PLHIP_STRATEGY_AUTO restores the library's choice and overrides the PLHIP_STRATEGY environment variable. */
 int32_t plhip_set_strategy(int32_t strategy /* plhip_strategy_t */);
 
-/* Name of the strategy the last plhip_group_by_agg call on this thread ran
- * ("global", "lds", "partitioned"); the POLARS_VERBOSE analogue
+/* Name of the strategy the last plhip_group_by_agg call on this thread ran ("global", "lds", "partitioned",
+ * "direct", "tilesort", "tilesort2", "leafsort", "sort", "sorted_keys", "dense"); the POLARS_VERBOSE analogue
  * (crates/polars-lazy/src/physical_plan/executors/group_by.rs:124-126). */
 const char *plhip_last_strategy(void);
 
@@ -231,6 +248,11 @@ int32_t plhip_vec_hash(const plhip_column_t *keys, int32_t n_keys, uint64_t null
  *   MEAN  f32 -> f32, everything else -> f64; all-null group -> null
  *   MIN/MAX own dtype; floats ignore NaN; all-null group -> null
  *   COUNT u32
+ * Float sums: the reference folds a group's values left to right in row order per thread and then adds the
+ * threads' partials; here f64 (and f32, folded in f64 and rounded once) sums are re-associated -- LDS / global atomics
+ * and fixed-order merges of per-workgroup partials -- so SUM / MEAN / VAR of floats agree with the reference to
+ * |err| <= 1e-12 * sum|x| of the group (f64; 1e-5 relative for f32 columns), not bit for bit, and the atomic part can
+ * differ between runs in the last bits.  Integer results, counts, keys and validity are bit-exact.
  * Errors: n_keys == 0 -> PLHIP_ERR_COMPUTE; length mismatch -> PLHIP_ERR_SHAPE_MISMATCH
  * (group_by/mod.rs:59-73). */
 int32_t plhip_group_by_agg(const plhip_column_t *keys, int32_t n_keys, const plhip_column_t *values,

@@ -165,6 +165,10 @@ def lib():
     L.plhip_group_by_agg_noalloc.argtypes = [P(ColumnStruct), i32, P(ColumnStruct), i32, P(AggStruct), i32, u32, i64,
                                              P(ColumnStruct), i32, P(i64)]
     L.plhip_group_by_agg_noalloc.restype = i32
+    L.plhip_release_workspace.argtypes = []
+    L.plhip_release_workspace.restype = i32
+    L.plhip_pooled_buffers.argtypes = [i32]
+    L.plhip_pooled_buffers.restype = i64
     L.plhip_result_num_rows.argtypes = [vp]
     L.plhip_result_num_rows.restype = i64
     L.plhip_result_num_columns.argtypes = [vp]
@@ -221,5 +225,5 @@ EXPORTED_SYMBOLS = [
     "plhip_result_num_columns", "plhip_result_column", "plhip_result_free", "plhip_group_tuples",
     "plhip_groups_num_groups", "plhip_groups_num_rows", "plhip_groups_buffers", "plhip_groups_free",
     "plhip_agg_groups", "plhip_agg_groups_quantile", "plhip_result_record_bytes", "plhip_result_pack_by_owner", "plhip_records_to_frame", "plhip_merge_records", "plhip_finalize_partial", "plhip_slot_bytes", "plhip_result_pack_slots", "plhip_merge_slots",
-    "plhip_group_by_agg_noalloc",
+    "plhip_group_by_agg_noalloc", "plhip_release_workspace", "plhip_pooled_buffers",
 ]

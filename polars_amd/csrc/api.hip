@@ -45,6 +45,7 @@ struct Scratch { // grow-only device buffer reused across calls (hipMalloc/hipFr
     if (e == hipSuccess) bytes = want;
     return e;
   }
+  void release() { if (p) hipFree(p); p = nullptr; bytes = 0; }
 };
 
 struct Ctx {
@@ -67,6 +68,25 @@ struct Ctx {
   bool hot_clean = false;  // the heavy-hitter words behind the flag block (FLAGS_HOT_OFF ..) are zero
   int timing_pending = 0; // 1: direct, 2: tilesort (S == 1), 3: tilesort + merge -- event times not read yet
   uint8_t *na_scratch = nullptr; // device address of this GPU's static scratch array (plhip_group_by_agg_noalloc)
+  // the grow-only workspace of this thread (roughly the largest query's working set): back to the driver
+  void release_workspace() {
+    if (device < 0) return;
+    if (hipSetDevice(device) != hipSuccess) return;
+    if (stream) hipStreamSynchronize(stream);
+    for (Scratch *b : {&table, &slots, &sortkeys, &flags, &misc, &rank, &plans, &items, &part, &dump, &hdr, &offs}) b->release();
+    flags_clean = false; hot_clean = false; timing_pending = 0;
+  }
+  // A thread that ends gives back what it holds: workspace, stream, events, pinned words.  (Threads still alive when the
+  // process exits are not unwound; the main thread's context is, before the HIP runtime's own static teardown.)
+  ~Ctx() {
+    if (device < 0) return;
+    release_workspace();
+    for (auto &e : ev) if (e) hipEventDestroy(e);
+    if (host_flags) hipHostFree(host_flags);
+    if (host_sig) hipHostFree(host_sig);
+    if (stream) hipStreamDestroy(stream);
+    device = -1;
+  }
 };
 
 // the flag block: 64 bytes of flags, then the single-level tile sort's heavy-hitter words (rows in long runs and done counters
@@ -210,18 +230,21 @@ struct ResultCol {
 
 namespace {
 // Device buffers of result frames are recycled: hipMalloc / hipFree cost more than a whole small query.
+// Entries are keyed by (device, size): a thread bound to one GPU must never be handed another GPU's memory.
 struct DevPool {
+  struct Entry { int dev; size_t cap; void *p; };
   std::mutex mu;
-  std::vector<std::pair<size_t, void *>> free_list;
+  std::vector<Entry> free_list;
   size_t pooled = 0;
   static size_t round_up(size_t b) { size_t c = 4096; while (c < b) c <<= 1; return c; }
-  hipError_t get(size_t bytes, void **p, size_t *cap) {
+  // a buffer of the CURRENT device `dev` (the calling thread's Ctx::device)
+  hipError_t get(int dev, size_t bytes, void **p, size_t *cap) {
     const size_t c = round_up(bytes);
     {
       std::lock_guard<std::mutex> g(mu);
       for (size_t i = 0; i < free_list.size(); i++)
-        if (free_list[i].first == c) {
-          *p = free_list[i].second; *cap = c; pooled -= c;
+        if (free_list[i].dev == dev && free_list[i].cap == c) {
+          *p = free_list[i].p; *cap = c; pooled -= c;
           free_list[i] = free_list.back(); free_list.pop_back();
           return hipSuccess;
         }
@@ -229,13 +252,30 @@ struct DevPool {
     *cap = c;
     return hipMalloc(p, c);
   }
-  void put(void *p, size_t cap) {
+  void put(int dev, void *p, size_t cap) {
     if (!p) return;
     {
       std::lock_guard<std::mutex> g(mu);
-      if (pooled + cap <= ((size_t)4 << 30) && free_list.size() < 256) { free_list.emplace_back(cap, p); pooled += cap; return; }
+      if (pooled + cap <= ((size_t)4 << 30) && free_list.size() < 256) { free_list.push_back(Entry{dev, cap, p}); pooled += cap; return; }
     }
     hipFree(p);
+  }
+  // test hook / trim: how many pooled buffers belong to `dev`
+  int64_t count(int dev) {
+    std::lock_guard<std::mutex> g(mu);
+    int64_t k = 0;
+    for (auto &e : free_list) k += e.dev == dev;
+    return k;
+  }
+  void trim(int dev) { // hands every pooled buffer of `dev` back to the driver
+    std::vector<void *> drop;
+    {
+      std::lock_guard<std::mutex> g(mu);
+      for (size_t i = 0; i < free_list.size();)
+        if (free_list[i].dev == dev) { drop.push_back(free_list[i].p); pooled -= free_list[i].cap; free_list[i] = free_list.back(); free_list.pop_back(); }
+        else i++;
+    }
+    for (void *q : drop) hipFree(q);
   }
 };
 DevPool g_pool;
@@ -250,8 +290,8 @@ struct plhip_result {
   ~plhip_result() {
     for (auto &c : cols) {
       if (on_device) {
-        if (c.vcap) g_pool.put(c.values, c.vcap); else if (c.values) hipFree(c.values);
-        if (c.bcap) g_pool.put(c.validity, c.bcap); else if (c.validity) hipFree(c.validity);
+        if (c.vcap) g_pool.put(device, c.values, c.vcap); else if (c.values) hipFree(c.values);
+        if (c.bcap) g_pool.put(device, c.validity, c.bcap); else if (c.validity) hipFree(c.validity);
       } else { free(c.values); free(c.validity); }
     }
   }
@@ -331,7 +371,12 @@ int dense_ids(const std::vector<KeyCol> &sub, int64_t n, Staging &st, KeyCol &ou
   Plan K{};
   K.n_rows = n;
   K.single_key = 0; // nulls are codes: a null tuple member must get an id like any other value
-  pack_keys(K, sub);
+  if (sub.size() == 1 && sub[0].bits > 64) { // a nullable column spanning all 2^64 values: no code is left for its null,
+    std::vector<KeyCol> one = sub;           // so it is encoded alone with the single-key rules (null -> the reserved slot)
+    one[0].lo = 0; one[0].bits = 64; one[0].nullable = false;
+    K.single_key = 1;
+    pack_keys(K, one);
+  } else pack_keys(K, sub);
   const uint64_t cap = next_pow2(std::max<uint64_t>(2 * (uint64_t)n, 1024));
   plan_layout(K, cap + 2);
   HIP_TRY(c.table.reserve(table_bytes(K, cap + 2)));
@@ -387,11 +432,7 @@ int build_keys(Plan &P, const std::vector<DevCol> &keys, Staging &st, KeyGather 
     std::stable_sort(cols.begin(), cols.end(), [](const KeyCol &a, const KeyCol &b) { return a.bits > b.bits; });
     std::vector<KeyCol> sub;
     size_t take = 0;
-    if (cols[0].bits > 64) { // 64-bit span plus nulls: split off the null flag by encoding the column alone
-      // a single nullable full-range column: encode it through the single-key path semantics
-      return fail(PLHIP_ERR_UNSUPPORTED_DTYPE, "a nullable key column spans the full 64-bit range inside a wide key tuple");
-    }
-    if (cols[0].bits > 32) take = 1;
+    if (cols[0].bits > 32) take = 1; // (65 bits = a nullable column over the full 64-bit range: dense_ids encodes it alone)
     else { int t = 0; while (take < cols.size() && t + (int)cols[take].bits <= 64) { t += (int)cols[take].bits; take++; } }
     sub.assign(cols.begin(), cols.begin() + take);
     KeyCol enc;
@@ -930,6 +971,7 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
   }
   const uint32_t lslots = (1u << lbits) + 66; // hashed slots + sentinel + null + 64 trash slots (fast_path.hip)
   const uint64_t out_cap = direct ? (uint64_t)lslots << mbits : (uint64_t)n_pg * lslots;
+  if (out_cap >= (1ull << 31)) return PLHIP_OK; // the host signal word carries the group count in 31 bits: decline, the sort strategy / general path take it
 
   // ---- scratch ---------------------------------------------------------------------------------------------
   DumpRef D{};
@@ -965,7 +1007,8 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
   }
 
   // ---- outputs (sized by the table capacities; G is only known at the end) ---------------------------------
-  plhip_result *R = new (std::nothrow) plhip_result();
+  std::unique_ptr<plhip_result> R_own(new (std::nothrow) plhip_result()); // freed on every early return
+  plhip_result *R = R_own.get();
   if (!R) return fail(PLHIP_ERR_OOM, "host allocation failed");
   R->on_device = true;
   R->device = c.device;
@@ -982,13 +1025,13 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
     OutSpec o = L.outs[i];
     ResultCol col;
     col.dtype = (int)o.dtype;
-    hipError_t e = g_pool.get((size_t)out_cap * dtype_width((int)o.dtype), &col.values, &col.vcap);
+    hipError_t e = g_pool.get(g_ctx.device, (size_t)out_cap * dtype_width((int)o.dtype), &col.values, &col.vcap);
     if (e == hipSuccess && o.validity) {
-      e = g_pool.get((size_t)(out_cap / 64 + 2) * 8, (void **)&col.validity, &col.bcap);
+      e = g_pool.get(g_ctx.device, (size_t)(out_cap / 64 + 2) * 8, (void **)&col.validity, &col.bcap);
       if (e == hipSuccess) e = hipMemsetAsync(col.validity, 0, (size_t)(out_cap / 64 + 2) * 8, c.stream);
     }
     R->cols.push_back(col);
-    if (e != hipSuccess) { delete R; return fail_hip(e, "hipMalloc(output)"); }
+    if (e != hipSuccess) { return fail_hip(e, "hipMalloc(output)"); }
     o.values = (uint8_t *)col.values;
     o.validity = col.validity;
     OP.outs[i] = o;
@@ -1007,13 +1050,13 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
     FoldRowsArgs A{};
     A.D = D; A.flags = dflags; A.rows_per_item = rows_per_item; A.kxor = kxor; A.lbits = lbits; A.keymode = keymode; A.mbits = mbits;
     launch_fold_rows(P, A, key_bytes, quad, n_items, block, c.stream);
-    if ((e = hipGetLastError()) != hipSuccess) { delete R; return fail_hip(e, "k_fold_rows launch"); }
+    if ((e = hipGetLastError()) != hipSuccess) { return fail_hip(e, "k_fold_rows launch"); }
     c.strategy = "direct";
   } else {
     // runs of 4x the mean length and more are added up per partition
     TileSortLevel1 HL{nullptr, nullptr, 0u, 0u, hot_self ? self_hot : nullptr, 4u * (uint32_t)TS_TILE / np, 0u, hot_self ? self_hot - 2 : nullptr};
     launch_tile_sort(P, O, pbits, n_tiles, (uint32_t *)c.offs.p, keymode, kxor, key_bytes, c.stream, &HL);
-    if ((e = hipGetLastError()) != hipSuccess) { delete R; return fail_hip(e, "k_tile_sort launch"); }
+    if ((e = hipGetLastError()) != hipSuccess) { return fail_hip(e, "k_tile_sort launch"); }
     hipEventRecord(c.ev[4], c.stream);
     Plan P2 = P; // the fold pass reads the sorted copies
     for (int v = 0; v < P.n_vals; v++) { // the key specs stay: k_fold_runs reads the packed keys from A.pkeys
@@ -1031,7 +1074,7 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
       A.hot_min_rows = 4 * A.hot_chunk_rows;
     }
     launch_fold_runs(P2, A, OP, key_bytes, block, c.stream);
-    if ((e = hipGetLastError()) != hipSuccess) { delete R; return fail_hip(e, "k_fold_runs launch"); }
+    if ((e = hipGetLastError()) != hipSuccess) { return fail_hip(e, "k_fold_runs launch"); }
     c.strategy = "tilesort";
   }
   hipEventRecord(c.ev[5], c.stream);
@@ -1041,7 +1084,7 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
   const bool merged = direct || S > 1;
   if (merged) {
     launch_merge_emit(P, M, OP, key_bytes, direct ? 1u : n_pg, 1024, c.stream);
-    if ((e = hipGetLastError()) != hipSuccess) { delete R; return fail_hip(e, "k_merge_emit launch"); }
+    if ((e = hipGetLastError()) != hipSuccess) { return fail_hip(e, "k_merge_emit launch"); }
     hipEventRecord(c.ev[2], c.stream);
   }
   e = hipGetLastError();
@@ -1049,19 +1092,19 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
   if (e == hipSuccess) {
     TableRef t{nullptr, 0, dflags};
     int rc = wait_signal(t, seq, fl);
-    if (rc) { delete R; return rc; }
+    if (rc) { return rc; }
     // for the next query (the heavy-hitter words too: one memset)
     if (hipMemsetAsync(dflags, 0, hot_self ? FLAGS_HOT_OFF + FLAGS_HOT_WORDS * 4 : 64, c.stream) == hipSuccess) {
       c.flags_clean = true;
       if (hot_self) c.hot_clean = true;
     }
-  } else { delete R; return fail_hip(e, "group-by kernels"); }
+  } else { return fail_hip(e, "group-by kernels"); }
   c.timing_pending = direct ? 1 : (merged ? 3 : 2);
-  if (fl[FLAG_OVERFLOW]) { delete R; return PLHIP_OK; } // estimate too low: the general path redoes the query
+  if (fl[FLAG_OVERFLOW]) { return PLHIP_OK; } // estimate too low: the general path redoes the query
   const uint64_t G = fl[FLAG_NGROUPS];
   R->n_rows = (int64_t)G;
   handled = true;
-  return finish_result(R, G, flags, out);
+  return finish_result(R_own.release(), G, flags, out);
 }
 
 
@@ -1348,7 +1391,7 @@ int run_dense(const Lowered &L0, const std::vector<DevCol> &dk, uint32_t flags, 
   A.dump = (uint8_t *)c.dump.p;
   uint32_t *dflags = (uint32_t *)c.flags.p;
   A.flags = dflags;
-  const uint64_t out_cap = A.n_slots;
+  const uint64_t out_cap = A.n_slots; // (< 2^31: groups_hint is bounded in run_dense's first line, and the signal word holds 31 bits)
   // ---- outputs --------------------------------------------------------------------------------------------------
   std::unique_ptr<plhip_result> R_(new (std::nothrow) plhip_result());
   if (!R_) return fail(PLHIP_ERR_OOM, "host allocation failed");
@@ -1362,9 +1405,9 @@ int run_dense(const Lowered &L0, const std::vector<DevCol> &dk, uint32_t flags, 
     OutSpec o = L.outs[i];
     ResultCol col;
     col.dtype = (int)o.dtype;
-    hipError_t e = g_pool.get((size_t)out_cap * dtype_width((int)o.dtype), &col.values, &col.vcap);
+    hipError_t e = g_pool.get(g_ctx.device, (size_t)out_cap * dtype_width((int)o.dtype), &col.values, &col.vcap);
     if (e == hipSuccess && o.validity) {
-      e = g_pool.get((size_t)(out_cap / 64 + 2) * 8, (void **)&col.validity, &col.bcap);
+      e = g_pool.get(g_ctx.device, (size_t)(out_cap / 64 + 2) * 8, (void **)&col.validity, &col.bcap);
       if (e == hipSuccess) e = hipMemsetAsync(col.validity, 0, (size_t)(out_cap / 64 + 2) * 8, c.stream);
     }
     R_->cols.push_back(col);
@@ -1478,6 +1521,7 @@ int run_two_level(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, uint64_t 
   const uint32_t lslots = (1u << lbits) + 66;
   const uint64_t n_items = (uint64_t)np1 * np2;
   const uint64_t out_cap = std::min<uint64_t>((uint64_t)n, n_items * lslots);
+  if (out_cap >= (1ull << 31)) return PLHIP_OK; // the host signal word carries the group count in 31 bits: decline, the sort strategy / general path take it
   // ---- scratch -------------------------------------------------------------------------------------------------
   const int64_t tile_rows1 = (int64_t)PART_SCATTER_R * 1024;
   const uint32_t n_tiles1 = (uint32_t)std::max<int64_t>(1, (n + tile_rows1 - 1) / tile_rows1);
@@ -1524,7 +1568,8 @@ int run_two_level(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, uint64_t 
     B.valid[v] = P.vals[v].validity ? pb + off_valid[v] : nullptr;
   }
   // ---- outputs ---------------------------------------------------------------------------------------------------
-  plhip_result *R = new (std::nothrow) plhip_result();
+  std::unique_ptr<plhip_result> R_own(new (std::nothrow) plhip_result()); // freed on every early return
+  plhip_result *R = R_own.get();
   if (!R) return fail(PLHIP_ERR_OOM, "host allocation failed");
   R->on_device = true; R->device = c.device;
   OutPlan OP{};
@@ -1536,13 +1581,13 @@ int run_two_level(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, uint64_t 
     OutSpec o = L.outs[i];
     ResultCol col;
     col.dtype = (int)o.dtype;
-    hipError_t e = g_pool.get((size_t)out_cap * dtype_width((int)o.dtype), &col.values, &col.vcap);
+    hipError_t e = g_pool.get(g_ctx.device, (size_t)out_cap * dtype_width((int)o.dtype), &col.values, &col.vcap);
     if (e == hipSuccess && o.validity) {
-      e = g_pool.get((size_t)(out_cap / 64 + 2) * 8, (void **)&col.validity, &col.bcap);
+      e = g_pool.get(g_ctx.device, (size_t)(out_cap / 64 + 2) * 8, (void **)&col.validity, &col.bcap);
       if (e == hipSuccess) e = hipMemsetAsync(col.validity, 0, (size_t)(out_cap / 64 + 2) * 8, c.stream);
     }
     R->cols.push_back(col);
-    if (e != hipSuccess) { delete R; return fail_hip(e, "hipMalloc(output)"); }
+    if (e != hipSuccess) { return fail_hip(e, "hipMalloc(output)"); }
     o.values = (uint8_t *)col.values; o.validity = col.validity;
     OP.outs[i] = o;
   }
@@ -1568,7 +1613,7 @@ int run_two_level(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, uint64_t 
     launch_part_scatter(P, A, pbits1, tile_rows1, n_tiles1, counts, pstart, c.stream);
   }
   hipError_t e = hipGetLastError();
-  if (e != hipSuccess) { delete R; return fail_hip(e, "level-1 partition launch"); }
+  if (e != hipSuccess) { return fail_hip(e, "level-1 partition launch"); }
   // ---- level 2 -----------------------------------------------------------------------------------------------------
   Plan P1 = P; // reads the level-1 copies: plain packed-key column, byte validity
   P1.n_rows = (int64_t)n_pad;
@@ -1580,7 +1625,7 @@ int run_two_level(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, uint64_t 
   // (with the leaf sort in front, the heavy-hitter plan is made only if some leaves are left for k_fold_runs: it is one
   // workgroup walking every leaf, 0.45 ms at 262 144 leaves)
   if (hot_on && !leaf_sort) launch_hot_plan(hot_rows, (uint32_t)n_items, np2, pstart, hot_min, hot_chunk, max_extra, hot_state, c.stream);
-  if ((e = hipGetLastError()) != hipSuccess) { delete R; return fail_hip(e, "level-2 k_tile_sort launch"); }
+  if ((e = hipGetLastError()) != hipSuccess) { return fail_hip(e, "level-2 k_tile_sort launch"); }
   hipEventRecord(c.ev[4], c.stream);
   Plan P2 = P; // the key specs stay: the fold decodes the packed keys with them
   for (int v = 0; v < P.n_vals; v++) { P2.vals[v].values = B.vals[v]; P2.vals[v].validity = B.valid[v]; P2.vals[v].boff = 0; P2.vals[v].valid_bytes = 1; }
@@ -1598,15 +1643,15 @@ int run_two_level(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, uint64_t 
   bool fold_needed = true;
   if (leaf_sort) { // a wave per leaf sorts and folds it; the leaves that do not fit (skew) are left to k_fold_runs below
     hipError_t er = c.rank.reserve((size_t)n_items + 256);
-    if (er != hipSuccess) { delete R; return fail_hip(er, "leaf flags"); }
+    if (er != hipSuccess) { return fail_hip(er, "leaf flags"); }
     LeafSortArgs Al{};
     Al.pkeys = B.keys; Al.offs = (const uint32_t *)c.offs.p; Al.seg_start = pstart; Al.n_pg = np2; Al.S = np1; Al.n_tiles = n_tiles2;
     Al.n_leaves = (uint32_t)n_items; Al.flags = dflags; Al.handled = (uint8_t *)c.rank.p; Al.out_cap = out_cap;
     Al.host_sig = c.host_sig_dev; Al.seq = seq;
     launch_leaf_sort(P2, Al, OP, key_bytes, c.stream);
-    if ((e = hipGetLastError()) != hipSuccess) { delete R; return fail_hip(e, "k_leaf_sort launch"); }
+    if ((e = hipGetLastError()) != hipSuccess) { return fail_hip(e, "k_leaf_sort launch"); }
     rc = wait_signal(t, seq, fl);
-    if (rc) { delete R; return rc; }
+    if (rc) { return rc; }
     const uint32_t left = __atomic_load_n(&c.host_sig[2], __ATOMIC_ACQUIRE); // (the stream has drained: the word is final)
     fold_needed = left != 0 && !fl[FLAG_OVERFLOW];
     if (fold_needed) {
@@ -1619,24 +1664,23 @@ int run_two_level(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, uint64_t 
   } else c.strategy = "tilesort2";
   if (fold_needed) {
     launch_fold_runs(P2, Af, OP, key_bytes, dbg_blk ? (uint32_t)atoi(dbg_blk) : ((uint64_t)n / n_items >= 8192 ? 512u : 256u), c.stream);
-    if ((e = hipGetLastError()) != hipSuccess) { delete R; return fail_hip(e, "leaf k_fold_runs launch"); }
+    if ((e = hipGetLastError()) != hipSuccess) { return fail_hip(e, "leaf k_fold_runs launch"); }
   }
   hipEventRecord(c.ev[5], c.stream);
   if (fold_needed) {
     rc = wait_signal(t, Af.seq, fl);
-    if (rc) { delete R; return rc; }
+    if (rc) { return rc; }
   }
   if (hipMemsetAsync(dflags, 0, 64, c.stream) == hipSuccess) c.flags_clean = true;
   c.timing_pending = 2;
   if (fl[FLAG_OVERFLOW]) { // a leaf table overflowed: the estimate was too low
     if (overflowed) *overflowed = true;
-    delete R;
     return PLHIP_OK;
   }
   const uint64_t G = fl[FLAG_NGROUPS];
   R->n_rows = (int64_t)G;
   handled = true;
-  return finish_result(R, G, flags, out);
+  return finish_result(R_own.release(), G, flags, out);
 }
 
 // The sort strategy (sort_path.hip): any number of groups, any skew; also serves wide key tuples (output keys
@@ -1698,7 +1742,8 @@ int run_sorted(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, plhip_result
   TableRef t{nullptr, 0, dflags};
   if ((rc = read_flags(t, fl))) return rc;
   const uint64_t G = fl[FLAG_NGROUPS];
-  plhip_result *R = new (std::nothrow) plhip_result();
+  std::unique_ptr<plhip_result> R_own(new (std::nothrow) plhip_result()); // freed on every early return
+  plhip_result *R = R_own.get();
   if (!R) return fail(PLHIP_ERR_OOM, "host allocation failed");
   R->on_device = true; R->device = c.device; R->n_rows = (int64_t)G;
   OutPlan OP{};
@@ -1707,13 +1752,13 @@ int run_sorted(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, plhip_result
     OutSpec o = L.outs[i];
     ResultCol col;
     col.dtype = (int)o.dtype;
-    hipError_t e = g_pool.get((size_t)std::max<uint64_t>(G, 1) * dtype_width((int)o.dtype), &col.values, &col.vcap);
+    hipError_t e = g_pool.get(g_ctx.device, (size_t)std::max<uint64_t>(G, 1) * dtype_width((int)o.dtype), &col.values, &col.vcap);
     if (e == hipSuccess && o.validity) {
-      e = g_pool.get((size_t)(G / 64 + 2) * 8, (void **)&col.validity, &col.bcap);
+      e = g_pool.get(g_ctx.device, (size_t)(G / 64 + 2) * 8, (void **)&col.validity, &col.bcap);
       if (e == hipSuccess) e = hipMemsetAsync(col.validity, 0, (size_t)(G / 64 + 2) * 8, c.stream);
     }
     R->cols.push_back(col);
-    if (e != hipSuccess) { delete R; return fail_hip(e, "hipMalloc(output)"); }
+    if (e != hipSuccess) { return fail_hip(e, "hipMalloc(output)"); }
     o.values = (uint8_t *)col.values;
     o.validity = col.validity;
     OP.outs[i] = o;
@@ -1747,7 +1792,7 @@ int run_sorted(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, plhip_result
   hipEventRecord(c.ev[5], c.stream);
   hipEventRecord(c.ev[3], c.stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
-  if (e != hipSuccess) { delete R; return fail_hip(e, "sort strategy kernels"); }
+  if (e != hipSuccess) { return fail_hip(e, "sort strategy kernels"); }
   hipEventElapsedTime(&c.total_ms, c.ev[0], c.ev[3]);
   c.k_ms[0] = c.k_ms[1] = c.k_ms[2] = 0.f;
   hipEventElapsedTime(&c.k_ms[0], c.ev[1], c.ev[4]);
@@ -1757,7 +1802,7 @@ int run_sorted(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, plhip_result
   c.dom_kernel = c.k_ms[0] >= c.k_ms[1] ? (keys_sorted ? "k_sorted_run_flags+run scan" : "k_pack_rows+rocprim radix sort+run scan") : "k_fold_sorted";
   c.strategy = keys_sorted ? "sorted_keys" : "sort";
   handled = true;
-  return finish_result(R, G, flags, out);
+  return finish_result(R_own.release(), G, flags, out);
 }
 
 } // namespace
@@ -1784,6 +1829,17 @@ int32_t plhip_init(int32_t device_id) {
 }
 
 const char *plhip_last_error(void) { return g_ctx.err.c_str(); }
+
+int32_t plhip_release_workspace(void) {
+  Ctx &c = g_ctx;
+  if (c.device < 0) return PLHIP_OK;
+  resolve_timing();
+  c.release_workspace();
+  g_pool.trim(c.device);
+  return PLHIP_OK;
+}
+
+int64_t plhip_pooled_buffers(int32_t device_id) { return g_pool.count(device_id); }
 
 int32_t plhip_set_strategy(int32_t strategy) {
   if (strategy < 0 || strategy > PLHIP_STRATEGY_DENSE) return fail(PLHIP_ERR_INVALID, "bad strategy");
@@ -2110,7 +2166,8 @@ int32_t group_by_agg_impl(const plhip_column_t *keys, int32_t n_keys, const plhi
   }
 
   // ---- outputs ---------------------------------------------------------------------------------------
-  plhip_result *R = new (std::nothrow) plhip_result();
+  std::unique_ptr<plhip_result> R_own(new (std::nothrow) plhip_result()); // freed on every early return
+  plhip_result *R = R_own.get();
   if (!R) return fail(PLHIP_ERR_OOM, "host allocation failed");
   R->n_rows = (int64_t)G;
   R->on_device = true; // until copied
@@ -2125,7 +2182,7 @@ int32_t group_by_agg_impl(const plhip_column_t *keys, int32_t n_keys, const plhi
     hipError_t e = hipMalloc(&rcnew.values, vb);
     if (e == hipSuccess && o.validity) e = hipMalloc((void **)&rcnew.validity, (G / 64 + 1) * 8);
     R->cols.push_back(rcnew);
-    if (e != hipSuccess) { delete R; return fail_hip(e, "hipMalloc(output)"); }
+    if (e != hipSuccess) { return fail_hip(e, "hipMalloc(output)"); }
     o.values = (uint8_t *)rcnew.values;
     o.validity = rcnew.validity;
     O.outs[i] = o;
@@ -2137,7 +2194,7 @@ int32_t group_by_agg_impl(const plhip_column_t *keys, int32_t n_keys, const plhi
   HIP_TRY(hipEventRecord(c.ev[3], c.stream));
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
-  if (e != hipSuccess) { delete R; return fail_hip(e, "group-by kernels"); }
+  if (e != hipSuccess) { return fail_hip(e, "group-by kernels"); }
   hipEventElapsedTime(&c.total_ms, c.ev[0], c.ev[3]);
   {
     // dominant kernel: the aggregation pass, or the partition scatter when that is the longer one
@@ -2152,7 +2209,7 @@ int32_t group_by_agg_impl(const plhip_column_t *keys, int32_t n_keys, const plhi
     } else { c.dom_ms = t_all; c.part_ms = 0.f; c.agg_ms = t_all; }
   }
 
-  return finish_result(R, G, flags, out);
+  return finish_result(R_own.release(), G, flags, out);
 }
 
 int64_t plhip_result_num_rows(const plhip_result_t *r) { return r ? r->n_rows : -1; }
@@ -2308,7 +2365,8 @@ static int32_t agg_groups_impl(const plhip_column_t *values, int32_t kind, const
       offsets = (const uint32_t *)d_off; indices = (const uint32_t *)d_idx;
     }
     const bool moment = kind == PLHIP_AGG_VAR || kind == PLHIP_AGG_STD || kind == PLHIP_AGG_MEDIAN || kind == AGG_EXT_QUANTILE; // float-valued results
-    plhip_result *R = new (std::nothrow) plhip_result();
+    std::unique_ptr<plhip_result> R_own(new (std::nothrow) plhip_result()); // freed on every early return
+    plhip_result *R = R_own.get();
     if (!R) return fail(PLHIP_ERR_OOM, "host allocation failed");
     R->n_rows = (int64_t)G; R->on_device = true; R->device = c.device;
     ResultCol col;
@@ -2318,13 +2376,13 @@ static int32_t agg_groups_impl(const plhip_column_t *values, int32_t kind, const
     if (e == hipSuccess) e = hipMalloc((void **)&col.validity, (G / 64 + 1) * 8);
     if (e == hipSuccess) e = hipMemsetAsync(col.validity, 0, (G / 64 + 1) * 8, c.stream);
     R->cols.push_back(col);
-    if (e != hipSuccess) { delete R; return fail_hip(e, "hipMalloc(output)"); }
+    if (e != hipSuccess) { return fail_hip(e, "hipMalloc(output)"); }
     AggExtArgs A{};
     A.values = dv.values; A.validity = dv.validity; A.boff = dv.boff; A.dtype = (uint32_t)dv.dtype; A.width = (uint32_t)dtype_width(dv.dtype);
     A.kind = (uint32_t)kind; A.ddof = (flags >> 8) & 0xFFu; A.out_dtype = (uint32_t)col.dtype;
     A.out = (uint8_t *)col.values; A.out_validity = col.validity;
     if (kind == PLHIP_AGG_MEDIAN || kind == PLHIP_AGG_N_UNIQUE || kind == AGG_EXT_QUANTILE) {
-      if (n > 0x7FFFFFFFll) { delete R; return fail(PLHIP_ERR_INVALID, "too many rows for the segmented sort"); }
+      if (n > 0x7FFFFFFFll) { return fail(PLHIP_ERR_INVALID, "too many rows for the segmented sort"); }
       size_t tb = 0;
       e = median_temp_bytes((uint64_t)n, G, &tb);
       const size_t n8 = ((size_t)std::max<int64_t>(n, 1) * 8 + 255) & ~(size_t)255;
@@ -2342,8 +2400,8 @@ static int32_t agg_groups_impl(const plhip_column_t *values, int32_t kind, const
       e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
-    if (e != hipSuccess) { delete R; return fail_hip(e, "agg_groups"); }
-    return finish_result(R, G, flags & PLHIP_FLAG_OUTPUT_DEVICE, out);
+    if (e != hipSuccess) { return fail_hip(e, "agg_groups"); }
+    return finish_result(R_own.release(), G, flags & PLHIP_FLAG_OUTPUT_DEVICE, out);
   }
   Staging st;
   std::vector<DevCol> dv;
@@ -2368,7 +2426,8 @@ static int32_t agg_groups_impl(const plhip_column_t *values, int32_t kind, const
     if (n) HIP_TRY(hipMemcpyAsync(d_idx, groups->indices, (size_t)n * 4, hipMemcpyHostToDevice, c.stream));
     offsets = (const uint32_t *)d_off; indices = (const uint32_t *)d_idx;
   }
-  plhip_result *R = new (std::nothrow) plhip_result();
+  std::unique_ptr<plhip_result> R_own(new (std::nothrow) plhip_result()); // freed on every early return
+  plhip_result *R = R_own.get();
   if (!R) return fail(PLHIP_ERR_OOM, "host allocation failed");
   R->n_rows = (int64_t)G; R->on_device = true; R->device = c.device;
   OutPlan OP{};
@@ -2382,14 +2441,14 @@ static int32_t agg_groups_impl(const plhip_column_t *values, int32_t kind, const
     if (e == hipSuccess) e = hipMemsetAsync(col.validity, 0, (G / 64 + 1) * 8, c.stream);
   }
   R->cols.push_back(col);
-  if (e != hipSuccess) { delete R; return fail_hip(e, "hipMalloc(output)"); }
+  if (e != hipSuccess) { return fail_hip(e, "hipMalloc(output)"); }
   o.values = (uint8_t *)col.values; o.validity = col.validity;
   OP.outs[0] = o;
   launch_agg_groups(L.P, OP, offsets, indices, G, G > 0 && (uint64_t)n / G >= 64, c.stream);
   e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
-  if (e != hipSuccess) { delete R; return fail_hip(e, "agg_groups"); }
-  return finish_result(R, G, flags & PLHIP_FLAG_OUTPUT_DEVICE, out);
+  if (e != hipSuccess) { return fail_hip(e, "agg_groups"); }
+  return finish_result(R_own.release(), G, flags & PLHIP_FLAG_OUTPUT_DEVICE, out);
 }
 
 // ---- exchange step of the row-sharded group-by (exchange.hip) ----------------------------------------------
@@ -2489,7 +2548,8 @@ int32_t plhip_agg_groups_quantile(const plhip_column_t *values, const plhip_grou
     int rc = ensure_ctx();
     if (rc) return rc;
     const uint64_t G = (uint64_t)groups->n_groups;
-    plhip_result *R = new (std::nothrow) plhip_result();
+    std::unique_ptr<plhip_result> R_own(new (std::nothrow) plhip_result()); // freed on every early return
+    plhip_result *R = R_own.get();
     if (!R) return fail(PLHIP_ERR_OOM, "host allocation failed");
     R->n_rows = (int64_t)G; R->on_device = true; R->device = g_ctx.device;
     ResultCol col;
@@ -2500,8 +2560,8 @@ int32_t plhip_agg_groups_quantile(const plhip_column_t *values, const plhip_grou
     if (e == hipSuccess) e = hipMemsetAsync(col.validity, 0, (G / 64 + 1) * 8, g_ctx.stream);
     R->cols.push_back(col);
     if (e == hipSuccess) e = hipStreamSynchronize(g_ctx.stream);
-    if (e != hipSuccess) { delete R; return fail_hip(e, "hipMalloc(output)"); }
-    return finish_result(R, G, flags & PLHIP_FLAG_OUTPUT_DEVICE, out);
+    if (e != hipSuccess) { return fail_hip(e, "hipMalloc(output)"); }
+    return finish_result(R_own.release(), G, flags & PLHIP_FLAG_OUTPUT_DEVICE, out);
   }
   return agg_groups_impl(values, AGG_EXT_QUANTILE, groups, flags, quantile, interpolation, out);
 }
@@ -2548,8 +2608,8 @@ int records_to_frame_impl(const void *records, int64_t n_rows, const int32_t *dt
   for (int i = 0; i < n_cols; i++) {
     ResultCol col;
     col.dtype = dtypes[i];
-    hipError_t e = g_pool.get((size_t)std::max<int64_t>(n_rows, 1) * R.width[i], &col.values, &col.vcap);
-    if (e == hipSuccess && nullable[i]) e = g_pool.get((size_t)(n_rows / 64 + 2) * 8, (void **)&col.validity, &col.bcap);
+    hipError_t e = g_pool.get(g_ctx.device, (size_t)std::max<int64_t>(n_rows, 1) * R.width[i], &col.values, &col.vcap);
+    if (e == hipSuccess && nullable[i]) e = g_pool.get(g_ctx.device, (size_t)(n_rows / 64 + 2) * 8, (void **)&col.validity, &col.bcap);
     F->cols.push_back(col);
     if (e != hipSuccess) { delete F; return fail_hip(e, "hipMalloc(frame)"); }
     R.values[i] = (const uint8_t *)col.values; R.validity[i] = col.validity; R.boff[i] = 0;
@@ -2610,13 +2670,15 @@ int merge_impl(const void *records, int64_t n_rows, const int32_t *dtypes, const
   std::vector<plhip_agg_t> aggs(nv);
   for (int i = 0; i < nv; i++) {
     if (merge_kinds[i] != PLHIP_AGG_SUM && merge_kinds[i] != PLHIP_AGG_MIN && merge_kinds[i] != PLHIP_AGG_MAX) {
+      hipStreamSynchronize(g_ctx.stream); // k_unpack is still writing F's columns
       delete F;
       return fail(PLHIP_ERR_INVALID, "partials merge by sum, min or max");
     }
     aggs[i].column = i; aggs[i].kind = merge_kinds[i];
   }
   rc = plhip_group_by_agg_opts(cols.data(), n_keys, cols.data() + n_keys, nv, aggs.data(), nv, flags, opts, out);
-  delete F; // the group-by has synchronised the stream
+  if (rc) hipStreamSynchronize(g_ctx.stream); // a failed group-by may have left k_unpack / its own kernels queued: F's buffers go back to the pool
+  delete F; // (on success the group-by has synchronised the stream)
   return rc;
 }
 } // namespace

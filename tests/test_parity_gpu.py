@@ -889,6 +889,39 @@ def test_db_benchmark_full_size_vs_oracle(oracle, workload, expect, hint):
     util.assert_frames_match(got, util.oracle_to_np(want), len(keys), what=f"{workload} 1e7 rows")
 
 
+@pytest.mark.parametrize("workload,dense,expect", [("q3", True, ("dense",)), ("q3", False, ("tilesort",)), ("q1", True, ("direct", "dense")), ("q5", False, ("tilesort",))])
+def test_db_benchmark_na_variant_full_size_vs_oracle(oracle, workload, dense, expect):
+    """db-benchmark's NA variant (groupby-datagen.R:30-44) at BASELINE config 2's size: 5 % of the distinct values of the
+    key are nulled (so the null key is a heavy group), 5 % of every value column is NA.  Whole frame against the oracle."""
+    import torch
+
+    import bench
+    from polars_amd import h2oai
+
+    n = 10_000_000
+    keys_n, vals_n, aggs, wide = bench.WORKLOADS[workload]
+    tensors = h2oai.generate(n, seed=108, device=torch.device("cuda:0"), wide=wide, columns=keys_n + vals_n, na=True)
+    cols = h2oai.to_columns(tensors, wide)
+    keys, vals = [cols[k] for k in keys_n], [cols[v] for v in vals_n]
+    assert all(c.validity is not None for c in keys + vals), "the NA variant carries validity on every column"
+    hint = keys[0].n_categories or 0
+    codes = [(ci, _ffi.AGG_NAMES[k]) for ci, k in aggs]
+    from polars_amd.frame import _host_column
+    handle, out = pa.group_by_agg_raw(keys, vals, codes, _ffi.FLAG_KEYS_DENSE if dense else 0, hint)
+    try:
+        got = [_host_column(str(i), cs) for i, cs in enumerate(out)]
+    finally:
+        _ffi.lib().plhip_result_free(handle)
+    assert pa.last_strategy() in expect
+    got = [(c.to_numpy(), c.valid_mask()) for c in got]
+    host = {k: v.cpu().numpy() for k, v in tensors.items()}
+    mk = lambda c: Column(c.name, host[c.name].view(np.uint32) if c.dtype == _ffi.U32 else host[c.name], host[c.name + "__valid"])
+    want, _ = oracle.group_by_agg([mk(c) for c in keys], [mk(c) for c in vals], aggs, n_threads=8)
+    w = util.oracle_to_np(want)
+    assert w[0][1] is not None and not w[0][1].all(), "the null key must be a group of its own"
+    util.assert_frames_match(got, w, len(keys), what=f"{workload} NA variant, 1e7 rows")
+
+
 def test_wrong_hints_cost_time_not_correctness(oracle):
     n = 2_000_000
     tensors, keys, vals, aggs, _ = _bench_frame("q3", n)
