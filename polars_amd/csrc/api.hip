@@ -256,7 +256,9 @@ struct DevPool {
     if (!p) return;
     {
       std::lock_guard<std::mutex> g(mu);
-      if (pooled + cap <= ((size_t)4 << 30) && free_list.size() < 256) { free_list.push_back(Entry{dev, cap, p}); pooled += cap; return; }
+      // sized for 288 GB of HBM: a one-row-per-group result at 1e8 rows is 7 GB of output columns, and handing them to
+      // hipFree / hipMalloc every query costs more than a millisecond
+      if (pooled + cap <= ((size_t)48 << 30) && free_list.size() < 256) { free_list.push_back(Entry{dev, cap, p}); pooled += cap; return; }
     }
     hipFree(p);
   }

@@ -951,7 +951,11 @@ __global__ void __launch_bounds__(1024) k_fold_runs(Plan P, FoldRunsArgs A, OutP
   // A chunk of a split leaf has few tiles with long runs: a wave then takes ONE tile per batch and cuts its run into
   // RUNS_B segments (the batch elements), so that all waves work and a 2 000-row run takes 4 trips instead of 32.
   const bool cut = chunks > 1 && (t1 - t0) * 2u <= nw * (uint32_t)RUNS_B;
-  const uint32_t TB = cut ? 1u : (uint32_t)RUNS_B; // tiles per wave batch
+  // Otherwise a wave takes the runs of 64 tiles at once (lane l: the bounds of tile t + l) and lays their rows out FLAT:
+  // batch element f of the concatenated runs goes to lane f % 64, whatever run it belongs to.  Runs are short when there are
+  // many partitions (8192-row tiles over 512 partitions: 16 rows), and a lane-per-row-of-ONE-run mapping would leave
+  // three lanes of four idle on every load, probe and atomic.
+  const uint32_t TB = cut ? 1u : 64u; // tiles per wave batch
   uint32_t t = t0 + wave * TB;
   uint32_t st = 0, len = 0;
   if (lane < TB && t + lane < t1) { st = o0[t + lane]; len = o1[t + lane] - st; }
@@ -959,8 +963,8 @@ __global__ void __launch_bounds__(1024) k_fold_runs(Plan P, FoldRunsArgs A, OutP
     const uint32_t tn = t + nw * TB;
     uint32_t stn = 0, lenn = 0;
     if (lane < TB && tn + lane < t1) { stn = o0[tn + lane]; lenn = o1[tn + lane] - stn; }
-    uint32_t s_[RUNS_B], n_[RUNS_B], maxlen = 0;
     if (cut) {
+      uint32_t s_[RUNS_B], n_[RUNS_B], maxlen = 0;
       const uint32_t st0 = (uint32_t)__builtin_amdgcn_readlane((int)st, 0) + t * (uint32_t)TS_TILE;
       const uint32_t len0 = (uint32_t)__builtin_amdgcn_readlane((int)len, 0), sg = (len0 + RUNS_B - 1) / RUNS_B;
 #pragma unroll
@@ -970,31 +974,62 @@ __global__ void __launch_bounds__(1024) k_fold_runs(Plan P, FoldRunsArgs A, OutP
         n_[b] = off < len0 ? (len0 - off < sg ? len0 - off : sg) : 0u;
         maxlen = n_[b] > maxlen ? n_[b] : maxlen;
       }
-    } else {
+      // dead lanes still look their (clamped) row's key up: an empty segment must not point them at another
+      // partition's rows, so it borrows the start of a segment that has rows
+      uint32_t s_any = s_[0];
 #pragma unroll
-    for (int b = 0; b < RUNS_B; b++) {
-      s_[b] = (uint32_t)__builtin_amdgcn_readlane((int)st, b) + (t + b) * (uint32_t)TS_TILE;
-      n_[b] = (uint32_t)__builtin_amdgcn_readlane((int)len, b);
-      maxlen = n_[b] > maxlen ? n_[b] : maxlen;
-    }
-    }
-    // dead lanes still look their (clamped) row's key up: an empty run must not point them at another
-    // partition's rows, so it borrows the start of a run of this batch that has rows
-    uint32_t s_any = s_[0];
+      for (int b = 0; b < RUNS_B; b++) if (n_[b]) s_any = s_[b];
 #pragma unroll
-    for (int b = 0; b < RUNS_B; b++) if (n_[b]) s_any = s_[b];
+      for (int b = 0; b < RUNS_B; b++) if (!n_[b]) s_[b] = s_any;
+      for (uint32_t i0 = 0; i0 < maxlen; i0 += 64) {
+        uint32_t row[RUNS_B];
+        uint32_t live = 0;
+        const uint32_t i = i0 + lane;
 #pragma unroll
-    for (int b = 0; b < RUNS_B; b++) if (!n_[b]) s_[b] = s_any;
-    for (uint32_t i0 = 0; i0 < maxlen; i0 += 64) {
-      uint32_t row[RUNS_B];
-      uint32_t live = 0;
-      const uint32_t i = i0 + lane;
-#pragma unroll
-      for (int b = 0; b < RUNS_B; b++) {
-        if (i < n_[b]) live |= 1u << b;
-        row[b] = s_[b] + (i < n_[b] ? i : 0); // dead lanes read the run's first row (or the padded row behind the data)
+        for (int b = 0; b < RUNS_B; b++) {
+          if (i < n_[b]) live |= 1u << b;
+          row[b] = s_[b] + (i < n_[b] ? i : 0); // dead lanes read the segment's first row
+        }
+        fold_batch<KS, RUNS_B, false, RUNS_NPRE, SH>(P, fsm, A.lbits, sh, row, live, keymode, A.pkeys, 0ull, null_pg, A.pbits);
       }
-      fold_batch<KS, RUNS_B, false, RUNS_NPRE, SH>(P, fsm, A.lbits, sh, row, live, keymode, A.pkeys, 0ull, null_pg, A.pbits);
+    } else {
+      const uint32_t astart = st + (t + lane) * (uint32_t)TS_TILE; // first row of lane's run in the sorted copy
+      uint32_t incl = len;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
+        if (lane >= (uint32_t)off) incl += up;
+      }
+      const uint32_t excl = incl - len;
+      const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+      // the run that holds flat element f: r = the number of runs that end at or before f (f < total: r <= 63)
+      auto run_of = [&](uint32_t f) -> uint32_t {
+        uint32_t lo = 0;
+#pragma unroll
+        for (uint32_t step = 32; step; step >>= 1) {
+          const uint32_t v = (uint32_t)__shfl((int)incl, (int)(lo + step - 1));
+          if (v <= f) lo += step;
+        }
+        return lo;
+      };
+      if (total) {
+        // dead lanes still look a row's key up: they take the batch's first row (a row of THIS partition)
+        const uint32_t s_any = (uint32_t)__shfl((int)astart, (int)run_of(0u));
+        for (uint32_t i0 = 0; i0 < total; i0 += 64u * RUNS_B) {
+          uint32_t row[RUNS_B];
+          uint32_t live = 0;
+#pragma unroll
+          for (int b = 0; b < RUNS_B; b++) {
+            const uint32_t f = i0 + (uint32_t)b * 64u + lane;
+            const uint32_t r = run_of(f) & 63u;
+            const uint32_t rs = (uint32_t)__shfl((int)astart, (int)r), re = (uint32_t)__shfl((int)excl, (int)r);
+            const bool lv = f < total;
+            if (lv) live |= 1u << b;
+            row[b] = lv ? rs + (f - re) : s_any;
+          }
+          fold_batch<KS, RUNS_B, false, RUNS_NPRE, SH>(P, fsm, A.lbits, sh, row, live, keymode, A.pkeys, 0ull, null_pg, A.pbits);
+        }
+      }
     }
     t = tn; st = stn; len = lenn;
   }

@@ -252,30 +252,68 @@ void launch_encode_rows(const Plan &p, TableRef t, const uint32_t *rank, uint32_
 // ---------------------------------------------------------------------------------------------------------
 // key range pre-pass (multi-key tuples)
 // ---------------------------------------------------------------------------------------------------------
+// 4- and 8-byte columns without nulls stream as 16-byte vectors, four requests in flight per lane (the scalar loop below ran
+// at 2.8 TB/s: one 8-byte load per lane per trip); everything else (narrow types, validity bitmaps) keeps the scalar loop.
+typedef uint32_t mm_u32x4 __attribute__((ext_vector_type(4)));
+DEVINL void mm_fold(uint64_t v, uint64_t &lo, uint64_t &hi) { lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+template <int W>
+DEVINL void mm_fold_vec(const mm_u32x4 &q, uint64_t x, uint64_t &lo, uint64_t &hi) {
+  if (W == 8) {
+    mm_fold(((uint64_t)q.x | ((uint64_t)q.y << 32)) ^ x, lo, hi);
+    mm_fold(((uint64_t)q.z | ((uint64_t)q.w << 32)) ^ x, lo, hi);
+  } else {
+    mm_fold((uint64_t)(q.x ^ (uint32_t)x), lo, hi); mm_fold((uint64_t)(q.y ^ (uint32_t)x), lo, hi);
+    mm_fold((uint64_t)(q.z ^ (uint32_t)x), lo, hi); mm_fold((uint64_t)(q.w ^ (uint32_t)x), lo, hi);
+  }
+}
+template <int W>
+DEVINL void mm_stream(const uint8_t *values, int64_t n_rows, uint64_t x, uint64_t &lo, uint64_t &hi) {
+  const mm_u32x4 *p = (const mm_u32x4 *)values;
+  const int64_t nv = n_rows * W / 16; // whole vectors; the last rows are block 0's
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < nv; i += 4 * stride) {
+    const mm_u32x4 a = __builtin_nontemporal_load(p + i), b = __builtin_nontemporal_load(p + i + stride);
+    const mm_u32x4 c = __builtin_nontemporal_load(p + i + 2 * stride), d = __builtin_nontemporal_load(p + i + 3 * stride);
+    mm_fold_vec<W>(a, x, lo, hi); mm_fold_vec<W>(b, x, lo, hi); mm_fold_vec<W>(c, x, lo, hi); mm_fold_vec<W>(d, x, lo, hi);
+  }
+  for (; i < nv; i += stride) mm_fold_vec<W>(p[i], x, lo, hi);
+  if (blockIdx.x == 0) {
+    const int64_t r = nv * (16 / W) + threadIdx.x;
+    if (r < n_rows) mm_fold(W == 8 ? ((const uint64_t *)values)[r] ^ x : (uint64_t)(((const uint32_t *)values)[r] ^ (uint32_t)x), lo, hi);
+  }
+}
+
 __global__ void __launch_bounds__(256) k_key_minmax(Plan P, uint64_t *minmax) {
   const int k = blockIdx.y;
   const KeySpec &K = P.keys[k];
   uint64_t lo = ~0ull, hi = 0;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < P.n_rows; row += stride) {
-    if (!bit_valid(K.validity, K.boff, row)) continue;
-    const uint64_t v = load_key_norm(K.values, K.dtype, row);
-    lo = v < lo ? v : lo;
-    hi = v > hi ? v : hi;
+  const uint32_t dt = K.dtype;
+  const bool vec = !K.validity && (((uintptr_t)K.values) & 15) == 0; // (uniform over the workgroup)
+  if (vec && (dt == PLHIP_I64 || dt == PLHIP_U64 || dt == PLHIP_F64)) {
+    mm_stream<8>(K.values, P.n_rows, dt == PLHIP_I64 ? SIGN64 : 0ull, lo, hi);
+  } else if (vec && (dt == PLHIP_I32 || dt == PLHIP_U32 || dt == PLHIP_F32)) {
+    mm_stream<4>(K.values, P.n_rows, dt == PLHIP_I32 ? 0x80000000ull : 0ull, lo, hi);
+  } else {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < P.n_rows; row += stride) {
+      if (!bit_valid(K.validity, K.boff, row)) continue;
+      mm_fold(load_key_norm(K.values, K.dtype, row), lo, hi);
+    }
   }
   for (int off = 32; off > 0; off >>= 1) {
     const uint64_t l2 = __shfl_xor(lo, off), h2 = __shfl_xor(hi, off);
     lo = l2 < lo ? l2 : lo;
     hi = h2 > hi ? h2 : hi;
   }
-  if ((threadIdx.x & 63) == 0) {
+  if ((threadIdx.x & 63) == 0 && lo <= hi) {
     atomicMin((unsigned long long *)&minmax[2 * k], (unsigned long long)lo);
     atomicMax((unsigned long long *)&minmax[2 * k + 1], (unsigned long long)hi);
   }
 }
 
 void launch_key_minmax(const Plan &p, uint64_t *minmax, hipStream_t s) {
-  int64_t blocks = (p.n_rows + 1023) / 1024;
+  int64_t blocks = (p.n_rows + 4095) / 4096;
   int grid = (int)(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks));
   hipLaunchKernelGGL(k_key_minmax, dim3(grid, p.n_keys), dim3(256), 0, s, p, minmax);
 }
