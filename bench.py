@@ -49,7 +49,7 @@ def skewed_keys(n, ids, seed, device):
     u = torch.rand(n, device=device, dtype=torch.float64, generator=g).clamp_min(1e-300)
     z = torch.floor(u.pow(-10.0)).clamp_max(float(ids) * 1e6)
     del u
-    coin = torch.rand(n, device=device, generator=g) < 0.5
+    coin = torch.rand(n, device=device, generator=g) < float(os.environ.get("PLHIP_BENCH_ZIPF_SHARE", "0.5"))  # (experiments: 0 = uniform ids)
     uni = torch.floor(torch.rand(n, device=device, dtype=torch.float64, generator=g) * ids)
     k = torch.where(coin, (z - 1) % ids, uni).to(torch.int64)
     del z, coin, uni

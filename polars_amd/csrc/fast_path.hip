@@ -1282,7 +1282,11 @@ using ShWide = StShape<USeq<PLHIP_I64, PLHIP_F64>,                              
                             ACC_ENC(ACC_ADD_F64, CONV_F64, 1, 8)>>;
 using ShSumF64 = StShape<USeq<PLHIP_F64>, USeq<ACC_ENC(ACC_ADD_F64, CONV_F64, 0, 8)>>;
 using ShSumI64 = StShape<USeq<PLHIP_I64>, USeq<ACC_ENC(ACC_ADD_U64, CONV_INT, 0, 8)>>;
-#define FP_SHAPES(X) X(0, ShSumI32) X(1, ShSumI32MeanF64) X(2, ShSum3) X(3, ShWide) X(4, ShSumF64) X(5, ShSumI64)
+using ShWideF = StShape<USeq<PLHIP_F64, PLHIP_I64>,                                        // the same with the f64 column first (config 5)
+                        USeq<ACC_ENC(ACC_CNT_ALL, CONV_NONE, -1, 4), ACC_ENC(ACC_ADD_F64, CONV_F64, 0, 8),
+                             ACC_ENC(ACC_ADD_U64, CONV_INT, 1, 8), ACC_ENC(ACC_MIN_I64, CONV_INT, 1, 8),
+                             ACC_ENC(ACC_MAX_I64, CONV_INT, 1, 8)>>;
+#define FP_SHAPES(X) X(0, ShSumI32) X(1, ShSumI32MeanF64) X(2, ShSum3) X(3, ShWide) X(4, ShSumF64) X(5, ShSumI64) X(6, ShWideF)
 
 template <typename SH>
 bool shape_matches(const Plan &p) {
