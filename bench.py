@@ -281,6 +281,7 @@ def main():
         from polars_amd import distributed as pdist
 
         eng = pdist.HipEngine(dev)
+        eng.dense_keys = bool(qflags)  # the local pass takes the dense-code path as the single-GPU run does
 
         def step():
             res = pdist.group_by_agg_sharded(keys, vals, aggs, device=dev, engine=eng, n_groups_hint=hint, force_exchange=rehearse)
@@ -370,7 +371,7 @@ def main():
                                    f"{' (NA variant)' if args.na else ''}: {', '.join(f'{k}({vals_n[c]})' for c, k in aggs)} by "
                                    f"{','.join(keys_n)}, {n} rows per GPU, {groups_total} groups",
                        "strategy": strategy, "n_groups_hint": hint, "dense_codes": bool(qflags), "rows_per_gpu": n, "groups": int(groups_total),
-                       "exchange": "none" if world == 1 and not rehearse else "all_to_all_single of partial records (RCCL)"},
+                       "exchange": "none" if world == 1 and not rehearse else "plhip_group_by_agg_sharded: ncclSend/ncclRecv of partial records on the library's stream (RCCL)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_by_kernel": traffic_kernels,
                          "traffic_over_algorithmic": (traffic / abytes) if traffic else None, "kernel": dom_name,
@@ -382,7 +383,7 @@ def main():
         }
         if phases:  # shuffle bytes and time reported separately
             line["sharded_step_ms"] = {k: sum(p.get(k, 0.0) for p in phases) / len(phases) for k in phases[0]}
-            line["shuffle"] = {"bytes_sent_per_rank": eng.last_shuffle_bytes, "protocol": eng.last_protocol}
+            line["shuffle"] = {"bytes_sent_per_rank": eng.last_shuffle_bytes, "protocol": eng.last_protocol, "host_syncs_per_step": eng.last_host_syncs}
         if world == 1 and not rehearse and not args.no_cpu_baseline:
             def gpu_frame():  # the timed configuration once more, result copied to the host
                 handle, out = pa.group_by_agg_raw(keys, vals, agg_codes, qflags, hint)

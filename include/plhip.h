@@ -395,6 +395,64 @@ typedef struct plhip_final {
 int32_t plhip_finalize_partial(const plhip_result_t *merged, int32_t n_keys, const plhip_final_t *finals, int32_t n_finals,
                                const plhip_column_t *out_cols);
 
+
+/* ---- the sharded path: one rank per GPU, the exchange inside the library ------------------------------ */
+
+/* The reference's partitioned group-by (crates/polars-lazy/src/physical_plan/executors/group_by_partitioned.rs:273-361) runs
+ * the aggregation per thread on a slice of the rows, hands every partial to the owner of its hash partition (:320-360)
+ * and finalizes there (AggregationExpr::finalize, expressions/aggregation.rs:367-483).  Across GPUs the "threads" are
+ * ranks, one per GPU, and the hand-over is an all-to-all of packed partial records over xGMI.  A communicator carries
+ * the transport:
+ *   - RCCL: plhip_comm_unique_id on one rank, the 128 bytes sent to the others by the host's own means (MPI, a file,
+ *     torch.distributed), plhip_comm_init_rccl on every rank with its device bound (plhip_init).  The exchange is
+ *     ncclGroupStart; ncclSend / ncclRecv to and from every peer; ncclGroupEnd on the library's stream: xGMI is point to
+ *     point, so these n - 1 transfers ARE the all-to-all.  librccl.so is loaded at run time (PLHIP_RCCL_LIBRARY names
+ *     another copy); an RCCL the process already holds is shared.
+ *   - host transport: the host supplies blocking all-to-all functions over device buffers (a host with its own
+ *     communicator; the one-GPU rehearsals of the tests).  The library drains its stream before it calls them. */
+#define PLHIP_COMM_ID_BYTES 128
+typedef struct plhip_comm plhip_comm_t;
+/* peer p: send[p * bytes_per_peer, ...) -> the peer's recv[rank * bytes_per_peer, ...); 0 = success */
+typedef int32_t (*plhip_alltoall_fn)(void *user, const void *send, void *recv, size_t bytes_per_peer);
+/* variable split: byte counts per peer, buffers packed peer after peer */
+typedef int32_t (*plhip_alltoallv_fn)(void *user, const void *send, const int64_t *send_bytes, void *recv, const int64_t *recv_bytes);
+int32_t plhip_comm_unique_id(uint8_t id[PLHIP_COMM_ID_BYTES]);
+int32_t plhip_comm_init_rccl(const uint8_t id[PLHIP_COMM_ID_BYTES], int32_t world, int32_t rank, plhip_comm_t **comm);
+int32_t plhip_comm_init_host(int32_t world, int32_t rank, plhip_alltoall_fn all_to_all, plhip_alltoallv_fn all_to_all_v, void *user,
+                             plhip_comm_t **comm);
+void plhip_comm_free(plhip_comm_t *comm);
+
+/* plhip_group_by_agg_opts over the rows of ALL ranks of `comm`: every rank passes its shard (same schema on every
+ * rank: dtypes and which columns carry a validity bitmap) and gets its share of the groups, disjoint in the keys between
+ * ranks; the shares together are the result.  One call = the whole of PartitionGroupByExec across GPUs:
+ *   local pass with mergeable partials (PLHIP_FLAG_PARTIAL) -> records packed by owner = vec_hash(keys) % world
+ *   -> exchange -> unpack + regroup (sum of sums and counts, min of mins, max of maxs) -> finalize.
+ * With opts->n_groups_hint (a bound on the groups of the whole job, the same on every rank) the buckets travel in
+ * fixed-capacity slots: ONE equal-split exchange, no counts round trip; a bucket that does not fit says so in its slot
+ * header, every rank sees it and all fall back to the exact protocol (counts, then a variable-size exchange).
+ * PLHIP_FLAG_EXACT_EXCHANGE forces the exact protocol.  flags: PLHIP_FLAG_OUTPUT_DEVICE, PLHIP_FLAG_EXACT_EXCHANGE.
+ * Collective: every rank of the communicator must call it with the same query. */
+#define PLHIP_FLAG_EXACT_EXCHANGE 32u
+int32_t plhip_group_by_agg_sharded(plhip_comm_t *comm, const plhip_column_t *keys, int32_t n_keys, const plhip_column_t *values,
+                                   int32_t n_values, const plhip_agg_t *aggs, int32_t n_aggs, uint32_t flags,
+                                   const plhip_options_t *opts, plhip_result_t **out);
+
+/* What the last plhip_group_by_agg_sharded call on this thread did (BASELINE config 4 asks for the shuffle's bytes and
+ * time beside the compute): host wall-clock per phase, the kernels of the local pass (the pass over the rank's rows,
+ * which is what a roofline is quoted on), bytes this rank sent. */
+typedef struct plhip_sharded_stats {
+  float partial_ms, pack_ms, exchange_ms, merge_ms, finalize_ms; /* host wall clock per phase */
+  float partial_kernel_ms, partial_dominant_ms;                  /* device time of the local pass's kernels */
+  float partial_breakdown_ms[3];                                  /* as plhip_last_kernel_breakdown */
+  int64_t shuffle_bytes;                                          /* bytes this rank handed to the transport */
+  int64_t partial_groups;                                         /* groups of the local pass */
+  int32_t protocol;                                               /* 1: slots (one exchange); 2: exact (counts + variable) */
+  int32_t host_syncs;                                             /* times the host waited for the device in the call */
+  char partial_strategy[16];
+  char partial_dominant_kernel[32];
+} plhip_sharded_stats_t;
+int32_t plhip_sharded_last_stats(plhip_sharded_stats_t *stats);
+
 #ifdef __cplusplus
 }
 #endif

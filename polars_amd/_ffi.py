@@ -105,6 +105,20 @@ def code_np_dtype(code: int):
     return _CODE_TO_NP[code]
 
 
+class ShardedStats(C.Structure):
+    """plhip_sharded_stats_t"""
+    _fields_ = [("partial_ms", C.c_float), ("pack_ms", C.c_float), ("exchange_ms", C.c_float), ("merge_ms", C.c_float),
+                ("finalize_ms", C.c_float), ("partial_kernel_ms", C.c_float), ("partial_dominant_ms", C.c_float),
+                ("partial_breakdown_ms", C.c_float * 3), ("shuffle_bytes", C.c_int64), ("partial_groups", C.c_int64),
+                ("protocol", C.c_int32), ("host_syncs", C.c_int32), ("partial_strategy", C.c_char * 16),
+                ("partial_dominant_kernel", C.c_char * 32)]
+
+
+ALLTOALL_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+ALLTOALLV_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int64))
+COMM_ID_BYTES = 128
+FLAG_EXACT_EXCHANGE = 32
+
 LIB_PATH = Path(__file__).resolve().parent / "_lib" / "libplhip.so"
 _lib = None
 
@@ -165,6 +179,19 @@ def lib():
     L.plhip_group_by_agg_noalloc.argtypes = [P(ColumnStruct), i32, P(ColumnStruct), i32, P(AggStruct), i32, u32, i64,
                                              P(ColumnStruct), i32, P(i64)]
     L.plhip_group_by_agg_noalloc.restype = i32
+    L.plhip_comm_unique_id.argtypes = [vp]
+    L.plhip_comm_unique_id.restype = i32
+    L.plhip_comm_init_rccl.argtypes = [vp, i32, i32, P(vp)]
+    L.plhip_comm_init_rccl.restype = i32
+    L.plhip_comm_init_host.argtypes = [i32, i32, ALLTOALL_FN, ALLTOALLV_FN, vp, P(vp)]
+    L.plhip_comm_init_host.restype = i32
+    L.plhip_comm_free.argtypes = [vp]
+    L.plhip_comm_free.restype = None
+    L.plhip_group_by_agg_sharded.argtypes = [vp, P(ColumnStruct), i32, P(ColumnStruct), i32, P(AggStruct), i32, u32,
+                                             P(OptionsStruct), P(vp)]
+    L.plhip_group_by_agg_sharded.restype = i32
+    L.plhip_sharded_last_stats.argtypes = [P(ShardedStats)]
+    L.plhip_sharded_last_stats.restype = i32
     L.plhip_release_workspace.argtypes = []
     L.plhip_release_workspace.restype = i32
     L.plhip_pooled_buffers.argtypes = [i32]
@@ -226,4 +253,6 @@ EXPORTED_SYMBOLS = [
     "plhip_groups_num_groups", "plhip_groups_num_rows", "plhip_groups_buffers", "plhip_groups_free",
     "plhip_agg_groups", "plhip_agg_groups_quantile", "plhip_result_record_bytes", "plhip_result_pack_by_owner", "plhip_records_to_frame", "plhip_merge_records", "plhip_finalize_partial", "plhip_slot_bytes", "plhip_result_pack_slots", "plhip_merge_slots",
     "plhip_group_by_agg_noalloc", "plhip_release_workspace", "plhip_pooled_buffers",
+    "plhip_comm_unique_id", "plhip_comm_init_rccl", "plhip_comm_init_host", "plhip_comm_free", "plhip_group_by_agg_sharded",
+    "plhip_sharded_last_stats",
 ]

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstddef>
 #include <cstring>
+#include <chrono>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -18,6 +19,7 @@
 
 #include "../../include/plhip.h"
 #include "dense.hpp"
+#include "comm.hpp"
 #include "fast.hpp"
 #include "kernels.hpp"
 
@@ -67,13 +69,15 @@ struct Ctx {
   uint32_t seq = 0;
   bool hot_clean = false;  // the heavy-hitter words behind the flag block (FLAGS_HOT_OFF ..) are zero
   int timing_pending = 0; // 1: direct, 2: tilesort (S == 1), 3: tilesort + merge -- event times not read yet
+  Scratch xsend, xrecv, xcnt; // the sharded path's exchange buffers
+  plhip_sharded_stats_t shard_stats{};
   uint8_t *na_scratch = nullptr; // device address of this GPU's static scratch array (plhip_group_by_agg_noalloc)
   // the grow-only workspace of this thread (roughly the largest query's working set): back to the driver
   void release_workspace() {
     if (device < 0) return;
     if (hipSetDevice(device) != hipSuccess) return;
     if (stream) hipStreamSynchronize(stream);
-    for (Scratch *b : {&table, &slots, &sortkeys, &flags, &misc, &rank, &plans, &items, &part, &dump, &hdr, &offs}) b->release();
+    for (Scratch *b : {&table, &slots, &sortkeys, &flags, &misc, &rank, &plans, &items, &part, &dump, &hdr, &offs, &xsend, &xrecv, &xcnt}) b->release();
     flags_clean = false; hot_clean = false; timing_pending = 0;
   }
   // A thread that ends gives back what it holds: workspace, stream, events, pinned words.  (Threads still alive when the
@@ -2490,8 +2494,9 @@ int64_t plhip_result_record_bytes(const plhip_result_t *r) {
 }
 
 namespace {
+// counts == nullptr (slotted layout only): nobody waits for the device here, the receivers read the counts in the slot headers
 int pack_impl(const plhip_result_t *r, int32_t n_keys, uint64_t null_hash, int32_t n_parts, int64_t slot_rows, void *records, int64_t *counts) {
-  if (!r || !counts) return fail(PLHIP_ERR_INVALID, "NULL pointer");
+  if (!r || (!counts && !slot_rows)) return fail(PLHIP_ERR_INVALID, "NULL pointer");
   if (!r->on_device) return fail(PLHIP_ERR_INVALID, "the frame must be device-resident (PLHIP_FLAG_OUTPUT_DEVICE)");
   if (n_parts < 1 || n_parts > (slot_rows ? EX_MAX_SLOTS : EX_MAX_PARTS)) return fail(PLHIP_ERR_INVALID, "owner count out of range");
   if (n_keys < 1 || n_keys > (int)r->cols.size() || n_keys > PLHIP_MAX_KEYS) return fail(PLHIP_ERR_INVALID, "bad key count");
@@ -2504,7 +2509,7 @@ int pack_impl(const plhip_result_t *r, int32_t n_keys, uint64_t null_hash, int32
   R.n_keys = n_keys; R.n_parts = (uint32_t)n_parts;
   R.slot_rows = (uint32_t)slot_rows;
   R.slot_stride = slot_rows ? (uint64_t)EX_SLOT_HDR + (uint64_t)slot_rows * R.rec_bytes : 0;
-  for (int p = 0; p < n_parts; p++) counts[p] = 0;
+  if (counts) for (int p = 0; p < n_parts; p++) counts[p] = 0;
   const int64_t n = r->n_rows;
   if (n == 0 && !slot_rows) return PLHIP_OK;
   if (!records) return fail(PLHIP_ERR_INVALID, "records buffer is NULL");
@@ -2521,6 +2526,7 @@ int pack_impl(const plhip_result_t *r, int32_t n_keys, uint64_t null_hash, int32
   }
   launch_pack_records(R, d_owner, d_counts, d_cursor, (uint8_t *)records, c.stream);
   HIP_TRY(hipGetLastError());
+  if (!counts) return PLHIP_OK;
   std::vector<uint32_t> h(n_parts);
   HIP_TRY(hipMemcpyAsync(h.data(), d_counts, (size_t)n_parts * 4, hipMemcpyDeviceToHost, c.stream));
   HIP_TRY(hipStreamSynchronize(c.stream));
@@ -2570,6 +2576,7 @@ int32_t plhip_agg_groups_quantile(const plhip_column_t *values, const plhip_grou
 
 int32_t plhip_result_pack_by_owner(const plhip_result_t *r, int32_t n_keys, uint64_t null_hash, int32_t n_parts, void *records,
                                    int64_t *counts) {
+  if (!counts) return fail(PLHIP_ERR_INVALID, "NULL pointer");
   return pack_impl(r, n_keys, null_hash, n_parts, 0, records, counts);
 }
 
@@ -2578,6 +2585,7 @@ int64_t plhip_slot_bytes(int64_t record_bytes, int64_t slot_rows) { return EX_SL
 int32_t plhip_result_pack_slots(const plhip_result_t *r, int32_t n_keys, uint64_t null_hash, int32_t n_parts, int64_t slot_rows,
                                 void *records, int64_t *counts) {
   if (slot_rows < 1) return fail(PLHIP_ERR_INVALID, "bad slot capacity");
+  if (!counts) return fail(PLHIP_ERR_INVALID, "NULL pointer");
   return pack_impl(r, n_keys, null_hash, n_parts, slot_rows, records, counts);
 }
 
@@ -2743,6 +2751,239 @@ int32_t plhip_finalize_partial(const plhip_result_t *merged, int32_t n_keys, con
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(c.stream));
   return PLHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// the sharded path (comm.hip carries the transport)
+// ---------------------------------------------------------------------------------------------------------
+int32_t plhip_comm_unique_id(uint8_t id[PLHIP_COMM_ID_BYTES]) {
+  if (!id) return fail(PLHIP_ERR_INVALID, "NULL pointer");
+  std::string err;
+  const int rc = comm_unique_id(id, err);
+  return rc ? fail(rc, err) : PLHIP_OK;
+}
+
+int32_t plhip_comm_init_rccl(const uint8_t id[PLHIP_COMM_ID_BYTES], int32_t world, int32_t rank, plhip_comm_t **comm) {
+  if (!id || !comm) return fail(PLHIP_ERR_INVALID, "NULL pointer");
+  *comm = nullptr;
+  if (world < 1 || world > EX_MAX_PARTS || rank < 0 || rank >= world) return fail(PLHIP_ERR_INVALID, "bad world size / rank");
+  int rc = ensure_ctx(); // the calling thread's device is current: RCCL binds the communicator to it
+  if (rc) return rc;
+  std::string err;
+  rc = comm_init_rccl(id, world, rank, g_ctx.device, comm, err);
+  return rc ? fail(rc, err) : PLHIP_OK;
+}
+
+int32_t plhip_comm_init_host(int32_t world, int32_t rank, plhip_alltoall_fn all_to_all, plhip_alltoallv_fn all_to_all_v, void *user,
+                             plhip_comm_t **comm) {
+  if (!comm || !all_to_all || !all_to_all_v) return fail(PLHIP_ERR_INVALID, "NULL pointer");
+  *comm = nullptr;
+  if (world < 1 || world > EX_MAX_PARTS || rank < 0 || rank >= world) return fail(PLHIP_ERR_INVALID, "bad world size / rank");
+  int rc = ensure_ctx();
+  if (rc) return rc;
+  plhip_comm *c = new (std::nothrow) plhip_comm();
+  if (!c) return fail(PLHIP_ERR_OOM, "host allocation failed");
+  c->world = world; c->rank = rank; c->device = g_ctx.device; c->a2a = all_to_all; c->a2av = all_to_all_v; c->user = user;
+  *comm = c;
+  return PLHIP_OK;
+}
+
+void plhip_comm_free(plhip_comm_t *comm) { comm_free(comm); }
+
+int32_t plhip_sharded_last_stats(plhip_sharded_stats_t *stats) {
+  if (!stats) return fail(PLHIP_ERR_INVALID, "NULL pointer");
+  *stats = g_ctx.shard_stats;
+  return PLHIP_OK;
+}
+
+namespace {
+constexpr uint64_t EXCHANGE_NULL_HASH = 0x9E3779B97F4A7C15ull; // any constant: null keys only need to agree on an owner
+
+struct FrameGuard { // a device-resident intermediate frame: back to the pool on every path out
+  plhip_result_t *p = nullptr;
+  ~FrameGuard() { if (p) delete p; }
+};
+
+int sharded_impl(plhip_comm *comm, const plhip_column_t *keys, int32_t n_keys, const plhip_column_t *values, int32_t n_values,
+                 const plhip_agg_t *aggs, int32_t n_aggs, uint32_t flags, const plhip_options_t *opts, plhip_result_t **out) {
+  using clk = std::chrono::steady_clock;
+  Ctx &c = g_ctx;
+  plhip_sharded_stats_t &S = c.shard_stats;
+  S = plhip_sharded_stats_t{};
+  auto t0 = clk::now();
+  auto lap = [&](float &slot) { const auto t1 = clk::now(); slot += std::chrono::duration<float, std::milli>(t1 - t0).count(); t0 = t1; };
+  const int world = comm->world;
+  const int64_t hint = (opts && opts->struct_size >= 16 && opts->n_groups_hint > 0) ? opts->n_groups_hint : 0;
+  if (opts && opts->struct_size >= sizeof(plhip_options_t) && opts->has_slice) return fail(PLHIP_ERR_INVALID, "a slice cannot be pushed into the sharded path");
+  // ---- local pass: mergeable partials, device-resident -------------------------------------------------------------
+  FrameGuard part;
+  const uint32_t pflags = PLHIP_FLAG_PARTIAL | PLHIP_FLAG_OUTPUT_DEVICE | (flags & PLHIP_FLAG_KEYS_DENSE);
+  int rc = plhip_group_by_agg_opts(keys, n_keys, values, n_values, aggs, n_aggs, pflags, opts, &part.p);
+  if (rc) return rc;
+  resolve_timing();
+  S.partial_kernel_ms = c.total_ms; S.partial_dominant_ms = c.dom_ms;
+  S.partial_breakdown_ms[0] = c.k_ms[0]; S.partial_breakdown_ms[1] = c.k_ms[1]; S.partial_breakdown_ms[2] = c.k_ms[2];
+  snprintf(S.partial_strategy, sizeof(S.partial_strategy), "%s", c.strategy.c_str());
+  snprintf(S.partial_dominant_kernel, sizeof(S.partial_dominant_kernel), "%s", c.dom_kernel.c_str());
+  S.partial_groups = part.p->n_rows;
+  S.host_syncs = 1; // the local pass ends with the host waiting for its group count
+  lap(S.partial_ms);
+  // ---- the record layout: a property of the query's schema (build_aggs under PLHIP_FLAG_PARTIAL), the same on every rank
+  const int n_cols = (int)part.p->cols.size();
+  if (n_cols > PLHIP_MAX_OUTS) return fail(PLHIP_ERR_INVALID, "too many partial columns");
+  int32_t dts[PLHIP_MAX_OUTS];
+  uint8_t nul[PLHIP_MAX_OUTS];
+  int32_t kinds[PLHIP_MAX_OUTS];
+  {
+    int o = 0, nm = 0;
+    for (int k = 0; k < n_keys; k++, o++) { dts[o] = keys[k].dtype; nul[o] = keys[k].validity ? 1 : 0; }
+    for (int i = 0; i < n_aggs; i++) {
+      const int kind = aggs[i].kind;
+      if (kind == PLHIP_AGG_COUNT) { dts[o] = PLHIP_U64; nul[o++] = 0; kinds[nm++] = PLHIP_AGG_SUM; continue; }
+      const int dt = values[aggs[i].column].dtype;
+      const bool is_f = dt_is_float(dt), is_s = dt_is_signed(dt), nullable = values[aggs[i].column].validity != nullptr;
+      const int w = dtype_width(dt);
+      const int sum_dt = is_f ? PLHIP_F64 : ((is_s || w < 4) ? PLHIP_I64 : PLHIP_U64);
+      if (kind == PLHIP_AGG_SUM) { dts[o] = sum_dt; nul[o++] = 0; kinds[nm++] = PLHIP_AGG_SUM; }
+      else if (kind == PLHIP_AGG_MEAN) {
+        dts[o] = (!is_f && w <= 4) ? (is_s ? PLHIP_I64 : PLHIP_U64) : PLHIP_F64; nul[o++] = 0; kinds[nm++] = PLHIP_AGG_SUM;
+        dts[o] = PLHIP_U64; nul[o++] = 0; kinds[nm++] = PLHIP_AGG_SUM;
+      } else { dts[o] = dt; nul[o++] = nullable ? 1 : 0; kinds[nm++] = kind == PLHIP_AGG_MIN ? PLHIP_AGG_MIN : PLHIP_AGG_MAX; }
+      if (o > PLHIP_MAX_OUTS - 2) return fail(PLHIP_ERR_INVALID, "too many partial columns");
+    }
+    if (o != n_cols) return fail(PLHIP_ERR_COMPUTE, "the partial frame does not match the query's schema");
+    for (int i = 0; i < n_cols; i++)
+      if (part.p->cols[i].dtype != dts[i] || (part.p->n_rows > 0 && (part.p->cols[i].validity != nullptr) != (nul[i] != 0)))
+        return fail(PLHIP_ERR_COMPUTE, "the partial frame does not match the query's schema (column " + std::to_string(i) + ")");
+  }
+  RecPlan RL{};
+  if ((rc = rec_layout(RL, dts, nul, n_cols))) return rc;
+  const uint64_t rec = RL.rec_bytes;
+  std::string err;
+  FrameGuard merged;
+  plhip_options_t mo{};
+  mo.struct_size = 16;
+  bool done = false;
+  if (hint > 0 && world <= EX_MAX_SLOTS && !(flags & PLHIP_FLAG_EXACT_EXCHANGE)) {
+    // ---- slots: 1.25x an even share per owner; one equal-split exchange ---------------------------------------------
+    const int64_t slot_rows = (5 * hint + 4 * world - 1) / (4 * world) + 512;
+    const size_t stride = (size_t)plhip_slot_bytes((int64_t)rec, slot_rows);
+    HIP_TRY(c.xsend.reserve(stride * world + 256));
+    HIP_TRY(c.xrecv.reserve(stride * world + 256));
+    if (part.p->n_rows == 0) { // the packer would find no bitmaps to read a layout from: write empty slot headers directly
+      HIP_TRY(hipMemsetAsync(c.xsend.p, 0, stride * world, c.stream));
+    } else if ((rc = pack_impl(part.p, n_keys, EXCHANGE_NULL_HASH, world, slot_rows, c.xsend.p, nullptr))) return rc;
+    lap(S.pack_ms);
+    if ((rc = comm_all_to_all(comm, c.xsend.p, c.xrecv.p, stride, c.stream, err))) return fail(rc, err);
+    uint64_t hdr[EX_MAX_SLOTS][2];
+    HIP_TRY(hipMemcpy2DAsync(hdr, 16, c.xrecv.p, stride, 16, (size_t)world, hipMemcpyDeviceToHost, c.stream));
+    HIP_TRY(hipStreamSynchronize(c.stream)); // the exchange has landed; the headers say how many records every peer sent
+    S.host_syncs++;
+    S.shuffle_bytes = (int64_t)(stride * world);
+    S.protocol = 1;
+    lap(S.exchange_ms);
+    bool overflow = false;
+    int64_t rcnt[EX_MAX_SLOTS], m = 0;
+    for (int p = 0; p < world; p++) { overflow |= hdr[p][1] != 0; rcnt[p] = (int64_t)hdr[p][0]; m += rcnt[p]; }
+    // an overflowing bucket anywhere is seen by its receiver only: all ranks must agree on the protocol, so the flag is
+    // part of what every rank sends to EVERY peer (pack sets it in all of a rank's headers when any of its buckets overflows)
+    if (!overflow) {
+      mo.n_groups_hint = std::max<int64_t>(std::min<int64_t>(m, hint), 1);
+      rc = merge_impl(c.xrecv.p, m, dts, nul, n_cols, n_keys, kinds, PLHIP_FLAG_OUTPUT_DEVICE, &mo, &merged.p, world, slot_rows, rcnt);
+      if (rc) return rc;
+      S.host_syncs++;
+      lap(S.merge_ms);
+      done = true;
+    }
+  }
+  if (!done) {
+    // ---- exact protocol: counts, then a variable-size exchange -----------------------------------------------------------
+    const int64_t g = part.p->n_rows;
+    int64_t sc[EX_MAX_PARTS], rcv[EX_MAX_PARTS];
+    HIP_TRY(c.xsend.reserve((size_t)std::max<int64_t>(g, 1) * rec + 256));
+    if (g > 0) { if ((rc = pack_impl(part.p, n_keys, EXCHANGE_NULL_HASH, world, 0, c.xsend.p, sc))) return rc; S.host_syncs++; }
+    else for (int p = 0; p < world; p++) sc[p] = 0;
+    lap(S.pack_ms);
+    HIP_TRY(c.xcnt.reserve((size_t)world * 16 + 64));
+    int64_t *d_sc = (int64_t *)c.xcnt.p, *d_rc = d_sc + world;
+    HIP_TRY(hipMemcpyAsync(d_sc, sc, (size_t)world * 8, hipMemcpyHostToDevice, c.stream));
+    if ((rc = comm_all_to_all(comm, d_sc, d_rc, 8, c.stream, err))) return fail(rc, err);
+    HIP_TRY(hipMemcpyAsync(rcv, d_rc, (size_t)world * 8, hipMemcpyDeviceToHost, c.stream));
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    S.host_syncs++;
+    int64_t m = 0, sb[EX_MAX_PARTS], rb[EX_MAX_PARTS];
+    for (int p = 0; p < world; p++) {
+      if (rcv[p] < 0 || rcv[p] > 0xFFFFFFFFll) return fail(PLHIP_ERR_COMPUTE, "a peer announced an impossible record count");
+      m += rcv[p]; sb[p] = sc[p] * (int64_t)rec; rb[p] = rcv[p] * (int64_t)rec;
+    }
+    HIP_TRY(c.xrecv.reserve((size_t)std::max<int64_t>(m, 1) * rec + 256));
+    if ((rc = comm_all_to_all_v(comm, c.xsend.p, sb, c.xrecv.p, rb, c.stream, err))) return fail(rc, err);
+    S.shuffle_bytes = g * (int64_t)rec + (int64_t)world * 8;
+    S.protocol = 2;
+    lap(S.exchange_ms);
+    mo.n_groups_hint = std::max<int64_t>(hint > 0 ? std::min<int64_t>(m, hint) : m, 1);
+    rc = merge_impl(m ? c.xrecv.p : nullptr, m, dts, nul, n_cols, n_keys, kinds, PLHIP_FLAG_OUTPUT_DEVICE, &mo, &merged.p, 0, 0, nullptr);
+    if (rc) return rc;
+    S.host_syncs++;
+    lap(S.merge_ms);
+  }
+  // ---- finalize: (sum, count) -> mean, 64-bit partial sums -> the column's type (aggregation.rs:367-483) -------------
+  const int64_t G = merged.p->n_rows;
+  std::unique_ptr<plhip_result> R_own(new (std::nothrow) plhip_result());
+  plhip_result *R = R_own.get();
+  if (!R) return fail(PLHIP_ERR_OOM, "host allocation failed");
+  R->on_device = true; R->device = c.device; R->n_rows = G;
+  plhip_column_t ocols[PLHIP_MAX_OUTS];
+  plhip_final_t fin[PLHIP_MAX_OUTS];
+  if (n_keys + n_aggs > PLHIP_MAX_OUTS) return fail(PLHIP_ERR_INVALID, "too many output columns");
+  for (int o = 0; o < n_keys + n_aggs; o++) {
+    int dt; bool nullable;
+    if (o < n_keys) { dt = keys[o].dtype; nullable = keys[o].validity != nullptr; }
+    else {
+      const plhip_agg_t &a = aggs[o - n_keys];
+      const int sdt = a.kind == PLHIP_AGG_COUNT ? PLHIP_U32 : values[a.column].dtype;
+      const bool src_null = a.kind != PLHIP_AGG_COUNT && values[a.column].validity != nullptr;
+      fin[o - n_keys].kind = a.kind; fin[o - n_keys].src_dtype = sdt;
+      if (a.kind == PLHIP_AGG_COUNT) { dt = PLHIP_U32; nullable = false; }
+      else if (a.kind == PLHIP_AGG_SUM) { dt = dt_is_float(sdt) ? sdt : (dtype_width(sdt) < 4 ? PLHIP_I64 : sdt); nullable = false; }
+      else if (a.kind == PLHIP_AGG_MEAN) { dt = sdt == PLHIP_F32 ? PLHIP_F32 : PLHIP_F64; nullable = src_null; }
+      else { dt = sdt; nullable = src_null; }
+    }
+    ResultCol col;
+    col.dtype = dt;
+    hipError_t e = g_pool.get(c.device, (size_t)std::max<int64_t>(G, 1) * dtype_width(dt), &col.values, &col.vcap);
+    if (e == hipSuccess && nullable) e = g_pool.get(c.device, (size_t)(G / 64 + 2) * 8, (void **)&col.validity, &col.bcap);
+    R->cols.push_back(col);
+    if (e != hipSuccess) return fail_hip(e, "hipMalloc(output)");
+    ocols[o] = plhip_column_t{};
+    ocols[o].values = col.values; ocols[o].validity = col.validity; ocols[o].offset = 0; ocols[o].length = G; ocols[o].dtype = dt;
+    ocols[o].location = PLHIP_DEVICE;
+  }
+  if ((rc = plhip_finalize_partial(merged.p, n_keys, fin, n_aggs, ocols))) return rc;
+  if (G > 0) S.host_syncs++;
+  lap(S.finalize_ms);
+  return finish_result(R_own.release(), (uint64_t)G, flags & PLHIP_FLAG_OUTPUT_DEVICE, out);
+}
+} // namespace
+
+int32_t plhip_group_by_agg_sharded(plhip_comm_t *comm, const plhip_column_t *keys, int32_t n_keys, const plhip_column_t *values,
+                                   int32_t n_values, const plhip_agg_t *aggs, int32_t n_aggs, uint32_t flags,
+                                   const plhip_options_t *opts, plhip_result_t **out) {
+  if (!out) return fail(PLHIP_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  if (!comm) return fail(PLHIP_ERR_INVALID, "comm is NULL");
+  if (flags & ~(PLHIP_FLAG_OUTPUT_DEVICE | PLHIP_FLAG_EXACT_EXCHANGE | PLHIP_FLAG_KEYS_DENSE))
+    return fail(PLHIP_ERR_INVALID, "the sharded path takes PLHIP_FLAG_OUTPUT_DEVICE, PLHIP_FLAG_EXACT_EXCHANGE and PLHIP_FLAG_KEYS_DENSE only");
+  if (n_keys < 1) return fail(PLHIP_ERR_COMPUTE, "at least one key is required in a group_by operation");
+  if (!keys || n_keys > PLHIP_MAX_KEYS || n_values < 0 || n_aggs < 0 || (n_aggs > 0 && !aggs) || (n_values > 0 && !values))
+    return fail(PLHIP_ERR_INVALID, "bad arguments");
+  for (int i = 0; i < n_aggs; i++)
+    if (aggs[i].kind != PLHIP_AGG_COUNT && (aggs[i].kind < 0 || aggs[i].kind > PLHIP_AGG_COUNT || aggs[i].column < 0 || aggs[i].column >= n_values))
+      return fail(PLHIP_ERR_INVALID, "bad aggregation");
+  int rc = ensure_ctx();
+  if (rc) return rc;
+  if (comm->device != g_ctx.device) return fail(PLHIP_ERR_INVALID, "the communicator belongs to another device than the calling thread's");
+  return sharded_impl(comm, keys, n_keys, values, n_values, aggs, n_aggs, flags, opts, out);
 }
 
 } // extern "C"

@@ -81,6 +81,56 @@ class _DevBuf:
         self._owner = owner
 
 
+class _HostTransport:
+    """plhip_alltoall_fn / plhip_alltoallv_fn over a torch.distributed group that cannot move device memory (gloo): the
+    buffers are copied to the host with plhip_memcpy (the library has drained its stream before it calls), exchanged
+    with dist.all_to_all_single, and copied back.  Rehearsal transport: several ranks on one GPU."""
+
+    def __init__(self, group, world: int):
+        self.group, self.world = group, world
+        self.a2a = _ffi.ALLTOALL_FN(self._a2a)
+        self.a2av = _ffi.ALLTOALLV_FN(self._a2av)
+
+    def _a2a(self, user, send, recv, bytes_per_peer):
+        try:
+            import torch
+            import torch.distributed as dist
+
+            n = int(bytes_per_peer) * self.world
+            hs = torch.empty(max(n, 1), dtype=torch.uint8)[:n]
+            hr = torch.empty_like(hs)
+            _ffi.check(_ffi.lib().plhip_memcpy(hs.data_ptr(), _ffi.HOST, send, _ffi.DEVICE, n))
+            dist.all_to_all_single(hr, hs, group=self.group)
+            _ffi.check(_ffi.lib().plhip_memcpy(recv, _ffi.DEVICE, hr.data_ptr(), _ffi.HOST, n))
+            return 0
+        except Exception:  # never unwind into C
+            import traceback
+
+            traceback.print_exc()
+            return 1
+
+    def _a2av(self, user, send, send_bytes, recv, recv_bytes):
+        try:
+            import torch
+            import torch.distributed as dist
+
+            sb = [int(send_bytes[p]) for p in range(self.world)]
+            rb = [int(recv_bytes[p]) for p in range(self.world)]
+            hs = torch.empty(max(sum(sb), 1), dtype=torch.uint8)[:sum(sb)]
+            hr = torch.empty(max(sum(rb), 1), dtype=torch.uint8)[:sum(rb)]
+            if sum(sb):
+                _ffi.check(_ffi.lib().plhip_memcpy(hs.data_ptr(), _ffi.HOST, send, _ffi.DEVICE, sum(sb)))
+            dist.all_to_all_single(hr, hs, output_split_sizes=rb, input_split_sizes=sb, group=self.group)
+            if sum(rb):
+                _ffi.check(_ffi.lib().plhip_memcpy(recv, _ffi.DEVICE, hr.data_ptr(), _ffi.HOST, sum(rb)))
+            return 0
+        except Exception:
+            import traceback
+
+            traceback.print_exc()
+            return 1
+
+
 class HipEngine:
     """Local passes through the C ABI with device-resident inputs and outputs."""
 
@@ -268,98 +318,82 @@ class HipEngine:
                 c.mask = _unpack_bits(bits, g)
         return out
 
-    def sharded(self, keys, vals, aggs, world: int, group, hint: int, names) -> list[Col]:
-        """partial pass -> pack -> exchange -> unpack + regroup -> finalize; torch only allocates the buffers and
-        runs the collectives.  With an n_groups_hint (a query-level bound, the same on every rank) the buckets
-        travel in fixed-capacity slots with ONE equal-split all_to_all_single and no counts round trip; a rank
-        whose bucket does not fit says so in its slot headers, which every rank sees, and all ranks fall back to
-        the exact protocol (counts, then a variable all_to_all_single)."""
+    def communicator(self, group):
+        """The library-side communicator of `group` (cached per group): RCCL when the group runs on it -- rank 0 draws the
+        unique id, torch.distributed only carries its 128 bytes to the others -- and the host transport when the group
+        is gloo (rehearsals of several ranks on one GPU): the library then calls back into `_HostTransport`, which
+        stages the buffers through the host and runs dist.all_to_all_single."""
         import ctypes as C
 
         import torch
         import torch.distributed as dist
 
-        from .frame import group_by_agg_raw
+        key = id(group) if group is not None else 0
+        hit = self._comms.get(key)
+        if hit is not None:
+            return hit[0]
+        L = _ffi.lib()
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        _ffi.check(L.plhip_init(self.device.index or 0))
+        comm = C.c_void_p()
+        if dist.get_backend(group) == "gloo":
+            tr = _HostTransport(group, world)
+            _ffi.check(L.plhip_comm_init_host(world, rank, tr.a2a, tr.a2av, None, C.byref(comm)))
+            self._comms[key] = (comm, tr)
+        else:
+            idbuf = (C.c_uint8 * _ffi.COMM_ID_BYTES)()
+            if rank == 0:
+                _ffi.check(L.plhip_comm_unique_id(idbuf))
+            t = torch.tensor(list(idbuf), dtype=torch.uint8, device=self.device)
+            dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            idbuf = (C.c_uint8 * _ffi.COMM_ID_BYTES)(*t.cpu().tolist())
+            _ffi.check(L.plhip_comm_init_rccl(idbuf, world, rank, C.byref(comm)))
+            self._comms[key] = (comm, None)
+        return comm
 
-        import time
+    _comms: dict = {}
 
-        from .frame import last_kernel_breakdown, last_kernel_ms, last_strategy
+    def sharded(self, keys, vals, aggs, world: int, group, hint: int, names) -> list[Col]:
+        """ONE library call: plhip_group_by_agg_sharded (local pass -> pack -> exchange -> unpack + regroup -> finalize,
+        the exchange being RCCL sends and receives on the library's stream).  This wrapper only builds the argument
+        arrays, wraps the device-resident result and copies the call's statistics for bench.py."""
+        import ctypes as C
 
         L = _ffi.lib()
-        nk = len(keys)
-        schema = partial_schema(keys, vals, aggs)
-        rec = sum(_ffi.code_np_dtype(code).itemsize + (1 if nullable else 0) for code, nullable in schema)
-        codes = [(ci, _ffi.AGG_NAMES[k]) for ci, k in aggs]
-        # RCCL moves device buffers; over gloo (rehearsals of several ranks on one GPU) they are staged through the host
-        staged = dist.get_backend(group) == "gloo"
+        comm = self.communicator(group)
         self._sync_torch()
-        ph = self.last_phase_ms = {}
-        t0 = time.perf_counter()
+        codes = [(ci, _ffi.AGG_NAMES[k]) for ci, k in aggs]
+        karr = (_ffi.ColumnStruct * max(1, len(keys)))(*[k.struct() for k in keys])
+        varr = (_ffi.ColumnStruct * max(1, len(vals)))(*[v.struct() for v in vals])
+        aarr = (_ffi.AggStruct * max(1, len(codes)))(*[_ffi.AggStruct(c, k) for c, k in codes])
+        opts = _ffi.OptionsStruct(C.sizeof(_ffi.OptionsStruct), int(hint))
+        flags = _ffi.FLAG_OUTPUT_DEVICE | (0 if self.use_slots else _ffi.FLAG_EXACT_EXCHANGE)
+        if self.dense_keys and len(keys) == 1 and keys[0].n_categories is not None and hint:
+            flags |= _ffi.FLAG_KEYS_DENSE
+        handle = C.c_void_p()
+        _ffi.check(L.plhip_group_by_agg_sharded(comm, karr, len(keys), varr, len(vals), aarr, len(codes), flags, C.byref(opts),
+                                                C.byref(handle)))
+        st = _ffi.ShardedStats()
+        _ffi.check(L.plhip_sharded_last_stats(C.byref(st)))
+        self.last_partial_kernel_ms = (st.partial_kernel_ms, st.partial_dominant_ms, st.partial_dominant_kernel.decode())
+        self.last_partial_breakdown = tuple(st.partial_breakdown_ms)
+        self.last_partial_strategy = st.partial_strategy.decode()
+        self.last_partial_groups = int(st.partial_groups)
+        self.last_phase_ms = {"partial_pass": st.partial_ms, "pack": st.pack_ms, "exchange": st.exchange_ms, "merge": st.merge_ms,
+                              "finalize": st.finalize_ms}
+        self.last_shuffle_bytes = int(st.shuffle_bytes)
+        self.last_host_syncs = int(st.host_syncs)
+        self.last_protocol = {1: "slots: one equal-split exchange (ncclSend/ncclRecv per peer)",
+                              2: "exact: counts exchange + variable-size exchange"}.get(st.protocol, "none")
+        cols = []
+        for i in range(L.plhip_result_num_columns(handle)):
+            cs = _ffi.ColumnStruct()
+            _ffi.check(L.plhip_result_column(handle, i, C.byref(cs)))
+            cols.append(cs)
+        return self._frame(handle, cols, [k.name for k in keys] + list(names))
 
-        def lap(name):
-            nonlocal t0
-            t1 = time.perf_counter()
-            ph[name] = ph.get(name, 0.0) + (t1 - t0) * 1e3
-            t0 = t1
-
-        handle, cols = group_by_agg_raw(keys, vals, codes, _ffi.FLAG_PARTIAL | _ffi.FLAG_OUTPUT_DEVICE, hint)
-        # the kernel times of THIS call (the pass over the rank's rows): later library calls of the step overwrite them
-        self.last_partial_kernel_ms = last_kernel_ms()
-        self.last_partial_breakdown = last_kernel_breakdown()
-        self.last_partial_strategy = last_strategy()
-        lap("partial_pass")
-        try:
-            g = int(L.plhip_result_num_rows(handle))
-            self.last_partial_groups = g
-            if g:  # the frame's layout is a property of the schema: every rank computes the same one
-                assert [(cs.dtype, bool(cs.validity)) for cs in cols] == schema, "partial frame does not match the schema"
-            counts = (C.c_int64 * world)()
-            merged = None
-            if hint > 0 and world <= 64 and self.use_slots:
-                slot_rows = -(-5 * int(hint) // (4 * world)) + 512  # 1.25x an even share: overflow needs a badly skewed hash
-                stride = int(L.plhip_slot_bytes(rec, slot_rows))
-                send = torch.empty(world * stride, dtype=torch.uint8, device=self.device)
-                _ffi.check(L.plhip_result_pack_slots(handle, nk, NULL_HASH, world, slot_rows, send.data_ptr(), counts))
-                lap("pack")
-                recv = torch.empty(world * stride, dtype=torch.uint8, device="cpu" if staged else self.device)
-                dist.all_to_all_single(recv, send.cpu() if staged else send, group=group)
-                if staged:
-                    recv = recv.to(self.device)
-                hdr = recv.view(world, stride)[:, :16].cpu().numpy().view(np.uint64)  # the one host sync of the exchange
-                lap("exchange")
-                self.last_shuffle_bytes = int(world * stride)
-                self.last_protocol = "slots: one equal-split all_to_all_single"
-                if not hdr[:, 1].any():
-                    rc = (C.c_int64 * world)(*[int(x) for x in hdr[:, 0]])
-                    merged = self._merge_call(recv, schema, nk, aggs, hint, sum(rc), slots=(world, slot_rows, rc))
-                    lap("merge")
-            if merged is None:  # no hint, or some rank's bucket overflowed its slot (all ranks saw the flag)
-                send = torch.empty((max(g, 1), rec), dtype=torch.uint8, device=self.device)
-                _ffi.check(L.plhip_result_pack_by_owner(handle, nk, NULL_HASH, world, send.data_ptr(), counts))
-                lap("pack")
-                sc = list(counts)
-                cdev = torch.device("cpu") if staged else self.device
-                send_counts = torch.tensor(sc, dtype=torch.int64, device=cdev)
-                recv_counts = torch.empty_like(send_counts)
-                dist.all_to_all_single(recv_counts, send_counts, group=group)
-                rc = recv_counts.tolist()
-                m = sum(rc)
-                recv = torch.empty((max(m, 1), rec), dtype=torch.uint8, device=cdev)[:m]
-                dist.all_to_all_single(recv, send[:g].cpu() if staged else send[:g], output_split_sizes=rc, input_split_sizes=sc, group=group)
-                if staged:
-                    recv = recv.to(self.device)
-                self._sync_torch()
-                lap("exchange")
-                self.last_shuffle_bytes = int(g * rec)
-                self.last_protocol = "counts all_to_all_single + variable all_to_all_single"
-                merged = self._merge_call(recv, schema, nk, aggs, hint, m)
-                lap("merge")
-        finally:
-            L.plhip_result_free(handle)
-        out = self.finalize_frame(merged, keys, vals, aggs, names)
-        lap("finalize")
-        return out
-
+    dense_keys = False  # bench.py: declare a single Categorical key's codes dense in the local pass
+    last_host_syncs = 0
     last_partial_kernel_ms = (0.0, 0.0, "")
     last_partial_breakdown = (0.0, 0.0, 0.0)
     last_partial_strategy = ""

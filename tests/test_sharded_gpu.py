@@ -1,0 +1,123 @@
+"""The sharded path behind the C ABI (plhip_group_by_agg_sharded): local pass -> pack -> exchange -> regroup -> finalize in
+ONE library call, the counterpart of PartitionGroupByExec (group_by_partitioned.rs:273-361) across GPUs.
+  - RCCL transport on the one GPU of the box: a communicator of world size 1 (the sends and receives go to the rank
+    itself: ncclGroupStart; ncclSend; ncclRecv; ncclGroupEnd run for real), both protocols, against the oracle;
+  - two and three ranks on ONE GPU over the host transport (gloo carries the bytes, everything else is the library):
+    scripts/rehearse_ranks.py under torch.distributed.run, whole result against the oracle."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from polars_amd import _ffi
+from polars_amd.column import Column
+from tests import util
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.fixture(scope="module")
+def rccl_world1():
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", device_id=torch.device("cuda:0"), rank=0, world_size=1)
+    yield
+    dist.destroy_process_group()
+
+
+def _frame(res):
+    return [(c.t.cpu().numpy().view(_ffi.code_np_dtype(c.code)), None if c.mask is None else c.mask.cpu().numpy()) for c in res]
+
+
+@pytest.mark.parametrize("protocol", ["slots", "exact", "hint_too_small", "no_hint"])
+def test_sharded_rccl_world1_vs_oracle(oracle, rccl_world1, protocol):
+    import torch
+
+    from polars_amd import distributed as pd_
+
+    rng = np.random.default_rng(31)
+    n, g = 1_000_000, 20_000
+    k = rng.integers(-g // 2, g // 2, n).astype(np.int32)
+    km = rng.random(n) >= 0.02
+    v1 = rng.integers(1, 6, n).astype(np.int32)
+    v3 = np.round(rng.uniform(0, 100, n), 6)  # (mixed signs: tests/test_edges_gpu.py, with the bound that applies there)
+    v3m = rng.random(n) >= 0.05
+    keys = [Column("k", k, km)]
+    vals = [Column("v1", v1), Column("v3", v3, v3m)]
+    aggs = [(0, "sum"), (1, "mean"), (1, "min"), (1, "max"), (0, "count"), (1, "sum"), (0, "mean")]
+    eng = pd_.HipEngine(torch.device("cuda:0"))
+    eng.use_slots = protocol != "exact"
+    hint = {"slots": g + 1, "exact": g + 1, "hint_too_small": 50, "no_hint": 0}[protocol]
+    res = pd_.group_by_agg_sharded(keys, vals, aggs, device=torch.device("cuda:0"), engine=eng, n_groups_hint=hint, force_exchange=True)
+    want, _ = oracle.group_by_agg(keys, vals, aggs)
+    util.assert_frames_match(_frame(res), util.oracle_to_np(want), 1, what=f"sharded, RCCL world 1, {protocol}")
+    assert eng.last_protocol.startswith("slots" if protocol == "slots" else "exact"), eng.last_protocol
+    assert eng.last_shuffle_bytes > 0 and eng.last_partial_groups == len(want[0][1])
+    assert eng.last_host_syncs <= (4 if protocol == "slots" else 8)
+    assert set(eng.last_phase_ms) == {"partial_pass", "pack", "exchange", "merge", "finalize"}
+
+
+def test_sharded_rccl_world1_dense_codes_and_device_inputs(oracle, rccl_world1):
+    """The bench's shape: a Categorical key's codes (dense-code local pass), device-resident torch columns."""
+    import torch
+
+    from polars_amd import distributed as pd_
+
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(5)
+    n, ncat = 4_000_000, 40_000
+    kt = torch.randint(0, ncat, (n,), generator=gen, device=dev, dtype=torch.int32)
+    v1 = torch.randint(1, 6, (n,), generator=gen, device=dev, dtype=torch.int32)
+    v3 = torch.rand((n,), generator=gen, device=dev, dtype=torch.float64) * 100
+    keys = [Column("id3", kt, dtype=_ffi.U32).set_categories(ncat)]
+    vals = [Column("v1", v1), Column("v3", v3)]
+    aggs = [(0, "sum"), (1, "mean")]
+    eng = pd_.HipEngine(dev)
+    eng.dense_keys = True
+    res = pd_.group_by_agg_sharded(keys, vals, aggs, device=dev, engine=eng, n_groups_hint=ncat, force_exchange=True)
+    assert eng.last_partial_strategy == "dense", eng.last_partial_strategy
+    hk = [Column("id3", kt.cpu().numpy().view(np.uint32))]
+    hv = [Column("v1", v1.cpu().numpy()), Column("v3", v3.cpu().numpy())]
+    want, _ = oracle.group_by_agg(hk, hv, aggs)
+    util.assert_frames_match(_frame(res), util.oracle_to_np(want), 1, what="sharded, dense local pass")
+
+
+def test_sharded_argument_errors(rccl_world1):
+    import ctypes as C
+
+    L = _ffi.lib()
+    k = Column("k", np.zeros(8, np.int32))
+    karr = (_ffi.ColumnStruct * 1)(k.struct())
+    aarr = (_ffi.AggStruct * 1)(_ffi.AggStruct(-1, _ffi.AGG_COUNT))
+    out = C.c_void_p()
+    assert L.plhip_group_by_agg_sharded(None, karr, 1, karr, 0, aarr, 1, 0, None, C.byref(out)) == 6  # PLHIP_ERR_INVALID: no communicator
+    assert b"comm" in L.plhip_last_error()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_ranks_on_one_gpu(world):
+    """`world` processes share the GPU; the exchange's bytes travel over gloo through the library's host transport."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "scripts", "rehearse_ranks.py")]
+    env = dict(os.environ)
+    env.pop("MASTER_PORT", None)
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert p.stdout.count("ok:") == 6, p.stdout[-3000:]
