@@ -233,6 +233,11 @@ def main():
     import polars_amd as pa
     from polars_amd import _ffi, h2oai
 
+    # ONE JSON line on stdout, nothing else: native libraries write to descriptor 1 on their own (RCCL prints a version banner
+    # when its first communicator is made), so everything but the line goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -400,7 +405,8 @@ def main():
                 line["cpu_baseline"], line["parity"] = cpu_baseline(tensors, keys, vals, aggs, gpu_frame)
             else:
                 line["cpu_baseline"], line["parity"] = cpu_baseline_sample(tensors, keys_n, vals_n, aggs, gpu_frame)
-        print(json.dumps(line))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if world > 1 or rehearse:
         dist.destroy_process_group()
 

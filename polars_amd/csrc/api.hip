@@ -458,6 +458,10 @@ struct Lowered {
   int first_acc = -1;
 };
 
+// Internal to the library (never set by callers: the entry points mask it): the partial sums of 4-byte integer columns
+// only have to be right modulo 2^32, because the caller -- the sharded path -- wraps them into the column's type at the end.
+constexpr uint32_t FLAG_INTERNAL_WRAP32 = 1u << 30;
+
 int build_aggs(Lowered &L, const std::vector<DevCol> &vals, const plhip_agg_t *aggs, int n_aggs, uint32_t flags) {
   Plan &P = L.P;
   P.n_vals = (int)vals.size();
@@ -499,7 +503,10 @@ int build_aggs(Lowered &L, const std::vector<DevCol> &vals, const plhip_agg_t *a
         o.acc = add_acc(P, ACC_ADD_U64, CONV_INT, ci, 8, 0);
       }
       if (partial && is_f) { o.kind = OUT_RAW_U64; o.dtype = PLHIP_F64; }
-      if (partial && !is_f) { o.kind = OUT_RAW_U64; o.dtype = (is_s || w < 4) ? PLHIP_I64 : PLHIP_U64; }
+      if (partial && !is_f) {
+        o.kind = ((flags & FLAG_INTERNAL_WRAP32) && w == 4) ? OUT_RAW_U64_WRAP32 : OUT_RAW_U64;
+        o.dtype = (is_s || w < 4) ? PLHIP_I64 : PLHIP_U64;
+      }
       o.validity = nullptr;
     } else if (kind == PLHIP_AGG_MEAN) {
       o.cnt_valid = cnt_valid;
@@ -1277,7 +1284,7 @@ int run_dense(const Lowered &L0, const std::vector<DevCol> &dk, uint32_t flags, 
     bool used = false;
     for (auto &o : L.outs) {
       if (o.kind == OUT_KEY) continue;
-      if (o.acc == a) { used = true; if (o.kind != OUT_SUM_INT || dtype_width((int)o.dtype) != 4) return false; }
+      if (o.acc == a) { used = true; if (o.kind != OUT_RAW_U64_WRAP32 && (o.kind != OUT_SUM_INT || dtype_width((int)o.dtype) != 4)) return false; }
     }
     return used;
   };
@@ -1926,7 +1933,7 @@ int32_t plhip_group_by_agg(const plhip_column_t *keys, int32_t n_keys, const plh
 int32_t plhip_group_by_agg_opts(const plhip_column_t *keys, int32_t n_keys, const plhip_column_t *values,
                                 int32_t n_values, const plhip_agg_t *aggs, int32_t n_aggs, uint32_t flags,
                                 const plhip_options_t *opts, plhip_result_t **out) {
-  const int rc = group_by_agg_impl(keys, n_keys, values, n_values, aggs, n_aggs, flags, opts, out);
+  const int rc = group_by_agg_impl(keys, n_keys, values, n_values, aggs, n_aggs, flags & ~FLAG_INTERNAL_WRAP32, opts, out);
   // slice pushdown (GroupByExec's `slice`, executors/group_by.rs:79-82; offsets as slice_offsets, utils/mod.rs:199-218)
   if (!rc && out && *out && opts && opts->struct_size >= offsetof(plhip_options_t, has_slice) + sizeof(uint32_t) && opts->has_slice) {
     plhip_result *R = *out;
@@ -2817,8 +2824,8 @@ int sharded_impl(plhip_comm *comm, const plhip_column_t *keys, int32_t n_keys, c
   if (opts && opts->struct_size >= sizeof(plhip_options_t) && opts->has_slice) return fail(PLHIP_ERR_INVALID, "a slice cannot be pushed into the sharded path");
   // ---- local pass: mergeable partials, device-resident -------------------------------------------------------------
   FrameGuard part;
-  const uint32_t pflags = PLHIP_FLAG_PARTIAL | PLHIP_FLAG_OUTPUT_DEVICE | (flags & PLHIP_FLAG_KEYS_DENSE);
-  int rc = plhip_group_by_agg_opts(keys, n_keys, values, n_values, aggs, n_aggs, pflags, opts, &part.p);
+  const uint32_t pflags = PLHIP_FLAG_PARTIAL | PLHIP_FLAG_OUTPUT_DEVICE | (flags & PLHIP_FLAG_KEYS_DENSE) | FLAG_INTERNAL_WRAP32;
+  int rc = group_by_agg_impl(keys, n_keys, values, n_values, aggs, n_aggs, pflags, opts, &part.p);
   if (rc) return rc;
   resolve_timing();
   S.partial_kernel_ms = c.total_ms; S.partial_dominant_ms = c.dom_ms;

@@ -266,7 +266,7 @@ DEVINL bool finalize_value(const OutSpec &S, uint64_t acc, uint32_t cnt_all, uin
       break;
     }
     case OUT_COUNT: ((uint32_t *)S.values)[i] = (uint32_t)acc; break;
-    case OUT_RAW_U64: ((uint64_t *)S.values)[i] = acc; break;
+    case OUT_RAW_U64: case OUT_RAW_U64_WRAP32: ((uint64_t *)S.values)[i] = acc; break;
     case OUT_RAW_U32_AS_U64: ((uint64_t *)S.values)[i] = acc; break;
     default: break;
   }

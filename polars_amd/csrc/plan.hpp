@@ -106,6 +106,8 @@ enum OutKind : uint32_t {
   OUT_COUNT = 9,
   OUT_RAW_U64 = 10,   // partial mode: accumulator as is (u64 / i64 / f64 bits)
   OUT_RAW_U32_AS_U64 = 11,
+  OUT_RAW_U64_WRAP32 = 12, // OUT_RAW_U64 of an i32 / u32 SUM whose consumer wraps it in 32 bits (the sharded path's finalize): the
+                           // 64-bit partial only has to be right modulo 2^32, so its accumulator may live in 32 bits
 };
 
 struct OutSpec {

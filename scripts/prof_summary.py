@@ -47,7 +47,11 @@ if "--json" in sys.argv:
     key = sys.argv[sys.argv.index("--json") + 1]
     out = Path("profiles/traffic.json")
     t = json.loads(out.read_text()) if out.exists() else {}
-    # launches per query: calls relative to the most-called kernel are not known here; every kernel listed runs once per query
-    t[key] = {"kernels": rows, "hbm_bytes": int(sum(r["fetch_bytes"] + r["write_bytes"] for r in rows.values())),
-              "note": "sum over the query's kernels, FETCH_SIZE x 2 (gfx950) + WRITE_SIZE, per launch"}
+    # launches per query: a kernel that runs twice per query (the two partition levels' k_tile_sort, k_estimate's two sample
+    # sizes) shows twice the calls of the ones that run once
+    base = min((r["calls"] for r in rows.values() if r["calls"]), default=1)
+    for r in rows.values():
+        r["launches_per_query"] = max(1, round(r["calls"] / base)) if r["calls"] else 1
+    t[key] = {"kernels": rows, "hbm_bytes": int(sum(r["launches_per_query"] * (r["fetch_bytes"] + r["write_bytes"]) for r in rows.values())),
+              "note": "sum over the query's kernels of launches_per_query x (FETCH_SIZE x 2 (gfx950) + WRITE_SIZE per launch)"}
     out.write_text(json.dumps(t, indent=1, sort_keys=True) + "\n")
