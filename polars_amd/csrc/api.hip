@@ -2399,18 +2399,23 @@ static int32_t agg_groups_impl(const plhip_column_t *values, int32_t kind, const
       size_t tb = 0;
       e = median_temp_bytes((uint64_t)n, G, &tb);
       const size_t n8 = ((size_t)std::max<int64_t>(n, 1) * 8 + 255) & ~(size_t)255;
-      if (e == hipSuccess) e = c.table.reserve(2 * n8);
+      const size_t n4 = ((size_t)std::max<int64_t>(n, 1) * 4 + 255) & ~(size_t)255;
+      if (e == hipSuccess) e = c.table.reserve(2 * n8 + 2 * n4);
+      uint32_t *gid_a = (uint32_t *)((uint8_t *)c.table.p + 2 * n8), *gid_b = (uint32_t *)((uint8_t *)c.table.p + 2 * n8 + n4);
       if (e == hipSuccess) e = c.sortkeys.reserve(tb + 256);
       if (e == hipSuccess && kind == PLHIP_AGG_N_UNIQUE) e = c.rank.reserve((G / 16 + 1) * 4);
       if (e == hipSuccess && kind == PLHIP_AGG_N_UNIQUE)
-        e = launch_n_unique(A, offsets, indices, (uint64_t)n, G, (uint64_t *)c.table.p, (uint64_t *)((uint8_t *)c.table.p + n8), (uint32_t *)c.rank.p,
+        e = launch_n_unique(A, offsets, indices, (uint64_t)n, G, (uint64_t *)c.table.p, (uint64_t *)((uint8_t *)c.table.p + n8), gid_a, gid_b, (uint32_t *)c.rank.p,
                             c.sortkeys.p, tb, c.stream);
       else if (e == hipSuccess)
-        e = launch_quantile(A, offsets, indices, (uint64_t)n, G, (uint64_t *)c.table.p, (uint64_t *)((uint8_t *)c.table.p + n8), c.sortkeys.p, tb,
+        e = launch_quantile(A, offsets, indices, (uint64_t)n, G, (uint64_t *)c.table.p, (uint64_t *)((uint8_t *)c.table.p + n8), gid_a, gid_b, c.sortkeys.p, tb,
                             quantile, interp, c.stream);
     } else {
-      launch_agg_groups_ext(A, offsets, indices, G, moment && G > 0 && (uint64_t)n / G >= 64, c.stream);
-      e = hipGetLastError();
+      e = c.misc.reserve(agg_long_scratch_bytes((uint64_t)n));
+      if (e == hipSuccess) {
+        launch_agg_groups_ext(A, offsets, indices, (uint64_t)n, G, moment && G > 0 && (uint64_t)n / G >= 64, c.misc.p, c.stream);
+        e = hipGetLastError();
+      }
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
     if (e != hipSuccess) { return fail_hip(e, "agg_groups"); }
@@ -2457,7 +2462,9 @@ static int32_t agg_groups_impl(const plhip_column_t *values, int32_t kind, const
   if (e != hipSuccess) { return fail_hip(e, "hipMalloc(output)"); }
   o.values = (uint8_t *)col.values; o.validity = col.validity;
   OP.outs[0] = o;
-  launch_agg_groups(L.P, OP, offsets, indices, G, G > 0 && (uint64_t)n / G >= 64, c.stream);
+  e = c.misc.reserve(agg_long_scratch_bytes((uint64_t)n));
+  if (e != hipSuccess) return fail_hip(e, "agg_groups scratch");
+  launch_agg_groups(L.P, OP, offsets, indices, (uint64_t)n, G, G > 0 && (uint64_t)n / G >= 64, c.misc.p, c.stream);
   e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
   if (e != hipSuccess) { return fail_hip(e, "agg_groups"); }

@@ -77,7 +77,12 @@ __global__ void __launch_bounds__(256) k_agg_global(Plan P, TableRef T) {
     for (int a = 0; a < P.n_accs; a++) {
       const AccSpec &A = P.accs[a];
       uint64_t operand;
-      if (acc_operand(P, A, row, operand)) acc_apply(T.base, A, slot, operand);
+      if (!acc_operand(P, A, row, operand)) continue;
+      // The first-row minimum only ever moves down: a row that cannot lower it skips the atomic (a stale read shows an
+      // older, LARGER value: then the atomic runs as before).  Without this one key on 30 % of 1e7 rows serialised 3e6
+      // returning atomics on one address (plhip_group_tuples: 47 ms).
+      if (A.op == ACC_FIRST_ROW && ((const volatile uint32_t *)(T.base + A.offset))[slot] <= (uint32_t)operand) continue;
+      acc_apply(T.base, A, slot, operand);
     }
   }
 }
@@ -413,11 +418,12 @@ DEVINL void acc_fold_local(const AccSpec &a, uint64_t &state, uint64_t operand) 
 // lane partials in a fixed butterfly order.
 template <bool WAVE>
 __global__ void __launch_bounds__(256) k_agg_groups(Plan P, OutPlan O, const uint32_t *__restrict__ offsets,
-                                                    const uint32_t *__restrict__ indices, uint64_t G) {
+                                                    const uint32_t *__restrict__ indices, uint64_t G, uint32_t long_min) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t g = WAVE ? t >> 6 : t;
   const uint32_t lane = threadIdx.x & 63;
-  const bool live = g < G;
+  // groups of more than long_min rows belong to k_agg_groups_long (several workgroups each)
+  const bool live = g < G && offsets[g + 1] - offsets[g] <= long_min;
   uint64_t st[4];
   for (int a = 0; a < 4; a++) st[a] = a < P.n_accs ? P.accs[a].init : 0;
   if (live) {
@@ -486,11 +492,12 @@ DEVINL double value_as_f64(const uint8_t *p, uint32_t dtype, int64_t row) {
 
 template <bool WAVE>
 __global__ void __launch_bounds__(256) k_agg_groups_ext(AggExtArgs A, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ indices,
-                                                        uint64_t G) {
+                                                        uint64_t G, uint32_t long_min) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t g = WAVE ? t >> 6 : t;
   const uint32_t lane = threadIdx.x & 63;
-  const bool live = g < G;
+  const bool moments = A.kind == AGG_EXT_VAR || A.kind == AGG_EXT_STD;
+  const bool live = g < G && (!moments || offsets[g + 1] - offsets[g] <= long_min); // (first / last read one row whatever the length)
   const uint32_t b = live ? offsets[g] : 0, e = live ? offsets[g + 1] : 0;
   bool valid = false;
   if (A.kind == AGG_EXT_FIRST || A.kind == AGG_EXT_LAST) {
@@ -538,14 +545,177 @@ __global__ void __launch_bounds__(256) k_agg_groups_ext(AggExtArgs A, const uint
   if (valid) atomicOr((unsigned int *)A.out_validity + (g >> 5), 1u << (g & 31)); // zeroed bitmap
 }
 
-void launch_agg_groups_ext(const AggExtArgs &a, const uint32_t *offsets, const uint32_t *indices, uint64_t G, bool wave, hipStream_t s) {
-  if (!G) return;
-  if (wave) hipLaunchKernelGGL(k_agg_groups_ext<true>, dim3((unsigned)((G * 64 + 255) / 256)), dim3(256), 0, s, a, offsets, indices, G);
-  else hipLaunchKernelGGL(k_agg_groups_ext<false>, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, s, a, offsets, indices, G);
+// ---- long groups (skew): a group of more than AGL_CHUNK rows is cut into chunks, one workgroup each; the workgroup that
+// finishes last folds the chunks' partial states in chunk order (a fixed order: the result does not depend on timing) and
+// writes the group's output row.  One wave -- or, for short average groups, one THREAD -- walking a 3e6-row group alone
+// took 35 ms (sum) at 1e7 rows; the fused paths split their hot leaves the same way (fast_path.hip).
+struct LongItem { uint32_t g, chunk, nchunks, base; };
+
+__global__ void __launch_bounds__(256) k_long_items(const uint32_t *__restrict__ offsets, uint64_t G, uint32_t long_min, uint32_t ch, LongItem *items,
+                                                    uint32_t *n_items, uint32_t max_items) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  const uint32_t len = offsets[g + 1] - offsets[g];
+  if (len <= long_min) return;
+  const uint32_t nch = (len + ch - 1) / ch; // <= 2 * len / ch: the items of all long groups fit 2 * n / ch
+  const uint32_t base = atomicAdd(n_items, nch);
+  if (base + nch > max_items) return; // (cannot happen; a group left out here would lose its row, so the bound is checked on the host side too)
+  for (uint32_t c = 0; c < nch; c++) items[base + c] = LongItem{(uint32_t)g, c, nch, base};
 }
 
-void launch_agg_groups(const Plan &p, const OutPlan &o, const uint32_t *offsets, const uint32_t *indices, uint64_t G, bool wave, hipStream_t s) {
+DEVINL uint64_t ld_agent(const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ void __launch_bounds__(256) k_agg_groups_long(Plan P, OutPlan O, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ indices,
+                                                         const LongItem *__restrict__ items, const uint32_t *__restrict__ n_items, uint64_t *partial,
+                                                         uint32_t *done, uint32_t ch) {
+  __shared__ uint64_t sh[4][4];
+  __shared__ uint32_t s_last;
+  if (blockIdx.x >= *n_items) return;
+  const LongItem it = items[blockIdx.x];
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t gb = offsets[it.g], ge = offsets[it.g + 1];
+  const uint32_t b = gb + it.chunk * ch, e = b + ch < ge ? b + ch : ge;
+  uint64_t st[4];
+  for (int a = 0; a < 4; a++) st[a] = a < P.n_accs ? P.accs[a].init : 0;
+  for (uint32_t i0 = b + threadIdx.x; i0 < e; i0 += 1024) { // four gathers in flight per lane
+    int64_t row[4];
+    bool ok[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const uint32_t i = i0 + 256u * (uint32_t)k; ok[k] = i < e; row[k] = indices[ok[k] ? i : b]; }
+    for (int a = 0; a < P.n_accs && a < 4; a++) {
+      uint64_t operand[4];
+      bool v[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) v[k] = acc_operand(P, P.accs[a], row[k], operand[k]) && ok[k];
+#pragma unroll
+      for (int k = 0; k < 4; k++) if (v[k]) acc_fold_local(P.accs[a], st[a], operand[k]);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1)
+    for (int a = 0; a < P.n_accs && a < 4; a++) {
+      const uint64_t other = ((uint64_t)(uint32_t)__shfl_xor((int)(st[a] >> 32), off) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)st[a], off);
+      acc_fold_local(P.accs[a], st[a], other);
+    }
+  if (lane == 0) for (int a = 0; a < 4; a++) sh[wave][a] = st[a];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++) for (int a = 0; a < P.n_accs && a < 4; a++) acc_fold_local(P.accs[a], st[a], sh[w][a]);
+    for (int a = 0; a < 4; a++) partial[(uint64_t)blockIdx.x * 4 + a] = st[a];
+    __threadfence(); // the chunk's state is visible device-wide before the chunk counts as done
+    s_last = atomicAdd(&done[it.base], 1u) == it.nchunks - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last || threadIdx.x != 0) return;
+  __threadfence(); // the other chunks' states, not stale lines of this XCD's L2
+  for (int a = 0; a < 4; a++) st[a] = a < P.n_accs ? P.accs[a].init : 0;
+  for (uint32_t c = 0; c < it.nchunks; c++)
+    for (int a = 0; a < P.n_accs && a < 4; a++) acc_fold_local(P.accs[a], st[a], ld_agent(&partial[(uint64_t)(it.base + c) * 4 + a]));
+  const OutSpec &S = O.outs[0];
+  const uint32_t cnt_all = S.cnt_all >= 0 ? (uint32_t)st[S.cnt_all] : 0;
+  const uint32_t cnt_valid = S.cnt_valid >= 0 ? (uint32_t)st[S.cnt_valid] : cnt_all;
+  const bool valid = finalize_value(S, S.acc >= 0 ? st[S.acc] : 0, cnt_all, cnt_valid, it.g);
+  if (S.validity) atomicOr((unsigned int *)S.validity + (it.g >> 5), valid ? 1u << (it.g & 31) : 0u);
+}
+
+DEVINL void chan_merge(double &cnt, double &mean, double &m2, double c2, double mean2, double m22) {
+  const double ct = cnt + c2;
+  if (ct > 0.0) {
+    const double d = mean2 - mean;
+    m2 = m2 + m22 + d * d * (cnt * c2 / ct);
+    mean = mean + d * (c2 / ct);
+  }
+  cnt = ct;
+}
+
+__global__ void __launch_bounds__(256) k_agg_groups_ext_long(AggExtArgs A, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ indices,
+                                                             const LongItem *__restrict__ items, const uint32_t *__restrict__ n_items, uint64_t *partial,
+                                                             uint32_t *done, uint32_t ch) {
+  __shared__ double sh[4][3];
+  __shared__ uint32_t s_last;
+  if (blockIdx.x >= *n_items) return;
+  const LongItem it = items[blockIdx.x];
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t gb = offsets[it.g], ge = offsets[it.g + 1];
+  const uint32_t b = gb + it.chunk * ch, e = b + ch < ge ? b + ch : ge;
+  double mean = 0.0, m2 = 0.0, cnt = 0.0;
+  for (uint32_t i = b + threadIdx.x; i < e; i += 256) {
+    const int64_t row = indices[i];
+    if (!bit_valid(A.validity, A.boff, row)) continue;
+    const double v = value_as_f64(A.values, A.dtype, row);
+    cnt += 1.0;
+    const double d1 = v - mean;
+    mean = d1 / cnt + mean;
+    m2 += d1 * (v - mean);
+  }
+  for (int off = 32; off > 0; off >>= 1) chan_merge(cnt, mean, m2, __shfl_xor(cnt, off), __shfl_xor(mean, off), __shfl_xor(m2, off));
+  if (lane == 0) { sh[wave][0] = cnt; sh[wave][1] = mean; sh[wave][2] = m2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++) chan_merge(cnt, mean, m2, sh[w][0], sh[w][1], sh[w][2]);
+    uint64_t *p = partial + (uint64_t)blockIdx.x * 4;
+    p[0] = (uint64_t)__double_as_longlong(cnt); p[1] = (uint64_t)__double_as_longlong(mean); p[2] = (uint64_t)__double_as_longlong(m2);
+    __threadfence();
+    s_last = atomicAdd(&done[it.base], 1u) == it.nchunks - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last || threadIdx.x != 0) return;
+  __threadfence();
+  cnt = 0.0; mean = 0.0; m2 = 0.0;
+  for (uint32_t c = 0; c < it.nchunks; c++) {
+    const uint64_t *p = partial + (uint64_t)(it.base + c) * 4;
+    chan_merge(cnt, mean, m2, __longlong_as_double((long long)ld_agent(p)), __longlong_as_double((long long)ld_agent(p + 1)),
+               __longlong_as_double((long long)ld_agent(p + 2)));
+  }
+  const bool valid = cnt > (double)A.ddof;
+  double r = valid ? m2 / (cnt - (double)A.ddof) : 0.0;
+  if (A.kind == AGG_EXT_STD) r = sqrt(r);
+  if (A.out_dtype == PLHIP_F32) ((float *)A.out)[it.g] = (float)r;
+  else ((double *)A.out)[it.g] = r;
+  if (valid) atomicOr((unsigned int *)A.out_validity + (it.g >> 5), 1u << (it.g & 31));
+}
+
+size_t agg_long_scratch_bytes(uint64_t n) {
+  const uint64_t max_items = 2 * (n / AGL_CHUNK) + 2;
+  return 256 + max_items * (sizeof(LongItem) + 32 + 4) + 256;
+}
+
+// scratch: n_items (u32, 256 B slot) | items | partial (4 u64 each) | done (u32 each)
+template <typename F>
+static void launch_long(const uint32_t *offsets, uint64_t n, uint64_t G, void *scratch, hipStream_t s, F launch) {
+  const uint32_t max_items = (uint32_t)(2 * (n / AGL_CHUNK) + 2);
+  uint8_t *sb = (uint8_t *)scratch;
+  uint32_t *n_items = (uint32_t *)sb;
+  LongItem *items = (LongItem *)(sb + 256);
+  uint64_t *partial = (uint64_t *)(sb + 256 + (size_t)max_items * sizeof(LongItem));
+  uint32_t *done = (uint32_t *)((uint8_t *)partial + (size_t)max_items * 32);
+  (void)hipMemsetAsync(n_items, 0, 256, s);
+  (void)hipMemsetAsync(done, 0, (size_t)max_items * 4, s);
+  hipLaunchKernelGGL(k_long_items, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, s, offsets, G, (uint32_t)AGL_CHUNK, (uint32_t)AGL_CHUNK, items, n_items, max_items);
+  launch(max_items, items, n_items, partial, done);
+}
+
+void launch_agg_groups_ext(const AggExtArgs &a, const uint32_t *offsets, const uint32_t *indices, uint64_t n, uint64_t G, bool wave, void *long_scratch,
+                           hipStream_t s) {
   if (!G) return;
-  if (wave) hipLaunchKernelGGL(k_agg_groups<true>, dim3((unsigned)((G * 64 + 255) / 256)), dim3(256), 0, s, p, o, offsets, indices, G);
-  else hipLaunchKernelGGL(k_agg_groups<false>, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, s, p, o, offsets, indices, G);
+  const bool split = long_scratch && n > AGL_CHUNK && (a.kind == AGG_EXT_VAR || a.kind == AGG_EXT_STD);
+  const uint32_t long_min = split ? (uint32_t)AGL_CHUNK : 0xFFFFFFFFu;
+  if (wave) hipLaunchKernelGGL(k_agg_groups_ext<true>, dim3((unsigned)((G * 64 + 255) / 256)), dim3(256), 0, s, a, offsets, indices, G, long_min);
+  else hipLaunchKernelGGL(k_agg_groups_ext<false>, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, s, a, offsets, indices, G, long_min);
+  if (split)
+    launch_long(offsets, n, G, long_scratch, s, [&](uint32_t max_items, LongItem *items, uint32_t *n_items, uint64_t *partial, uint32_t *done) {
+      hipLaunchKernelGGL(k_agg_groups_ext_long, dim3(max_items), dim3(256), 0, s, a, offsets, indices, items, n_items, partial, done, (uint32_t)AGL_CHUNK);
+    });
+}
+
+void launch_agg_groups(const Plan &p, const OutPlan &o, const uint32_t *offsets, const uint32_t *indices, uint64_t n, uint64_t G, bool wave,
+                       void *long_scratch, hipStream_t s) {
+  if (!G) return;
+  const bool split = long_scratch && n > AGL_CHUNK && p.n_accs > 0; // (group_count reads no rows)
+  const uint32_t long_min = split ? (uint32_t)AGL_CHUNK : 0xFFFFFFFFu;
+  if (wave) hipLaunchKernelGGL(k_agg_groups<true>, dim3((unsigned)((G * 64 + 255) / 256)), dim3(256), 0, s, p, o, offsets, indices, G, long_min);
+  else hipLaunchKernelGGL(k_agg_groups<false>, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, s, p, o, offsets, indices, G, long_min);
+  if (split)
+    launch_long(offsets, n, G, long_scratch, s, [&](uint32_t max_items, LongItem *items, uint32_t *n_items, uint64_t *partial, uint32_t *done) {
+      hipLaunchKernelGGL(k_agg_groups_long, dim3(max_items), dim3(256), 0, s, p, o, offsets, indices, items, n_items, partial, done, (uint32_t)AGL_CHUNK);
+    });
 }

@@ -73,7 +73,11 @@ hipError_t sort_pairs_u32(uint32_t *keys, uint32_t *vals, uint64_t n, int end_bi
 void launch_iota_u32(uint32_t *out, uint64_t n, hipStream_t s);
 void launch_csr(const uint32_t *ids_sorted, const uint32_t *indices, uint64_t n, uint64_t G, uint32_t *offsets, uint32_t *first, hipStream_t s);
 // `o.outs[0]` is the one output column; at most 4 accumulators; o.outs[0].validity must be zeroed
-void launch_agg_groups(const Plan &p, const OutPlan &o, const uint32_t *offsets, const uint32_t *indices, uint64_t G, bool wave, hipStream_t s);
+// long_scratch (agg_long_scratch_bytes(n) bytes, or nullptr): groups of more than AGL_CHUNK rows are cut into chunks, one workgroup each
+#define AGL_CHUNK 4096u
+size_t agg_long_scratch_bytes(uint64_t n);
+void launch_agg_groups(const Plan &p, const OutPlan &o, const uint32_t *offsets, const uint32_t *indices, uint64_t n, uint64_t G, bool wave,
+                       void *long_scratch, hipStream_t s);
 
 // first / last / var / std over CSR groups
 #define AGG_EXT_FIRST 5
@@ -93,10 +97,11 @@ struct AggExtArgs {
 #define AGG_EXT_QUANTILE 11 // plhip_agg_groups_quantile only
 hipError_t median_temp_bytes(uint64_t n, uint64_t G, size_t *bytes);
 hipError_t launch_n_unique(const AggExtArgs &a, const uint32_t *offsets, const uint32_t *indices, uint64_t n, uint64_t G, uint64_t *codes_a,
-                           uint64_t *codes_b, uint32_t *marks, void *temp, size_t temp_bytes, hipStream_t s);
+                           uint64_t *codes_b, uint32_t *gid_a, uint32_t *gid_b, uint32_t *marks, void *temp, size_t temp_bytes, hipStream_t s);
 hipError_t launch_quantile(const AggExtArgs &a, const uint32_t *offsets, const uint32_t *indices, uint64_t n, uint64_t G, uint64_t *codes_a,
-                           uint64_t *codes_b, void *temp, size_t temp_bytes, double q, int interp, hipStream_t s);
-void launch_agg_groups_ext(const AggExtArgs &a, const uint32_t *offsets, const uint32_t *indices, uint64_t G, bool wave, hipStream_t s);
+                           uint64_t *codes_b, uint32_t *gid_a, uint32_t *gid_b, void *temp, size_t temp_bytes, double q, int interp, hipStream_t s);
+void launch_agg_groups_ext(const AggExtArgs &a, const uint32_t *offsets, const uint32_t *indices, uint64_t n, uint64_t G, bool wave, void *long_scratch,
+                           hipStream_t s);
 
 // sort strategy (sort_path.hip)
 hipError_t sort_path_temp_bytes(uint64_t n, int end_bit, size_t *bytes);

@@ -363,25 +363,34 @@ __global__ void __launch_bounds__(256) k_gather_exact(AggExtArgs A, const uint32
   codes[i] = c;
   if (mark) {
     const uint32_t g = segment_of(offsets, G, (uint32_t)i);
-    atomicOr(&marks[g >> 4], mark << ((g & 15u) * 2u));
+    const uint32_t bits = mark << ((g & 15u) * 2u);
+    if ((marks[g >> 4] & bits) != bits) atomicOr(&marks[g >> 4], bits); // (bits only ever get set: a stale read costs an atomic, never a mark)
   }
 }
 __global__ void __launch_bounds__(256) k_count_changes(AggExtArgs A, const uint64_t *__restrict__ sorted, const uint32_t *__restrict__ offsets,
                                                        uint64_t n, uint64_t G, uint32_t is_float) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint64_t c = sorted[i];
-  bool counts = i == 0 || sorted[i - 1] != c || (is_float && c == NU_NAN_CODE);
+  const bool in = i < n; // (no early return: the wave votes below)
+  const uint64_t c = in ? sorted[i] : 0;
+  bool counts = in && (i == 0 || sorted[i - 1] != c || (is_float && c == NU_NAN_CODE));
   uint32_t g = 0;
   bool have_g = false;
-  if (!counts) { // equal to its predecessor: still the first of its segment?
+  if (in && !counts) { // equal to its predecessor: still the first of its segment?
     g = segment_of(offsets, G, (uint32_t)i);
     have_g = true;
     counts = offsets[g] == (uint32_t)i;
   }
-  if (!counts) return;
-  if (!have_g) g = segment_of(offsets, G, (uint32_t)i);
-  atomicAdd((unsigned int *)A.out + g, 1u);
+  if (counts && !have_g) g = segment_of(offsets, G, (uint32_t)i);
+  // neighbours in the sorted column mostly belong to one group: one atomic per (wave, group), not per element (a long
+  // group of distinct values would put its whole length on one address otherwise)
+  unsigned long long active = __ballot(counts);
+  while (active) {
+    const int leader = __ffsll((long long)active) - 1;
+    const uint32_t gl = (uint32_t)__shfl((int)g, leader);
+    const unsigned long long m = __ballot(counts && g == gl);
+    if ((int)(threadIdx.x & 63) == leader) atomicAdd((unsigned int *)A.out + gl, (unsigned int)__popcll(m));
+    active &= ~m;
+  }
 }
 __global__ void __launch_bounds__(256) k_n_unique_finish(AggExtArgs A, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ marks, uint64_t G) {
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -427,26 +436,80 @@ __global__ void __launch_bounds__(256) k_quantile(AggExtArgs A, const uint64_t *
 }
 } // namespace
 
-hipError_t median_temp_bytes(uint64_t n, uint64_t G, size_t *bytes) {
-  return rocprim::segmented_radix_sort_keys(nullptr, *bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, (unsigned int)n, (unsigned int)G,
-                                            (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0, 64);
+// ---- sorting the values inside every group, whatever the group sizes -------------------------------------------------------
+// rocPRIM's segmented sort gives a segment to one workgroup: one key on 30 % of 1e7 rows made it 91 ms (median) against
+// 1.9 ms on uniform groups.  When some group is long, two device-wide STABLE radix sorts replace it -- by value, then by
+// group id -- whose cost does not depend on the group sizes at all; the result layout is the same (groups in CSR order,
+// values ascending inside).
+#define SEG_LONG (1u << 15)
+namespace {
+__global__ void __launch_bounds__(256) k_max_seg(const uint32_t *__restrict__ offsets, uint64_t G, uint32_t *out) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t len = g < G ? offsets[g + 1] - offsets[g] : 0u;
+  for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)len, off); len = o > len ? o : len; }
+  if ((threadIdx.x & 63) == 0 && len) atomicMax(out, len);
 }
-// codes_a / codes_b: n u64 each
+__global__ void __launch_bounds__(256) k_fill_gid(const uint32_t *__restrict__ offsets, uint64_t G, uint64_t n, uint32_t *__restrict__ gid) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) gid[i] = segment_of(offsets, G, (uint32_t)i);
+}
+int bits_of(uint64_t x) { int b = 0; while (x) { b++; x >>= 1; } return b < 1 ? 1 : b; }
+} // namespace
+
+hipError_t median_temp_bytes(uint64_t n, uint64_t G, size_t *bytes) {
+  size_t a = 0, b = 0, c = 0;
+  hipError_t e = rocprim::segmented_radix_sort_keys(nullptr, a, (uint64_t *)nullptr, (uint64_t *)nullptr, (unsigned int)n, (unsigned int)G,
+                                                    (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0, 64);
+  if (e == hipSuccess) e = rocprim::radix_sort_pairs(nullptr, b, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, n, 0, 64);
+  if (e == hipSuccess) e = rocprim::radix_sort_pairs(nullptr, c, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint64_t *)nullptr, (uint64_t *)nullptr, n, 0, 32);
+  *bytes = std::max(a, std::max(b, c)) + 512; // + the (aligned) word k_max_seg writes
+  return e;
+}
+
+// codes_a (n u64, filled) -> *sorted (codes_a or codes_b): ascending inside every CSR segment.  gid_a / gid_b: n u32 each.
+static hipError_t sort_in_segments(const uint32_t *offsets, uint64_t n, uint64_t G, uint64_t *codes_a, uint64_t *codes_b, uint32_t *gid_a,
+                                   uint32_t *gid_b, void *temp, size_t temp_bytes, const uint64_t **sorted, hipStream_t s) {
+  uint32_t *d_max = (uint32_t *)((uint8_t *)temp + ((temp_bytes - 256) & ~(size_t)255));
+  uint32_t max_len = 0;
+  hipError_t e = hipMemsetAsync(d_max, 0, 4, s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_max_seg, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, s, offsets, G, d_max);
+  e = hipMemcpyAsync(&max_len, d_max, 4, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) return e;
+  const size_t tb = (temp_bytes - 256) & ~(size_t)255;
+  if (max_len <= SEG_LONG && !getenv("PLHIP_FORCE_TWO_SORTS")) {
+    *sorted = codes_b;
+    size_t t2 = tb;
+    return rocprim::segmented_radix_sort_keys(temp, t2, codes_a, codes_b, (unsigned int)n, (unsigned int)G, offsets, offsets + 1, 0, 64, s);
+  }
+  hipLaunchKernelGGL(k_fill_gid, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, offsets, G, n, gid_a);
+  size_t t2 = tb;
+  e = rocprim::radix_sort_pairs(temp, t2, codes_a, codes_b, gid_a, gid_b, n, 0, 64, s);
+  if (e != hipSuccess) return e;
+  t2 = tb;
+  e = rocprim::radix_sort_pairs(temp, t2, gid_b, gid_a, codes_b, codes_a, n, 0, bits_of(G ? G - 1 : 0), s); // stable: value order survives
+  *sorted = codes_a;
+  return e;
+}
+
+// codes_a / codes_b: n u64 each; gid_a / gid_b: n u32 each
 hipError_t launch_quantile(const AggExtArgs &a, const uint32_t *offsets, const uint32_t *indices, uint64_t n, uint64_t G, uint64_t *codes_a,
-                           uint64_t *codes_b, void *temp, size_t temp_bytes, double q, int interp, hipStream_t s) {
+                           uint64_t *codes_b, uint32_t *gid_a, uint32_t *gid_b, void *temp, size_t temp_bytes, double q, int interp, hipStream_t s) {
   if (!G) return hipSuccess;
+  const uint64_t *sorted = codes_b;
   if (n) {
     hipLaunchKernelGGL(k_gather_ordered, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, indices, n, codes_a);
-    hipError_t e = rocprim::segmented_radix_sort_keys(temp, temp_bytes, codes_a, codes_b, (unsigned int)n, (unsigned int)G, offsets, offsets + 1, 0, 64, s);
+    hipError_t e = sort_in_segments(offsets, n, G, codes_a, codes_b, gid_a, gid_b, temp, temp_bytes, &sorted, s);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(k_quantile, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, s, a, codes_b, offsets, G, q, interp);
+  hipLaunchKernelGGL(k_quantile, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, s, a, sorted, offsets, G, q, interp);
   return hipGetLastError();
 }
 
 // marks: (G / 16 + 1) u32; A.out: G u32 -- both zeroed here
 hipError_t launch_n_unique(const AggExtArgs &a, const uint32_t *offsets, const uint32_t *indices, uint64_t n, uint64_t G, uint64_t *codes_a,
-                           uint64_t *codes_b, uint32_t *marks, void *temp, size_t temp_bytes, hipStream_t s) {
+                           uint64_t *codes_b, uint32_t *gid_a, uint32_t *gid_b, uint32_t *marks, void *temp, size_t temp_bytes, hipStream_t s) {
   if (!G) return hipSuccess;
   hipError_t e = hipMemsetAsync(marks, 0, (G / 16 + 1) * 4, s);
   if (e == hipSuccess) e = hipMemsetAsync(a.out, 0, G * 4, s);
@@ -454,10 +517,11 @@ hipError_t launch_n_unique(const AggExtArgs &a, const uint32_t *offsets, const u
   if (n) {
     const unsigned grid = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_gather_exact, dim3(grid), dim3(256), 0, s, a, indices, offsets, n, G, codes_a, marks);
-    e = rocprim::segmented_radix_sort_keys(temp, temp_bytes, codes_a, codes_b, (unsigned int)n, (unsigned int)G, offsets, offsets + 1, 0, 64, s);
+    const uint64_t *sorted = codes_b;
+    e = sort_in_segments(offsets, n, G, codes_a, codes_b, gid_a, gid_b, temp, temp_bytes, &sorted, s);
     if (e != hipSuccess) return e;
     const uint32_t is_float = a.dtype == PLHIP_F32 || a.dtype == PLHIP_F64;
-    hipLaunchKernelGGL(k_count_changes, dim3(grid), dim3(256), 0, s, a, codes_b, offsets, n, G, is_float);
+    hipLaunchKernelGGL(k_count_changes, dim3(grid), dim3(256), 0, s, a, sorted, offsets, n, G, is_float);
   }
   hipLaunchKernelGGL(k_n_unique_finish, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, s, a, offsets, marks, G);
   return hipGetLastError();

@@ -396,6 +396,61 @@ def test_agg_groups_first_last_var_std(oracle, dt):
                                                rtol=1e-5 if gv.dtype == np.float32 else 1e-11, atol=0, err_msg=f"{kind} ddof={ddof}")
 
 
+@pytest.mark.parametrize("vdt", [np.int32, np.float64], ids=lambda d: np.dtype(d).name)
+@pytest.mark.parametrize("card", [20, 40_000], ids=["wave_mode", "thread_mode"])
+def test_csr_seams_with_a_heavy_key(oracle, vdt, card, monkeypatch):
+    """One key on 30 % of the rows (a 180 000-row group beside short ones): the group is cut into chunks of 4 096 rows for
+    sum / mean / min / max / var / std (k_agg_groups_long: several workgroups, fixed-order merge) and the values are
+    sorted inside the groups with two device-wide sorts for median / quantile / n_unique (no segment is one workgroup's)."""
+    rng = np.random.default_rng(211)
+    n = 600_000
+    k = rng.integers(0, card, n).astype(np.int32)
+    k[rng.random(n) < 0.3] = 7
+    keys = [Column("k", k)]
+    dt = np.dtype(vdt)
+    v = rand_col(rng, "v", vdt, n, null_frac=0.1, lo=-1000 if dt.kind == "i" else None, hi=1000 if dt.kind == "i" else None,
+                 nan_frac=0.01 if dt.kind == "f" else 0.0)
+    monkeypatch.delenv("PLHIP_FORCE_TWO_SORTS", raising=False)
+    g_o, g_p = oracle.Groups(keys, True), pa.group_tuples(keys, True)
+    assert g_p.n_groups == len(np.unique(k))
+    for kind in ALL_AGGS:
+        wv, wm = oracle.agg(None if kind == "count" else v, kind, g_o)
+        col = pa.agg_groups(None if kind == "count" else v, kind, g_p)
+        gv, gm = col.to_numpy(), col.valid_mask()
+        gm = np.ones(len(gv), bool) if gm is None else gm
+        assert np.array_equal(gm, wm), f"{kind}: validity"
+        assert gv.dtype == wv.dtype, kind
+        if gv.dtype.kind == "f":
+            np.testing.assert_allclose(gv[gm], wv[wm], rtol=1e-11, atol=0, equal_nan=True, err_msg=kind)
+        else:
+            assert np.array_equal(gv[gm], wv[wm]), kind
+    for kind in ("first", "last", "var", "std", "median", "n_unique"):
+        wv, wm = oracle.agg_ext(v, kind, g_o, 1)
+        got = pa.agg_groups(v, kind, g_p, ddof=1)
+        gv, gm = got.to_numpy(), got.valid_mask()
+        gm = np.ones(len(gv), bool) if gm is None else gm
+        assert gv.dtype == wv.dtype and np.array_equal(gm, wm), kind
+        if kind in ("first", "last", "n_unique"):
+            assert np.array_equal(gv[gm].view(np.uint8), wv[wm].view(np.uint8)), kind
+        else:
+            np.testing.assert_allclose(gv[gm].astype(np.float64), wv[wm].astype(np.float64), rtol=1e-10, atol=0, err_msg=kind)
+    # the two-sort route on uniform groups too (forced): the layout it produces must be the segmented sort's
+    monkeypatch.setenv("PLHIP_FORCE_TWO_SORTS", "1")
+    for kind in ("median", "n_unique"):
+        wv, wm = oracle.agg_ext(v, kind, g_o, 1)
+        got = pa.agg_groups(v, kind, g_p)
+        gv, gm = got.to_numpy(), got.valid_mask()
+        gm = np.ones(len(gv), bool) if gm is None else gm
+        assert np.array_equal(gm, wm) and np.array_equal(gv[gm], wv[wm], equal_nan=gv.dtype.kind == "f"), kind
+    from polars_amd.frame import agg_groups_quantile
+
+    got = agg_groups_quantile(v, 0.3, g_p, "linear")
+    wv, wm = oracle.agg_quantile(v, 0.3, "linear", g_o)
+    gv, gm = got.to_numpy(), got.valid_mask()
+    gm = np.ones(len(gv), bool) if gm is None else gm
+    assert np.array_equal(gm, wm) and np.array_equal(gv[gm], wv[wm], equal_nan=True), "quantile 0.3 linear"
+
+
 def test_eager_group_by_var_std_first_last():
     # test_group_by_var (crates/polars-core/src/frame/group_by/mod.rs:1134-1156) through the eager GroupBy mirror
     df = pa.DataFrame({"g": np.array([4, 4, 2], dtype=np.int32), "flt": np.array([1.0, 2.0, 3.0]), "int": np.array([1, 2, 3], dtype=np.int32)})
