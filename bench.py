@@ -104,7 +104,21 @@ def cpu_baseline(tensors, keys, vals, aggs, gpu_frame, budget_s=10.0):
         if dt >= budget_s or passes >= 200:
             break
     base = {"value": n * passes / dt, "unit": "rows/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
-            "sample": f"{passes} whole passes over the same {n} rows ({dt:.1f} s)"}
+            "sample": f"{passes} whole passes over the same {n} rows ({dt:.1f} s)",
+            "path": "A: partitioned hash maps of row-index lists, then gather-fold per group (hashing.rs:182-243 + aggregations/mod.rs)"}
+    if len(hk) == 1:  # path B: the streaming sink's accumulators, timed on the same rows
+        p2, t1 = 0, time.perf_counter()
+        while True:
+            g2 = orc.sink_group_by(hk[0], hv, aggs, n_threads=threads, outputs=False)
+            p2 += 1
+            d2 = time.perf_counter() - t1
+            if d2 >= budget_s / 2 or p2 >= 200:
+                break
+        base["path_b"] = {"value": n * p2 / d2, "unit": "rows/s", "cores": threads, "groups": int(g2),
+                          "groups_match_path_a": int(g2) == len(want[0][1]),
+                          "what": "PrimitiveGroupbySink restated (polars-pipe sinks/group_by/primitive/mod.rs:359-454): per-thread "
+                                  "partitioned hash maps of accumulators, 50 000-row morsels, sinks combined at the end",
+                          "sample": f"{p2} whole passes over the same {n} rows ({d2:.1f} s)"}
     return base, parity_check(hk, hv, aggs, want, gpu_frame)
 
 

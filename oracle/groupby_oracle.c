@@ -647,3 +647,179 @@ int orc_take_keys(const plhip_column_t *key, const orc_groups_t *g, void *out_va
   }
   return PLHIP_OK;
 }
+
+/* ---------------------------------------------------------------------------------------------- */
+/* Path B: the streaming engine's group-by sink (accumulators updated row by row, no index lists)   */
+/* ---------------------------------------------------------------------------------------------- */
+/* PrimitiveGroupbySink (crates/polars-pipe/src/executors/sinks/group_by/primitive/mod.rs:359-454): every thread owns a
+ * sink = P hash maps (P = the partition count, a power of two; partition = hash & (P - 1), polars-utils/src/
+ * functions.rs:15-19) from Key{hash, Option<value>} to an index into ONE flat vector of aggregators; a morsel is hashed
+ * (vec_hash), every row finds or inserts its key (insert_and_get, :497-531: new key -> `agg_fn.split()` per aggregation
+ * appended), then apply_aggregation feeds the row's values to the key's aggregators: SumAgg { sum: Option<K> }
+ * (aggregates/sum.rs:25-33), MeanAgg { sum: Option<K>, count } (mean.rs), MinMaxAgg, CountAgg.  At the end the sinks are
+ * combined pairwise (`combine`, :401-441: keys of `other` inserted into `self`, aggregators combined) and the result
+ * is produced partition by partition.  Restated for ONE primitive key column; aggregation states are kept in f64 /
+ * i64 as the benchmark's dtypes need them (i32 / i64 sums in i64, f64 sums and means in f64).  The CPU baseline's
+ * second data point: test infrastructure like the rest of this file. */
+typedef struct { int64_t i; double f; uint32_t count; uint8_t has; } sink_agg_t;
+typedef struct { uint64_t hash, key; uint32_t agg; uint8_t used, is_null; } sink_slot_t;
+typedef struct { sink_slot_t *slots; uint64_t cap, len; } sink_map_t;
+typedef struct {
+  sink_map_t *maps; /* P */
+  sink_agg_t *aggs; uint64_t n_aggs_len, aggs_cap;
+} sink_t;
+typedef struct {
+  const plhip_column_t *key, *values; const int *agg_col, *agg_kind; int n_aggs; uint64_t P;
+  int64_t n, morsel; int tid, n_threads; sink_t *sink; int rc;
+} sink_job_t;
+
+static int sink_map_grow(sink_map_t *m) {
+  uint64_t ncap = m->cap ? m->cap * 2 : 64;
+  sink_slot_t *ns = (sink_slot_t *)calloc(ncap, sizeof(sink_slot_t));
+  if (!ns) return PLHIP_ERR_OOM;
+  for (uint64_t i = 0; i < m->cap; i++) if (m->slots[i].used) {
+    uint64_t s = (m->slots[i].hash >> 7) & (ncap - 1);
+    while (ns[s].used) s = (s + 1) & (ncap - 1);
+    ns[s] = m->slots[i];
+  }
+  free(m->slots); m->slots = ns; m->cap = ncap;
+  return PLHIP_OK;
+}
+/* insert_and_get (:497-531) */
+static int64_t sink_insert_and_get(sink_t *S, uint64_t P, uint64_t h, uint64_t key, int is_null, int n_aggs) {
+  sink_map_t *m = &S->maps[h & (P - 1)];
+  if (m->len * 2 >= m->cap && sink_map_grow(m)) return -1;
+  uint64_t s = (h >> 7) & (m->cap - 1);
+  for (;; s = (s + 1) & (m->cap - 1)) {
+    sink_slot_t *e = &m->slots[s];
+    if (!e->used) {
+      if (S->n_aggs_len + (uint64_t)n_aggs > S->aggs_cap) {
+        uint64_t nc = S->aggs_cap ? S->aggs_cap * 2 : 4096;
+        sink_agg_t *na = (sink_agg_t *)realloc(S->aggs, nc * sizeof(sink_agg_t));
+        if (!na) return -1;
+        S->aggs = na; S->aggs_cap = nc;
+      }
+      e->used = 1; e->hash = h; e->key = key; e->is_null = (uint8_t)is_null; e->agg = (uint32_t)S->n_aggs_len;
+      memset(&S->aggs[S->n_aggs_len], 0, (size_t)n_aggs * sizeof(sink_agg_t)); /* agg_fn.split(): fresh state */
+      S->n_aggs_len += (uint64_t)n_aggs; m->len++;
+      return (int64_t)e->agg;
+    }
+    if (e->hash == h && e->is_null == is_null && (is_null || e->key == key)) return (int64_t)e->agg;
+  }
+}
+static inline void sink_pre_agg(sink_agg_t *a, int kind, const plhip_column_t *v, int64_t row) {
+  if (kind == PLHIP_AGG_COUNT) { a->count++; return; } /* CountAgg: rows, nulls included */
+  if (!col_valid(v, row)) return;                         /* (None, _) => {} */
+  const int64_t j = v->offset + row;
+  double f = 0; int64_t x = 0; int is_f = v->dtype == PLHIP_F32 || v->dtype == PLHIP_F64;
+  if (v->dtype == PLHIP_F32) f = (double)((const float *)v->values)[j];
+  else if (v->dtype == PLHIP_F64) f = ((const double *)v->values)[j];
+  else x = (int64_t)col_as_u64(v, row), x = (v->dtype == PLHIP_I32) ? (int64_t)(int32_t)x : x;
+  switch (kind) {
+    case PLHIP_AGG_SUM: if (is_f) a->f += f; else a->i += x; a->has = 1; break;
+    case PLHIP_AGG_MEAN: a->f += is_f ? f : (double)x; a->count++; a->has = 1; break;
+    case PLHIP_AGG_MIN: if (is_f) { if (!a->has || f < a->f) a->f = f; } else if (!a->has || x < a->i) a->i = x; a->has = 1; break;
+    case PLHIP_AGG_MAX: if (is_f) { if (!a->has || f > a->f) a->f = f; } else if (!a->has || x > a->i) a->i = x; a->has = 1; break;
+    default: break;
+  }
+}
+static inline void sink_combine_agg(sink_agg_t *a, const sink_agg_t *b, int kind, int is_f) {
+  if (kind == PLHIP_AGG_COUNT) { a->count += b->count; return; }
+  if (!b->has) return;
+  if (!a->has) { *a = *b; return; }
+  switch (kind) {
+    case PLHIP_AGG_SUM: a->f += b->f; a->i += b->i; break;
+    case PLHIP_AGG_MEAN: a->f += b->f; a->count += b->count; break;
+    case PLHIP_AGG_MIN: if (is_f) { if (b->f < a->f) a->f = b->f; } else if (b->i < a->i) a->i = b->i; break;
+    case PLHIP_AGG_MAX: if (is_f) { if (b->f > a->f) a->f = b->f; } else if (b->i > a->i) a->i = b->i; break;
+    default: break;
+  }
+}
+static void *sink_job(void *arg) { /* Sink::sink (:359-399) over this thread's morsels */
+  sink_job_t *J = (sink_job_t *)arg;
+  uint64_t *hashes = (uint64_t *)malloc((size_t)J->morsel * 8);
+  uint32_t *idx = (uint32_t *)malloc((size_t)J->morsel * 4);
+  if (!hashes || !idx) { J->rc = PLHIP_ERR_OOM; free(hashes); free(idx); return NULL; }
+  for (int64_t m0 = (int64_t)J->tid * J->morsel; m0 < J->n; m0 += (int64_t)J->n_threads * J->morsel) {
+    const int64_t m1 = m0 + J->morsel < J->n ? m0 + J->morsel : J->n, len = m1 - m0;
+    for (int64_t r = 0; r < len; r++) /* s.vec_hash (null -> a fixed hash: the seed-dependent value does not matter here) */
+      hashes[r] = col_valid(J->key, m0 + r) ? orc_folded_multiply(col_as_u64(J->key, m0 + r), ORC_MULTIPLE) : 0x9E3779B97F4A7C15ULL;
+    for (int64_t r = 0; r < len; r++) {
+      const int isn = !col_valid(J->key, m0 + r);
+      const int64_t a = sink_insert_and_get(J->sink, J->P, hashes[r], isn ? 0 : col_key_bits(J->key, m0 + r), isn, J->n_aggs);
+      if (a < 0) { J->rc = PLHIP_ERR_OOM; free(hashes); free(idx); return NULL; }
+      idx[r] = (uint32_t)a;
+    }
+    for (int g = 0; g < J->n_aggs; g++) { /* apply_aggregation: column by column over the morsel */
+      const plhip_column_t *v = J->agg_kind[g] == PLHIP_AGG_COUNT ? NULL : &J->values[J->agg_col[g]];
+      for (int64_t r = 0; r < len; r++) sink_pre_agg(&J->sink->aggs[idx[r] + (uint32_t)g], J->agg_kind[g], v, m0 + r);
+    }
+  }
+  free(hashes); free(idx);
+  return NULL;
+}
+/* out_keys: normalised key bits (col_key_bits) per group, out_key_valid: 0 for the null key, out_vals: n_aggs arrays of G
+ * doubles (integer sums exact below 2^53), out_valid: n_aggs arrays of G bytes.  Pass NULL outputs to time only; *n_groups
+ * is always set.  max_groups = capacity of the output arrays. */
+int orc_sink_group_by(const plhip_column_t *key, const plhip_column_t *values, int n_values, const int *agg_col, const int *agg_kind,
+                      int n_aggs, int n_threads, int64_t morsel, int64_t max_groups, uint64_t *out_keys, uint8_t *out_key_valid,
+                      double *out_vals, uint8_t *out_valid, int64_t *n_groups) {
+  (void)n_values;
+  if (!key || n_aggs < 1 || n_threads < 1 || morsel < 1) return PLHIP_ERR_INVALID;
+  const uint64_t P = set_partition_size(n_threads);
+  const int T = n_threads;
+  sink_t *sinks = (sink_t *)calloc((size_t)T, sizeof(sink_t));
+  sink_job_t *jobs = (sink_job_t *)calloc((size_t)T, sizeof(sink_job_t));
+  pthread_t *tids = (pthread_t *)calloc((size_t)T, sizeof(pthread_t));
+  int rc = PLHIP_OK;
+  for (int t = 0; t < T; t++) {
+    sinks[t].maps = (sink_map_t *)calloc(P, sizeof(sink_map_t));
+    jobs[t] = (sink_job_t){key, values, agg_col, agg_kind, n_aggs, P, key->length, morsel, t, T, &sinks[t], PLHIP_OK};
+  }
+  for (int t = 0; t < T; t++) pthread_create(&tids[t], NULL, sink_job, &jobs[t]);
+  for (int t = 0; t < T; t++) { pthread_join(tids[t], NULL); if (jobs[t].rc) rc = jobs[t].rc; }
+  /* combine: the reference reduces the sinks pairwise; here every other sink is folded into sink 0 (same operations, same result) */
+  int is_f[64];
+  for (int g = 0; g < n_aggs && g < 64; g++)
+    is_f[g] = agg_kind[g] != PLHIP_AGG_COUNT && (values[agg_col[g]].dtype == PLHIP_F32 || values[agg_col[g]].dtype == PLHIP_F64);
+  for (int t = 1; t < T && !rc; t++)
+    for (uint64_t p = 0; p < P && !rc; p++) {
+      sink_map_t *mo = &sinks[t].maps[p];
+      for (uint64_t s = 0; s < mo->cap; s++) if (mo->slots[s].used) {
+        const sink_slot_t *e = &mo->slots[s];
+        const int64_t a = sink_insert_and_get(&sinks[0], P, e->hash, e->key, e->is_null, n_aggs);
+        if (a < 0) { rc = PLHIP_ERR_OOM; break; }
+        for (int g = 0; g < n_aggs; g++) sink_combine_agg(&sinks[0].aggs[a + g], &sinks[t].aggs[e->agg + (uint32_t)g], agg_kind[g], is_f[g]);
+      }
+    }
+  /* pre_finalize: partition by partition */
+  int64_t G = 0;
+  for (uint64_t p = 0; p < P && !rc; p++) {
+    sink_map_t *m = &sinks[0].maps[p];
+    for (uint64_t s = 0; s < m->cap; s++) if (m->slots[s].used) {
+      if (out_keys && G < max_groups) {
+        const sink_slot_t *e = &m->slots[s];
+        out_keys[G] = e->key; out_key_valid[G] = !e->is_null;
+        for (int g = 0; g < n_aggs; g++) {
+          const sink_agg_t *a = &sinks[0].aggs[e->agg + (uint32_t)g];
+          double v = 0; uint8_t ok = 1;
+          switch (agg_kind[g]) {
+            case PLHIP_AGG_COUNT: v = (double)a->count; break;
+            case PLHIP_AGG_SUM: v = is_f[g] ? a->f : (double)a->i; break; /* a SumAgg that saw no value finalizes to 0 in the frame */
+            case PLHIP_AGG_MEAN: ok = a->has; v = ok ? a->f / (double)a->count : 0; break;
+            default: ok = a->has; v = is_f[g] ? a->f : (double)a->i; break;
+          }
+          out_vals[(int64_t)g * max_groups + G] = v; out_valid[(int64_t)g * max_groups + G] = ok;
+        }
+      }
+      G++;
+    }
+  }
+  *n_groups = G;
+  for (int t = 0; t < T; t++) {
+    for (uint64_t p = 0; p < P; p++) free(sinks[t].maps[p].slots);
+    free(sinks[t].maps); free(sinks[t].aggs);
+  }
+  free(sinks); free(jobs); free(tids);
+  return rc;
+}

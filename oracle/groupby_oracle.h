@@ -65,6 +65,10 @@ int orc_agg_partitioned(const plhip_column_t *values, int kind, const orc_groups
                         void *out_values, uint8_t *out_valid);
 
 /* Gather key output (GroupBy::keys_sliced, group_by/mod.rs:262-296): out[g] = key[first[g]]. */
+/* Path B (streaming sink, polars-pipe PrimitiveGroupbySink): see groupby_oracle.c */
+int orc_sink_group_by(const plhip_column_t *key, const plhip_column_t *values, int n_values, const int *agg_col, const int *agg_kind,
+                      int n_aggs, int n_threads, int64_t morsel, int64_t max_groups, uint64_t *out_keys, uint8_t *out_key_valid,
+                      double *out_vals, uint8_t *out_valid, int64_t *n_groups);
 int orc_take_keys(const plhip_column_t *key, const orc_groups_t *g, void *out_values, uint8_t *out_valid);
 
 #ifdef __cplusplus

@@ -50,6 +50,8 @@ def lib():
         L.orc_agg.argtypes = [P(_ffi.ColumnStruct), C.c_int, P(_Groups), C.c_void_p, C.c_void_p, C.c_int]
         L.orc_agg_partitioned.argtypes = [P(_ffi.ColumnStruct), C.c_int, P(_Groups), C.c_int, C.c_void_p, C.c_void_p]
         L.orc_take_keys.argtypes = [P(_ffi.ColumnStruct), P(_Groups), C.c_void_p, C.c_void_p]
+        L.orc_sink_group_by.argtypes = [P(_ffi.ColumnStruct), P(_ffi.ColumnStruct), C.c_int, P(C.c_int), P(C.c_int), C.c_int, C.c_int,
+                                        C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, P(C.c_int64)]
         _lib = L
     return _lib
 
@@ -141,6 +143,31 @@ def group_by_agg(keys: list[Column], values: list[Column], aggs: list[tuple[int,
         v, m = agg(col, kind, groups, n_threads, partitioned)
         out.append((f"{values[ci].name if col is not None else 'count'}_{kind}", v, m))
     return out, groups
+
+
+def sink_group_by(key: Column, values: list[Column], aggs: list[tuple[int, str]], n_threads: int = 1, morsel: int = 50_000,
+                  max_groups: int | None = None, outputs: bool = True):
+    """Path B, the streaming engine's PrimitiveGroupbySink (crates/polars-pipe/src/executors/sinks/group_by/primitive/
+    mod.rs:359-454): per-thread sinks of partitioned hash maps with one accumulator per (key, aggregation), morsel by morsel,
+    combined at the end.  One primitive key.  Returns (key bits u64, key valid, [f64 values per agg], [valid per agg]) in
+    sink order (partition by partition); with outputs=False only the group count (timing runs)."""
+    L = lib()
+    n = len(key)
+    cap = int(max_groups if max_groups is not None else max(n, 1))
+    kinds = (C.c_int * len(aggs))(*[_ffi.AGG_NAMES[k] for _, k in aggs])
+    cols = (C.c_int * len(aggs))(*[max(ci, 0) for ci, _ in aggs])
+    varr = (_ffi.ColumnStruct * max(len(values), 1))(*[v.struct() for v in values])
+    ks = key.struct()
+    ng = C.c_int64(0)
+    if not outputs:
+        _check(L.orc_sink_group_by(C.byref(ks), varr, len(values), cols, kinds, len(aggs), n_threads, morsel, 0, None, None, None, None, C.byref(ng)))
+        return int(ng.value)
+    ok, okv = np.empty(cap, np.uint64), np.empty(cap, np.uint8)
+    ov, ovv = np.empty((len(aggs), cap), np.float64), np.empty((len(aggs), cap), np.uint8)
+    _check(L.orc_sink_group_by(C.byref(ks), varr, len(values), cols, kinds, len(aggs), n_threads, morsel, cap, ok.ctypes.data, okv.ctypes.data,
+                               ov.ctypes.data, ovv.ctypes.data, C.byref(ng)))
+    g = int(ng.value)
+    return ok[:g], okv[:g].astype(bool), [ov[i, :g] for i in range(len(aggs))], [ovv[i, :g].astype(bool) for i in range(len(aggs))]
 
 
 def sorted_key_groups(key: Column) -> list[list[int]]:
