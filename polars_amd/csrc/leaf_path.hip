@@ -16,6 +16,7 @@
 
 #include "device.hpp"
 #include "fast.hpp"
+#include "shapes.hpp"
 
 extern __shared__ __align__(16) uint8_t lsm[];
 
@@ -102,38 +103,42 @@ DEVINL void fold_state(uint32_t op, uint64_t &state, uint64_t operand) {
   }
 }
 
-// one row (position `pos` in the partitioned copy; raw bits of the first LS_NPRE value columns already here) into the states
+// one row (position `pos` in the partitioned copy; raw bits of the first LS_NPRE value columns already here) into the states.
+// SH: the query's shape (shapes.hpp): a static shape unrolls the accumulator list into straight-line code on registers
+template <typename SH>
 DEVINL void fold_row(const Plan &P, uint64_t (&st)[LS_MAX_ACCS], uint32_t pos, const uint64_t (&pre)[LS_NPRE]) {
   int cur_src = -2;
   uint64_t raw[1] = {0};
   bool vok = true;
-#pragma unroll
-  for (int a = 0; a < LS_MAX_ACCS; a++) {
-    if (a >= P.n_accs) break;
-    const uint32_t op = P.accs[a].op;
-    const int src = P.accs[a].src;
-    if (op == ACC_CNT_ALL) { st[a] += 1; continue; }
+  auto body = [&](int a) {
+    const uint32_t op = SH::acc_op(P, a);
+    const int src = SH::acc_src(P, a);
+    if (op == ACC_CNT_ALL) { st[a] += 1; return; }
     if (src != cur_src) { // accumulators are ordered by source column
       cur_src = src;
-      const ValSpec V = P.vals[src];
-      vok = val_valid(V, (int64_t)pos);
+      vok = SH::val_nullable(P, src) ? val_valid(P.vals[src], (int64_t)pos) : true;
       if (src < LS_NPRE) {
 #pragma unroll
         for (int c = 0; c < LS_NPRE; c++) if (src == c) raw[0] = pre[c];
       } else {
         const uint32_t row1[1] = {pos};
-        load_raw<1, false>(V.values, wbytes(V.dtype), row1, raw);
+        load_raw<1, false>(P.vals[src].values, wbytes(SH::val_dtype(P, src)), row1, raw);
       }
     }
-    if (!vok) continue;
-    if (op == ACC_CNT_VALID) { st[a] += 1; continue; }
+    if (!vok) return;
+    if (op == ACC_CNT_VALID) { st[a] += 1; return; }
     uint64_t opnd[1];
-    raw_to_operands<1>(P.vals[src].dtype, P.accs[a].conv, raw, opnd);
+    raw_to_operands<1>(SH::val_dtype(P, src), SH::acc_conv(P, a), raw, opnd);
     fold_state(op, st[a], opnd[0]);
+  };
+  if constexpr (SH::STATIC) static_for<0, SH::NA>(body);
+  else {
+#pragma unroll
+    for (int a = 0; a < LS_MAX_ACCS; a++) if (a < P.n_accs) body(a);
   }
 }
 
-template <typename KS>
+template <typename KS, typename SH>
 __global__ void __launch_bounds__(LS_BLOCK) k_leaf_sort(Plan P, LeafSortArgs A, OutPlan O) {
   __shared__ uint32_t s_cnt[LS_WAVES], s_pre[LS_WAVES], s_ok[LS_WAVES];
   __shared__ uint32_t s_base, s_over;
@@ -163,27 +168,36 @@ __global__ void __launch_bounds__(LS_BLOCK) k_leaf_sort(Plan P, LeafSortArgs A, 
   uint32_t n_runs = 0;
   uint64_t c[8];
   if (ok && total) {
-    // ---- stage keys and positions (a lane per tile's run, eight loads in flight) -------------------------------------------
-    uint32_t maxlen = len;
+    // ---- keys and positions: the runs laid out flat over the lanes (element r * 64 + lane), eight coalesced loads in flight; the
+    // composites are built in registers right away -- a sort does not care where its input sits -- and only the positions go to LDS
+    auto run_of = [&](uint32_t f) -> uint32_t { // the run that holds flat element f: the number of runs that end at or before f
+      uint32_t lo = 0;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)maxlen, off); maxlen = o > maxlen ? o : maxlen; }
+      for (uint32_t step = 32; step; step >>= 1) {
+        const uint32_t v = (uint32_t)__shfl((int)incl, (int)(lo + step - 1));
+        if (v <= f) lo += step;
+      }
+      return lo & 63u;
+    };
     const KS *pk = (const KS *)A.pkeys;
-    for (uint32_t k0 = 0; k0 < maxlen; k0 += 8) {
-      KS kk[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) kk[u] = (k0 + u < len) ? pk[st + k0 + u] : (KS)0;
-#pragma unroll
-      for (int u = 0; u < 8; u++)
-        if (k0 + u < len) { wk[excl + k0 + u] = (uint64_t)kk[u]; wg[excl + k0 + u] = st + k0 + u; }
-    }
-    wave_lds_fence();
-    // ---- sort (key << 9 | slot) ---------------------------------------------------------------------------------------------
+    const uint32_t p_any = (uint32_t)__shfl((int)st, (int)run_of(0u)); // dead lanes read the leaf's first row
+    uint32_t posr[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-      const uint32_t e = lane * 8u + (uint32_t)r;
-      c[r] = e < total ? ((wk[e] << LS_IDXB) | (uint64_t)e) : ~0ull;
+      const uint32_t e = (uint32_t)r * 64u + lane;
+      const uint32_t run = run_of(e);
+      const uint32_t rs = (uint32_t)__shfl((int)st, (int)run), rx = (uint32_t)__shfl((int)excl, (int)run);
+      posr[r] = e < total ? rs + (e - rx) : p_any;
     }
-    wave_lds_fence();
+    KS kk[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) kk[r] = pk[posr[r]];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const uint32_t e = (uint32_t)r * 64u + lane;
+      if (e < total) wg[e] = posr[r];
+      c[r] = e < total ? (((uint64_t)kk[r] << LS_IDXB) | (uint64_t)e) : ~0ull;
+    }
     bitonic512(c, lane);
     // ---- run heads ----------------------------------------------------------------------------------------------------------
     uint64_t up_lo = (uint64_t)(uint32_t)__shfl_up((int)(uint32_t)c[7], 1), up_hi = (uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(c[7] >> 32), 1);
@@ -257,7 +271,7 @@ __global__ void __launch_bounds__(LS_BLOCK) k_leaf_sort(Plan P, LeafSortArgs A, 
 #pragma unroll
       for (int a = 0; a < LS_MAX_ACCS; a++) stt[a] = a < P.n_accs ? P.accs[a].init : 0ull;
       const uint64_t p1[LS_NPRE] = {pre0, pre1};
-      fold_row(P, stt, pos_u, p1);
+      fold_row<SH>(P, stt, pos_u, p1);
       for (uint32_t el = rs_u + 1; el < re_u; el++) { // (rare here: more than one row in the group)
         const uint32_t pp = wg[(uint32_t)wk[el] & (LS_WCAP - 1u)];
         uint64_t p2[LS_NPRE];
@@ -271,7 +285,7 @@ __global__ void __launch_bounds__(LS_BLOCK) k_leaf_sort(Plan P, LeafSortArgs A, 
             p2[v] = raw1[0];
           }
         }
-        fold_row(P, stt, pp, p2);
+        fold_row<SH>(P, stt, pp, p2);
       }
       const uint64_t g = gbase + run;
       for (int o = 0; o < O.n_outs; o++) {
@@ -319,15 +333,28 @@ __global__ void __launch_bounds__(LS_BLOCK) k_leaf_sort(Plan P, LeafSortArgs A, 
 
 } // namespace
 
-void launch_leaf_sort(const Plan &p2, const LeafSortArgs &a, const OutPlan &o, int key_bytes, hipStream_t s) {
+template <typename KS, typename SH>
+static void launch_leaf_sort_t(const Plan &p2, const LeafSortArgs &a, const OutPlan &o, size_t lds, uint32_t grid, hipStream_t s) {
   static bool once = false;
-  const size_t lds = (size_t)LS_WAVES * LS_WAVE_BYTES;
   if (!once) {
-    if (hipFuncSetAttribute((const void *)k_leaf_sort<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess) (void)hipGetLastError();
-    if (hipFuncSetAttribute((const void *)k_leaf_sort<uint64_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess) (void)hipGetLastError();
+    if (hipFuncSetAttribute((const void *)k_leaf_sort<KS, SH>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess) (void)hipGetLastError();
     once = true;
   }
+  hipLaunchKernelGGL((k_leaf_sort<KS, SH>), dim3(grid), dim3(LS_BLOCK), lds, s, p2, a, o);
+}
+
+void launch_leaf_sort(const Plan &p2, const LeafSortArgs &a, const OutPlan &o, int key_bytes, hipStream_t s) {
+  const size_t lds = (size_t)LS_WAVES * LS_WAVE_BYTES;
   const uint32_t grid = (a.n_leaves + LS_WAVES - 1) / LS_WAVES;
-  if (key_bytes == 4) hipLaunchKernelGGL(k_leaf_sort<uint32_t>, dim3(grid), dim3(LS_BLOCK), lds, s, p2, a, o);
-  else hipLaunchKernelGGL(k_leaf_sort<uint64_t>, dim3(grid), dim3(LS_BLOCK), lds, s, p2, a, o);
+  // the one-row-per-group shapes that have a static form (BASELINE config 3 and its f64-first twin); everything else interprets the plan
+  const int sid = find_shape(p2);
+#define LS_GO(SH)                                                                         \
+  do {                                                                                    \
+    if (key_bytes == 4) launch_leaf_sort_t<uint32_t, SH>(p2, a, o, lds, grid, s);         \
+    else launch_leaf_sort_t<uint64_t, SH>(p2, a, o, lds, grid, s);                        \
+  } while (0)
+  if (sid == 3) LS_GO(ShWide);
+  else if (sid == 6) LS_GO(ShWideF);
+  else LS_GO(RtShape);
+#undef LS_GO
 }
