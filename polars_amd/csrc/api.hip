@@ -632,7 +632,9 @@ void resolve_timing() {
   if (!direct) hipEventElapsedTime(&c.k_ms[0], c.ev[1], c.ev[4]);
   hipEventElapsedTime(&c.k_ms[1], direct ? c.ev[1] : c.ev[4], c.ev[5]);
   if (merged) hipEventElapsedTime(&c.k_ms[2], c.ev[5], c.ev[2]);
-  const char *names[3] = {"k_tile_sort", dense ? "k_dense_fold" : (direct ? "k_fold_rows" : "k_fold_runs"), dense ? "k_dense_merge" : "k_merge_emit"};
+  const bool leaf = c.strategy == "leafsort";
+  const char *names[3] = {"k_tile_sort", dense ? "k_dense_fold" : (direct ? "k_fold_rows" : (leaf ? "k_leaf_sort" : "k_fold_runs")),
+                          dense ? "k_dense_merge" : "k_merge_emit"};
   int dom = 0;
   for (int i = 1; i < 3; i++) if (c.k_ms[i] > c.k_ms[dom]) dom = i;
   c.dom_ms = c.k_ms[dom]; c.dom_kernel = names[dom]; c.part_ms = c.k_ms[0]; c.agg_ms = c.k_ms[1];
