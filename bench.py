@@ -402,7 +402,8 @@ def main():
         }
         if phases:  # shuffle bytes and time reported separately
             line["sharded_step_ms"] = {k: sum(p.get(k, 0.0) for p in phases) / len(phases) for k in phases[0]}
-            line["shuffle"] = {"bytes_sent_per_rank": eng.last_shuffle_bytes, "protocol": eng.last_protocol, "host_syncs_per_step": eng.last_host_syncs}
+            line["shuffle"] = {"bytes_sent_per_rank": eng.last_shuffle_bytes, "protocol": eng.last_protocol, "host_syncs_per_step": eng.last_host_syncs,
+                               "transport": eng.transport}
         if world == 1 and not rehearse and not args.no_cpu_baseline:
             def gpu_frame():  # the timed configuration once more, result copied to the host
                 handle, out = pa.group_by_agg_raw(keys, vals, agg_codes, qflags, hint)

@@ -86,10 +86,27 @@ class _HostTransport:
     buffers are copied to the host with plhip_memcpy (the library has drained its stream before it calls), exchanged
     with dist.all_to_all_single, and copied back.  Rehearsal transport: several ranks on one GPU."""
 
-    def __init__(self, group, world: int):
-        self.group, self.world = group, world
+    def __init__(self, group, world: int, device=None):
+        # device = None: stage through host memory (gloo); a torch device: the group moves device memory itself (NCCL) and
+        # the buffers are copied device-to-device into torch-owned tensors -- the fallback when the library's own RCCL
+        # communicator cannot be made
+        self.group, self.world, self.device = group, world, device
         self.a2a = _ffi.ALLTOALL_FN(self._a2a)
         self.a2av = _ffi.ALLTOALLV_FN(self._a2av)
+
+    def _buf(self, n):
+        import torch
+
+        return torch.empty(max(n, 1), dtype=torch.uint8, device=self.device if self.device is not None else "cpu")[:n]
+
+    def _loc(self):
+        return _ffi.DEVICE if self.device is not None else _ffi.HOST
+
+    def _done(self):
+        if self.device is not None:
+            import torch
+
+            torch.cuda.current_stream(self.device).synchronize()
 
     def _a2a(self, user, send, recv, bytes_per_peer):
         try:
@@ -97,11 +114,11 @@ class _HostTransport:
             import torch.distributed as dist
 
             n = int(bytes_per_peer) * self.world
-            hs = torch.empty(max(n, 1), dtype=torch.uint8)[:n]
-            hr = torch.empty_like(hs)
-            _ffi.check(_ffi.lib().plhip_memcpy(hs.data_ptr(), _ffi.HOST, send, _ffi.DEVICE, n))
+            hs, hr = self._buf(n), self._buf(n)
+            _ffi.check(_ffi.lib().plhip_memcpy(hs.data_ptr(), self._loc(), send, _ffi.DEVICE, n))
             dist.all_to_all_single(hr, hs, group=self.group)
-            _ffi.check(_ffi.lib().plhip_memcpy(recv, _ffi.DEVICE, hr.data_ptr(), _ffi.HOST, n))
+            self._done()
+            _ffi.check(_ffi.lib().plhip_memcpy(recv, _ffi.DEVICE, hr.data_ptr(), self._loc(), n))
             return 0
         except Exception:  # never unwind into C
             import traceback
@@ -116,13 +133,13 @@ class _HostTransport:
 
             sb = [int(send_bytes[p]) for p in range(self.world)]
             rb = [int(recv_bytes[p]) for p in range(self.world)]
-            hs = torch.empty(max(sum(sb), 1), dtype=torch.uint8)[:sum(sb)]
-            hr = torch.empty(max(sum(rb), 1), dtype=torch.uint8)[:sum(rb)]
+            hs, hr = self._buf(sum(sb)), self._buf(sum(rb))
             if sum(sb):
-                _ffi.check(_ffi.lib().plhip_memcpy(hs.data_ptr(), _ffi.HOST, send, _ffi.DEVICE, sum(sb)))
+                _ffi.check(_ffi.lib().plhip_memcpy(hs.data_ptr(), self._loc(), send, _ffi.DEVICE, sum(sb)))
             dist.all_to_all_single(hr, hs, output_split_sizes=rb, input_split_sizes=sb, group=self.group)
+            self._done()
             if sum(rb):
-                _ffi.check(_ffi.lib().plhip_memcpy(recv, _ffi.DEVICE, hr.data_ptr(), _ffi.HOST, sum(rb)))
+                _ffi.check(_ffi.lib().plhip_memcpy(recv, _ffi.DEVICE, hr.data_ptr(), self._loc(), sum(rb)))
             return 0
         except Exception:
             import traceback
@@ -341,15 +358,37 @@ class HipEngine:
             _ffi.check(L.plhip_comm_init_host(world, rank, tr.a2a, tr.a2av, None, C.byref(comm)))
             self._comms[key] = (comm, tr)
         else:
+            import os
+
+            # the library's own RCCL communicator; if it cannot be made on EVERY rank (no librccl the loader can find, an id that
+            # could not be drawn) all ranks agree on the fallback: the group's own all_to_all_single through the host transport
+            ok = os.environ.get("PLHIP_EXCHANGE_TRANSPORT", "rccl") != "torch"
             idbuf = (C.c_uint8 * _ffi.COMM_ID_BYTES)()
-            if rank == 0:
-                _ffi.check(L.plhip_comm_unique_id(idbuf))
-            t = torch.tensor(list(idbuf), dtype=torch.uint8, device=self.device)
+            if ok and rank == 0:
+                ok = L.plhip_comm_unique_id(idbuf) == 0
+            t = torch.tensor(list(idbuf) + [1 if ok else 0], dtype=torch.uint8, device=self.device)
             dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-            idbuf = (C.c_uint8 * _ffi.COMM_ID_BYTES)(*t.cpu().tolist())
-            _ffi.check(L.plhip_comm_init_rccl(idbuf, world, rank, C.byref(comm)))
-            self._comms[key] = (comm, None)
+            vals = t.cpu().tolist()
+            ok = bool(vals[-1])
+            if ok:
+                idbuf = (C.c_uint8 * _ffi.COMM_ID_BYTES)(*vals[:-1])
+                ok = L.plhip_comm_init_rccl(idbuf, world, rank, C.byref(comm)) == 0
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            if int(flag.item()) == 1:
+                self._comms[key] = (comm, None)
+                self.transport = "rccl (library-side ncclSend / ncclRecv)"
+            else:
+                if ok:
+                    L.plhip_comm_free(comm)
+                comm = C.c_void_p()
+                tr = _HostTransport(group, world, device=self.device)
+                _ffi.check(L.plhip_comm_init_host(world, rank, tr.a2a, tr.a2av, None, C.byref(comm)))
+                self._comms[key] = (comm, tr)
+                self.transport = "torch.distributed all_to_all_single (fallback: " + L.plhip_last_error().decode()[:120] + ")"
         return comm
+
+    transport = "host (gloo rehearsal)"
 
     _comms: dict = {}
 

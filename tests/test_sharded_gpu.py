@@ -99,6 +99,29 @@ def test_sharded_rccl_world1_dense_codes_and_device_inputs(oracle, rccl_world1):
     util.assert_frames_match(_frame(res), util.oracle_to_np(want), 1, what="sharded, dense local pass")
 
 
+def test_sharded_torch_transport_fallback(oracle, rccl_world1, monkeypatch):
+    """When the library's own RCCL communicator cannot be made, every rank falls back to the group's all_to_all_single
+    (device tensors) behind the same entry point: forced here."""
+    import torch
+
+    from polars_amd import distributed as pd_
+
+    monkeypatch.setenv("PLHIP_EXCHANGE_TRANSPORT", "torch")
+    monkeypatch.setattr(pd_.HipEngine, "_comms", {})
+    rng = np.random.default_rng(77)
+    n = 300_000
+    keys = [Column("k", rng.integers(0, 5000, n).astype(np.int64))]
+    vals = [Column("v", rng.integers(-9, 9, n).astype(np.int32)), Column("w", np.round(rng.uniform(0, 1, n), 6))]
+    aggs = [(0, "sum"), (1, "mean"), (0, "max"), (0, "count")]
+    eng = pd_.HipEngine(torch.device("cuda:0"))
+    for hint in (5000, 0):
+        res = pd_.group_by_agg_sharded(keys, vals, aggs, device=torch.device("cuda:0"), engine=eng, n_groups_hint=hint, force_exchange=True)
+        want, _ = oracle.group_by_agg(keys, vals, aggs)
+        util.assert_frames_match(_frame(res), util.oracle_to_np(want), 1, what=f"sharded, torch transport, hint {hint}")
+    assert eng.transport.startswith("torch.distributed")
+    monkeypatch.setattr(pd_.HipEngine, "_comms", {})
+
+
 def test_sharded_argument_errors(rccl_world1):
     import ctypes as C
 
