@@ -317,10 +317,13 @@ def main():
         widths = [_ffi.code_np_dtype(cs.dtype).itemsize for cs in out_cols]
         L.plhip_result_free(handle0)
 
+        handle = C.c_void_p()
+        call_args = (karr, len(keys), varr, len(vals), aarr, len(agg_codes), _ffi.FLAG_OUTPUT_DEVICE | qflags, C.byref(opts), C.byref(handle))
+
         def step():
-            handle = C.c_void_p()
-            _ffi.check(L.plhip_group_by_agg_opts(karr, len(keys), varr, len(vals), aarr, len(agg_codes), _ffi.FLAG_OUTPUT_DEVICE | qflags,
-                                                 C.byref(opts), C.byref(handle)))
+            rc = L.plhip_group_by_agg_opts(*call_args)
+            if rc:
+                _ffi.check(rc)
             g = L.plhip_result_num_rows(handle)  # the result frame stays in HBM; its row count is on the host
             L.plhip_result_free(handle)
             return g, widths
@@ -335,18 +338,28 @@ def main():
         step()
     sync()
     kernel_ms, dom_ms, parts, dom_names, phases = [], [], [], [], []
+    # the library's HIP-event times of every step are read inside the timed region; the ctypes out-parameters are built once
+    # (three object constructions per call cost more than the call)
+    import ctypes as C
+
+    f_tot, f_dom, f_name, f_a, f_b, f_c = C.c_float(), C.c_float(), C.c_char_p(), C.c_float(), C.c_float(), C.c_float()
+    r_ms = (C.byref(f_tot), C.byref(f_dom), C.byref(f_name))
+    r_bd = (C.byref(f_a), C.byref(f_b), C.byref(f_c))
+    sharded = world > 1 or rehearse
     t0 = time.perf_counter()
     for _ in range(steps):
         g, out_widths = step()
-        if world > 1 or rehearse:
+        if sharded:
             # the sharded step makes several library calls: the engine kept the kernel times of the LOCAL partial pass
             # (the pass over this rank's rows) and the wall time of every phase of the step
             tot, dom, dom_name = eng.last_partial_kernel_ms
             parts.append(eng.last_partial_breakdown)
             phases.append(dict(eng.last_phase_ms))
         else:
-            tot, dom, dom_name = pa.last_kernel_ms()  # HIP events on the library's own stream, recorded live
-            parts.append(pa.last_kernel_breakdown())
+            L.plhip_last_kernel_ms(*r_ms)  # HIP events on the library's own stream, recorded live
+            L.plhip_last_kernel_breakdown(*r_bd)
+            tot, dom, dom_name = f_tot.value, f_dom.value, f_name.value
+            parts.append((f_a.value, f_b.value, f_c.value))
         kernel_ms.append(tot)
         dom_ms.append(dom)
         dom_names.append(dom_name)
@@ -371,6 +384,7 @@ def main():
         tot_avg = sum(kernel_ms) / len(kernel_ms)
         achieved = abytes / (dom_avg * 1e-3) / 1e9 if dom_avg > 0 else 0.0
         dom_name = max(set(dom_names), key=dom_names.count)
+        dom_name = dom_name.decode() if isinstance(dom_name, bytes) else dom_name
         traffic, traffic_kernels = measured_traffic(args.workload + ("_na" if args.na else ""), n, strategy)
         acc_dtype = {"q1": "i32", "q3": "i32+f64", "q5": "i32+f64", "c3": "i64+f64", "c5": "i64+f64"}[args.workload]
         line = {

@@ -2016,7 +2016,6 @@ int32_t group_by_agg_impl(const plhip_column_t *keys, int32_t n_keys, const plhi
 
   Lowered L{};
   L.P.n_rows = n;
-  HIP_TRY(hipEventRecord(c.ev[0], c.stream));
   L.n_out_keys = n_keys;
   if ((rc = build_keys(L.P, dk, st, L.KG))) return rc;
   if ((rc = build_aggs(L, dv, aggs, n_aggs, flags))) return rc;
@@ -2075,6 +2074,7 @@ int32_t group_by_agg_impl(const plhip_column_t *keys, int32_t n_keys, const plhi
     if (handled) return PLHIP_OK;
     strategy = PLHIP_STRATEGY_AUTO;
   }
+  HIP_TRY(hipEventRecord(c.ev[0], c.stream)); // the general path's timing starts here (the LDS-only pipelines above record their own events)
   uint64_t g_est = (uint64_t)n;
   if (n >= (1 << 14) && (rc = estimate_groups(P, g_est))) return rc;
   if (strategy == PLHIP_STRATEGY_AUTO && (flags & PLHIP_FLAG_MAINTAIN_ORDER) && n >= (1 << 20) && g_est > (1u << 16)) {
