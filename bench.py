@@ -302,9 +302,14 @@ def main():
         eng = pdist.HipEngine(dev)
         eng.dense_keys = bool(qflags)  # the local pass takes the dense-code path as the single-GPU run does
 
-        def step():
-            res = pdist.group_by_agg_sharded(keys, vals, aggs, device=dev, engine=eng, n_groups_hint=hint, force_exchange=rehearse)
-            return res[0].t.numel(), [_ffi.code_np_dtype(c.code).itemsize for c in res]
+        group = None  # the default process group
+
+        def step():  # ONE library call per rank; the result frame stays in HBM, its row count is on the host
+            handle, cols = eng.sharded_raw(keys, vals, aggs, group, hint)
+            g = L.plhip_result_num_rows(handle)
+            widths = [_ffi.code_np_dtype(cs.dtype).itemsize for cs in cols]
+            L.plhip_result_free(handle)
+            return g, widths
     else:
         import ctypes as C
 

@@ -66,6 +66,7 @@ struct Ctx {
   // fast path: the last kernel publishes the flag block here (pinned, coherent, device-visible) and the host
   // spins on its first 64-bit word instead of queueing a device-to-host copy and waiting for the stream
   uint32_t *host_sig = nullptr, *host_sig_dev = nullptr;
+  uint64_t *host_hdr = nullptr, *host_hdr_dev = nullptr; // pinned, device-mapped: the slot headers of the sharded path's exchange
   uint32_t seq = 0;
   bool hot_clean = false;  // the heavy-hitter words behind the flag block (FLAGS_HOT_OFF ..) are zero
   int timing_pending = 0; // 1: direct, 2: tilesort (S == 1), 3: tilesort + merge -- event times not read yet
@@ -88,6 +89,7 @@ struct Ctx {
     for (auto &e : ev) if (e) hipEventDestroy(e);
     if (host_flags) hipHostFree(host_flags);
     if (host_sig) hipHostFree(host_sig);
+    if (host_hdr) hipHostFree(host_hdr);
     if (stream) hipStreamDestroy(stream);
     device = -1;
   }
@@ -137,6 +139,9 @@ int ensure_ctx() {
   HIP_TRY(hipHostMalloc((void **)&c.host_sig, 64, hipHostMallocMapped | hipHostMallocCoherent));
   memset(c.host_sig, 0, 64);
   HIP_TRY(hipHostGetDevicePointer((void **)&c.host_sig_dev, c.host_sig, 0));
+  HIP_TRY(hipHostMalloc((void **)&c.host_hdr, EX_MAX_SLOTS * 16, hipHostMallocMapped | hipHostMallocCoherent));
+  memset(c.host_hdr, 0, EX_MAX_SLOTS * 16);
+  HIP_TRY(hipHostGetDevicePointer((void **)&c.host_hdr_dev, c.host_hdr, 0));
   { const int rs = resolve_scratch(dev, &c.na_scratch); if (rs) return rs; } // `dev` is current
   c.device = dev;
   return PLHIP_OK;
@@ -2891,9 +2896,13 @@ int sharded_impl(plhip_comm *comm, const plhip_column_t *keys, int32_t n_keys, c
     } else if ((rc = pack_impl(part.p, n_keys, EXCHANGE_NULL_HASH, world, slot_rows, c.xsend.p, nullptr))) return rc;
     lap(S.pack_ms);
     if ((rc = comm_all_to_all(comm, c.xsend.p, c.xrecv.p, stride, c.stream, err))) return fail(rc, err);
-    uint64_t hdr[EX_MAX_SLOTS][2];
-    HIP_TRY(hipMemcpy2DAsync(hdr, 16, c.xrecv.p, stride, 16, (size_t)world, hipMemcpyDeviceToHost, c.stream));
+    // the headers of the received slots: a one-workgroup kernel writes them into pinned host memory (a strided 2-D copy into
+    // pageable memory came back with stale bytes under rocprofv3's copy interception, and costs more than a launch anyway)
+    launch_slot_headers((const uint8_t *)c.xrecv.p, (uint64_t)stride, (uint32_t)world, c.host_hdr_dev, c.stream);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c.stream)); // the exchange has landed; the headers say how many records every peer sent
+    uint64_t hdr[EX_MAX_SLOTS][2];
+    for (int p = 0; p < world; p++) { hdr[p][0] = __atomic_load_n(&c.host_hdr[2 * p], __ATOMIC_ACQUIRE); hdr[p][1] = __atomic_load_n(&c.host_hdr[2 * p + 1], __ATOMIC_ACQUIRE); }
     S.host_syncs++;
     S.shuffle_bytes = (int64_t)(stride * world);
     S.protocol = 1;

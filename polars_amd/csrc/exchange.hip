@@ -149,6 +149,19 @@ __global__ void __launch_bounds__(EX_BLOCK) k_finalize_partial(FinPlan F) {
 
 } // namespace
 
+// the received slots' 16-byte headers {rows, overflow flag} -> one small block of (pinned, device-mapped) host memory
+__global__ void __launch_bounds__(64) k_slot_headers(const uint8_t *__restrict__ slots, uint64_t stride, uint32_t n_slots, uint64_t *__restrict__ out) {
+  const uint32_t p = threadIdx.x;
+  if (p < n_slots) {
+    const uint64_t *h = (const uint64_t *)(slots + (uint64_t)p * stride);
+    out[2 * p] = h[0];
+    out[2 * p + 1] = h[1];
+  }
+}
+void launch_slot_headers(const uint8_t *slots, uint64_t stride, uint32_t n_slots, uint64_t *out, hipStream_t s) {
+  hipLaunchKernelGGL(k_slot_headers, dim3(1), dim3(64), 0, s, slots, stride, n_slots, out);
+}
+
 void launch_finalize_partial(const FinPlan &f, hipStream_t s) {
   hipLaunchKernelGGL(k_finalize_partial, dim3((unsigned)((f.n_rows + EX_BLOCK - 1) / EX_BLOCK)), dim3(EX_BLOCK), 0, s, f);
 }

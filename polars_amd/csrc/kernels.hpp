@@ -140,6 +140,7 @@ struct RecPlan {
 void launch_owner_count(const RecPlan &r, uint64_t null_hash, uint16_t *owner, uint32_t *counts, hipStream_t s);
 void launch_pack_records(const RecPlan &r, const uint16_t *owner, const uint32_t *counts, uint32_t *cursor, uint8_t *records, hipStream_t s);
 void launch_unpack_records(const RecPlan &r, const uint8_t *records, hipStream_t s);
+void launch_slot_headers(const uint8_t *slots, uint64_t stride, uint32_t n_slots, uint64_t *out, hipStream_t s); // n_slots <= 64
 
 // AggregationExpr::finalize on a regrouped partial frame (exchange.hip)
 #define FIN_COPY 0  // keys, min, max: value and validity bit as they are
