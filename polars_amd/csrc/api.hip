@@ -343,14 +343,17 @@ int measure_key_columns(std::vector<KeyCol> &cols, int64_t n) {
   Plan M{};
   M.n_rows = n; M.n_keys = (int)cols.size();
   for (size_t i = 0; i < cols.size(); i++) { cols[i].lo = 0; cols[i].bits = 64; set_keyspec(M.keys[i], cols[i]); }
+  // mm[2i] = ~min, mm[2i + 1] = max over the valid rows (0, 0 when there is none); the result comes back through PINNED host
+  // memory (pageable async copies are staged: ~100 us each way)
   const size_t mm_bytes = cols.size() * 2 * sizeof(uint64_t);
-  HIP_TRY(c.misc.reserve(mm_bytes));
-  std::vector<uint64_t> mm(cols.size() * 2);
-  for (size_t i = 0; i < cols.size(); i++) { mm[2 * i] = ~0ull; mm[2 * i + 1] = 0; }
-  HIP_TRY(hipMemcpyAsync(c.misc.p, mm.data(), mm_bytes, hipMemcpyHostToDevice, c.stream));
-  if (n > 0) launch_key_minmax(M, (uint64_t *)c.misc.p, c.stream);
-  HIP_TRY(hipMemcpyAsync(mm.data(), c.misc.p, mm_bytes, hipMemcpyDeviceToHost, c.stream));
+  HIP_TRY(c.misc.reserve(256 + key_minmax_scratch_bytes((int)cols.size())));
+  HIP_TRY(hipMemsetAsync(c.misc.p, 0, mm_bytes, c.stream));
+  if (n > 0) launch_key_minmax(M, (uint64_t *)c.misc.p, (uint64_t *)((uint8_t *)c.misc.p + 256), c.stream);
+  uint64_t *mm = c.host_hdr; // (EX_MAX_SLOTS * 16 bytes >= PLHIP_MAX_KEYS * 16; the sharded path reads it only inside its own call)
+  static_assert(EX_MAX_SLOTS * 16 >= PLHIP_MAX_KEYS * 16, "the pinned block holds a min / max pair per key column");
+  HIP_TRY(hipMemcpyAsync(mm, c.misc.p, mm_bytes, hipMemcpyDeviceToHost, c.stream));
   HIP_TRY(hipStreamSynchronize(c.stream));
+  for (size_t i = 0; i < cols.size(); i++) mm[2 * i] = ~mm[2 * i];
   for (size_t i = 0; i < cols.size(); i++) {
     KeyCol &k = cols[i];
     const uint64_t lo = mm[2 * i], hi = mm[2 * i + 1];
@@ -1247,12 +1250,15 @@ int run_direct_noalloc(Lowered &L, const std::vector<DevCol> &dk, int64_t groups
 // 24-185, 190-227) -- a Categorical key's physical codes ARE the group indices -- on LDS tables.  Taken when the caller
 // declares the single u32 key column dense (PLHIP_FLAG_KEYS_DENSE: codes < n_groups_hint = the rev-map's length).  A code
 // outside the promise raises the overflow flag and the hashed strategies redo the query: time, never correctness.
-int run_dense(const Lowered &L0, const std::vector<DevCol> &dk, uint32_t flags, int64_t groups_hint, bool forced, plhip_result_t **out, bool &handled) {
+// key_bias: a plain 32-bit integer key whose measured range [min, max] is compact is a dense code after subtracting its minimum
+// (group_by_agg_impl): codes = raw bits - key_bias, groups_hint = max - min + 1.
+int run_dense(const Lowered &L0, const std::vector<DevCol> &dk, uint32_t flags, int64_t groups_hint, bool forced, plhip_result_t **out, bool &handled,
+              uint32_t key_bias = 0) {
   handled = false;
   Ctx &c = g_ctx;
   const int64_t n = L0.P.n_rows;
   if ((flags & PLHIP_FLAG_MAINTAIN_ORDER) || L0.KG.enabled || L0.first_acc >= 0) return PLHIP_OK;
-  if (!L0.P.single_key || dk[0].dtype != PLHIP_U32 || groups_hint < 1 || groups_hint > 0x7FFFFFF0ll) return PLHIP_OK;
+  if (!L0.P.single_key || (dk[0].dtype != PLHIP_U32 && dk[0].dtype != PLHIP_I32) || groups_hint < 1 || groups_hint > 0x7FFFFFF0ll) return PLHIP_OK;
   if (n < 1 || (!forced && n < (1 << 15))) return PLHIP_OK;
   if (((uintptr_t)dk[0].values & 15u) != 0) return PLHIP_OK; // the row loop reads aligned quads
   for (int v = 0; v < L0.P.n_vals; v++)
@@ -1315,6 +1321,7 @@ int run_dense(const Lowered &L0, const std::vector<DevCol> &dk, uint32_t flags, 
     D.n_accs++;
   }
   A.cnt_acc = (uint32_t)cnt_acc_idx;
+  A.key_bias = key_bias;
   // ---- ranges: the largest part's arrays cut into pieces of one CU's LDS ------------------------------------------
   const size_t LDS_CAP = 160 * 1024 - 512;
   uint32_t state_max = 0;
@@ -2033,6 +2040,29 @@ int32_t group_by_agg_impl(const plhip_column_t *keys, int32_t n_keys, const plhi
     if ((rc = run_sorted(L, dk, flags, out, handled, true))) return rc;
     if (handled) return PLHIP_OK;
   }
+  // A plain 32-bit integer key (db-benchmark's id4 .. id6) whose values sit in a compact range IS a dense code once its minimum is
+  // subtracted: one vectorised min / max pass over the key column (it replaces the cardinality sample the hashed pipelines
+  // would take) and the dense-code path runs without hashing, probing or a sorted copy.  The reference has no counterpart for
+  // plain integers (group_tuples_perfect serves Categoricals only, perfect.rs:190-227); the result is the same set of groups.
+  int64_t range_bound = 0; // > 0: the key takes at most this many distinct values (a bound the hashed pipelines can use as a hint)
+  if (strategy == PLHIP_STRATEGY_AUTO && !(flags & (PLHIP_FLAG_KEYS_DENSE | PLHIP_FLAG_MAINTAIN_ORDER | PLHIP_FLAG_KEYS_SORTED)) && n_keys == 1 &&
+      (dk[0].dtype == PLHIP_I32 || dk[0].dtype == PLHIP_U32) && n >= (1 << 20) && !getenv("PLHIP_NO_RANGE_DENSE")) {
+    int64_t hint = 0;
+    if (opts && opts->struct_size >= offsetof(plhip_options_t, n_groups_hint) + sizeof(int64_t)) hint = opts->n_groups_hint;
+    if (hint <= 0 || hint > 4096) { // (a few thousand groups: DIRECT's single table is the right tool, no pass needed)
+      std::vector<KeyCol> one(1);
+      one[0].col = dk[0]; one[0].nullable = dk[0].validity != nullptr;
+      if ((rc = measure_key_columns(one, n))) return rc;
+      const uint64_t span = one[0].hi - one[0].lo; // normalised bits: order-preserving for i32 and u32 alike
+      if (span < (uint64_t)n && span < 0x7FFFFFF0ull) {
+        range_bound = (int64_t)span + 1 + (one[0].nullable ? 1 : 0);
+        const uint32_t raw_min = dk[0].dtype == PLHIP_I32 ? (uint32_t)one[0].lo ^ 0x80000000u : (uint32_t)one[0].lo;
+        bool handled = false;
+        if ((rc = run_dense(L, dk, flags, (int64_t)span + 1, false, out, handled, raw_min))) return rc;
+        if (handled) return PLHIP_OK;
+      }
+    }
+  }
   if ((flags & PLHIP_FLAG_KEYS_DENSE) && (strategy == PLHIP_STRATEGY_AUTO || strategy == PLHIP_STRATEGY_DENSE)) {
     int64_t hint = 0;
     if (opts && opts->struct_size >= offsetof(plhip_options_t, n_groups_hint) + sizeof(int64_t)) hint = opts->n_groups_hint;
@@ -2044,6 +2074,7 @@ int32_t group_by_agg_impl(const plhip_column_t *keys, int32_t n_keys, const plhi
   if (strategy == PLHIP_STRATEGY_AUTO || strategy == PLHIP_STRATEGY_DIRECT || strategy == PLHIP_STRATEGY_TILESORT) {
     int64_t hint = 0;
     if (opts && opts->struct_size >= offsetof(plhip_options_t, n_groups_hint) + sizeof(int64_t)) hint = opts->n_groups_hint;
+    if (hint <= 0 && range_bound > 0 && range_bound <= n / 2) hint = range_bound; // the measured value range bounds the groups: no sample
     bool handled = false;
     uint64_t g_seen = 0;
     if ((rc = run_fast(L, dk, flags, hint, strategy, out, handled, g_seen))) return rc;

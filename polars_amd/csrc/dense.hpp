@@ -58,7 +58,8 @@ struct DenseArgs {
   uint32_t hint;    // codes are < hint
   uint32_t xcds;    // workgroup w -> XCD lane w % xcds, position w / xcds there; group slot = (position / R) * xcds + lane
   uint32_t cnt_acc; // Plan::accs index of ACC_CNT_ALL (a group exists iff its count is not 0)
-  uint32_t pad;
+  uint32_t key_bias; // code = the key's raw 32 bits - key_bias (0 for Categorical codes; the column's minimum for a plain integer key
+                     // whose measured value range is compact)
   uint8_t *dump;
   uint32_t *flags;
   DensePart part[DENSE_MAX_PARTS];

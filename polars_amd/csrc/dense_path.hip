@@ -106,7 +106,7 @@ DEVINL void dense_process(const Plan &P, const DenseArgs &A, const DensePart &D,
                           const DenseRows<B> &X, uint32_t &bad) {
   uint32_t code[B], rel[B];
 #pragma unroll
-  for (int b = 0; b < B; b++) code[b] = X.key[b];
+  for (int b = 0; b < B; b++) code[b] = X.key[b] - A.key_bias;
   if (is_last) { // (uniform) the last range holds the null key's slot `hint` (perfect.rs:51-56) and sees every code >= hint
 #pragma unroll
     for (int b = 0; b < B; b++) {
@@ -245,7 +245,7 @@ DEVINL void dense_fold_buf(const DenseArgs &A, const DensePart &D, uint8_t *tab,
     uint32_t rel[4];
 #pragma unroll
     for (int b = 0; b < 4; b++) {
-      uint32_t code = key[b];
+      uint32_t code = key[b] - A.key_bias;
       const bool isnull = KV && ((knull >> b) & 1u);
       if (is_last) { // (uniform test)
         if (!isnull && code >= A.hint) { bad = 1; code = 0xFFFFFFFFu; } // not a code of this rev-map
@@ -507,7 +507,10 @@ __global__ void __launch_bounds__(DENSE_BLOCK) k_dense_merge(Plan P, DenseArgs A
         const OutSpec &S = O.outs[o];
         bool valid = false;
         if (livek) {
-          if (S.kind == OUT_KEY) valid = finalize_key(P, S, (uint64_t)gg, gg == A.hint, false, i);
+          if (S.kind == OUT_KEY) { // the key's normalised bits (device.hpp load_key_norm) from its slot
+            const uint32_t rawk = gg + A.key_bias;
+            valid = finalize_key(P, S, (uint64_t)(P.keys[0].dtype == PLHIP_I32 ? rawk ^ 0x80000000u : rawk), gg == A.hint, false, i);
+          }
           else {
             const uint64_t acc = S.acc >= 0 ? FIN(S.acc, s) : 0ull;
             const uint32_t cnt_all = S.cnt_all >= 0 ? (uint32_t)FIN(S.cnt_all, s) : 0u;

@@ -289,7 +289,12 @@ DEVINL void mm_stream(const uint8_t *values, int64_t n_rows, uint64_t x, uint64_
   }
 }
 
-__global__ void __launch_bounds__(256) k_key_minmax(Plan P, uint64_t *minmax) {
+// Every workgroup writes ONE (~min, max) pair per key column to `partials`; k_key_minmax_final folds them.  (One atomic pair per
+// wave on the result words themselves -- 8 192 waves on two addresses -- took 190 us at 1e7 rows: same-address atomics retire
+// at ~88 per us.)
+#define MM_GRID 1024
+__global__ void __launch_bounds__(256) k_key_minmax(Plan P, uint64_t *partials) {
+  __shared__ uint64_t sh[4][2];
   const int k = blockIdx.y;
   const KeySpec &K = P.keys[k];
   uint64_t lo = ~0ull, hi = 0;
@@ -311,16 +316,45 @@ __global__ void __launch_bounds__(256) k_key_minmax(Plan P, uint64_t *minmax) {
     lo = l2 < lo ? l2 : lo;
     hi = h2 > hi ? h2 : hi;
   }
-  if ((threadIdx.x & 63) == 0 && lo <= hi) {
-    atomicMin((unsigned long long *)&minmax[2 * k], (unsigned long long)lo);
-    atomicMax((unsigned long long *)&minmax[2 * k + 1], (unsigned long long)hi);
+  if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6][0] = lo; sh[threadIdx.x >> 6][1] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++) { lo = sh[w][0] < lo ? sh[w][0] : lo; hi = sh[w][1] > hi ? sh[w][1] : hi; }
+    uint64_t *p = partials + ((uint64_t)k * gridDim.x + blockIdx.x) * 2;
+    p[0] = lo; p[1] = hi; // (lo > hi: this workgroup saw no valid row)
+  }
+}
+// minmax[2k] = ~min (0 when no row is valid), minmax[2k + 1] = max: the host's measure_key_columns reads them
+__global__ void __launch_bounds__(256) k_key_minmax_final(const uint64_t *__restrict__ partials, uint32_t n_blocks, uint64_t *minmax) {
+  __shared__ uint64_t sh[4][2];
+  const int k = blockIdx.x;
+  uint64_t lo = ~0ull, hi = 0;
+  for (uint32_t b = threadIdx.x; b < n_blocks; b += 256) {
+    const uint64_t l = partials[((uint64_t)k * n_blocks + b) * 2], h = partials[((uint64_t)k * n_blocks + b) * 2 + 1];
+    if (l <= h) { lo = l < lo ? l : lo; hi = h > hi ? h : hi; }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const uint64_t l2 = __shfl_xor(lo, off), h2 = __shfl_xor(hi, off);
+    lo = l2 < lo ? l2 : lo;
+    hi = h2 > hi ? h2 : hi;
+  }
+  if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6][0] = lo; sh[threadIdx.x >> 6][1] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++) { lo = sh[w][0] < lo ? sh[w][0] : lo; hi = sh[w][1] > hi ? sh[w][1] : hi; }
+    minmax[2 * k] = lo <= hi ? ~lo : 0ull;
+    minmax[2 * k + 1] = lo <= hi ? hi : 0ull;
   }
 }
 
-void launch_key_minmax(const Plan &p, uint64_t *minmax, hipStream_t s) {
+size_t key_minmax_scratch_bytes(int n_keys) { return (size_t)n_keys * MM_GRID * 16; }
+
+// partials: key_minmax_scratch_bytes(p.n_keys) bytes of scratch
+void launch_key_minmax(const Plan &p, uint64_t *minmax, uint64_t *partials, hipStream_t s) {
   int64_t blocks = (p.n_rows + 4095) / 4096;
-  int grid = (int)(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks));
-  hipLaunchKernelGGL(k_key_minmax, dim3(grid, p.n_keys), dim3(256), 0, s, p, minmax);
+  int grid = (int)(blocks < 1 ? 1 : (blocks > MM_GRID ? MM_GRID : blocks));
+  hipLaunchKernelGGL(k_key_minmax, dim3(grid, p.n_keys), dim3(256), 0, s, p, partials);
+  hipLaunchKernelGGL(k_key_minmax_final, dim3(p.n_keys), dim3(256), 0, s, partials, (uint32_t)grid, minmax);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -64,7 +64,8 @@ void launch_finalize(const Plan &p, TableRef t, const OutPlan *o, const KeyGathe
 void launch_rank_scatter(const uint64_t *slots, uint64_t n, uint32_t *rank, hipStream_t s);
 void launch_encode_rows(const Plan &p, TableRef t, const uint32_t *rank, uint32_t *ids, hipStream_t s);
 void launch_sample_keys(const Plan &p, TableRef t, int64_t n_sample, int64_t stride, hipStream_t s);
-void launch_key_minmax(const Plan &p, uint64_t *minmax /* [n_keys][2], pre-set to {~0, 0} */, hipStream_t s);
+size_t key_minmax_scratch_bytes(int n_keys);
+void launch_key_minmax(const Plan &p, uint64_t *minmax, uint64_t *partials, hipStream_t s); // minmax[2k] = ~min, [2k + 1] = max
 void launch_vec_hash(const Plan &p, uint64_t null_hash, uint64_t *out, hipStream_t s);
 hipError_t sort_pairs_u64(uint64_t *keys, uint64_t *vals, uint64_t n, int end_bit, hipStream_t s);
 
