@@ -24,7 +24,9 @@ namespace {
 
 #define LS_WCAP 512u  // rows a wave sorts
 #define LS_IDXB 9u    // log2(LS_WCAP): low bits of a composite = the row's slot in the wave's staging area
+#ifndef LS_BLOCK
 #define LS_BLOCK 256
+#endif
 #define LS_WAVES (LS_BLOCK / 64)
 #define LS_WAVE_BYTES (LS_WCAP * 8u + LS_WCAP * 4u + (LS_WCAP + 8u) * 2u) // composites | positions | run starts (u16)
 #define LS_MAX_ACCS 8
