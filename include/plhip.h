@@ -264,6 +264,22 @@ int32_t plhip_group_by_agg_opts(const plhip_column_t *keys, int32_t n_keys, cons
                                 int32_t n_values, const plhip_agg_t *aggs, int32_t n_aggs, uint32_t flags,
                                 const plhip_options_t *opts, plhip_result_t **out);
 
+/* plhip_group_by_agg_opts over CHUNKED columns.  The reference rechunks the frame before this path
+ * (`df.as_single_chunk_par()`, crates/polars-lazy/src/physical_plan/executors/group_by.rs:66; ChunkedArray::rechunk,
+ * crates/polars-core/src/chunked_array/ops/chunkops.rs); here the chunks of every column -- host or device memory, each with its
+ * own Arrow offset and optional validity bitmap -- are laid end to end in HBM by the library (values: one copy per chunk on the
+ * library's stream; validity: a bit-granular copy kernel, chunks without a bitmap contribute ones) and the query runs on the
+ * single-chunk columns.  A column with ONE chunk is passed through untouched (zero-copy for device memory).  All columns must
+ * have the same total length; chunk boundaries need not line up between columns. */
+typedef struct plhip_chunked_column {
+  const plhip_column_t *chunks; /* n_chunks single-chunk arrays of one dtype */
+  int32_t n_chunks;
+  int32_t pad;
+} plhip_chunked_column_t;
+int32_t plhip_group_by_agg_chunked(const plhip_chunked_column_t *keys, int32_t n_keys, const plhip_chunked_column_t *values,
+                                   int32_t n_values, const plhip_agg_t *aggs, int32_t n_aggs, uint32_t flags,
+                                   const plhip_options_t *opts, plhip_result_t **out);
+
 /* plhip_group_by_agg_opts for callers that cannot allocate: code under HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc.  NO counterpart in the reference (there every aggregation allocates its output
  * Series); it exists for those callers only.  It calls no hipMalloc / hipFree / allocating routine: inputs and

@@ -105,6 +105,11 @@ def code_np_dtype(code: int):
     return _CODE_TO_NP[code]
 
 
+class ChunkedColumnStruct(C.Structure):
+    """plhip_chunked_column_t"""
+    _fields_ = [("chunks", C.POINTER(ColumnStruct)), ("n_chunks", C.c_int32), ("pad", C.c_int32)]
+
+
 class ShardedStats(C.Structure):
     """plhip_sharded_stats_t"""
     _fields_ = [("partial_ms", C.c_float), ("pack_ms", C.c_float), ("exchange_ms", C.c_float), ("merge_ms", C.c_float),
@@ -192,6 +197,9 @@ def lib():
     L.plhip_group_by_agg_sharded.restype = i32
     L.plhip_sharded_last_stats.argtypes = [P(ShardedStats)]
     L.plhip_sharded_last_stats.restype = i32
+    L.plhip_group_by_agg_chunked.argtypes = [P(ChunkedColumnStruct), i32, P(ChunkedColumnStruct), i32, P(AggStruct), i32, u32,
+                                             P(OptionsStruct), P(vp)]
+    L.plhip_group_by_agg_chunked.restype = i32
     L.plhip_release_workspace.argtypes = []
     L.plhip_release_workspace.restype = i32
     L.plhip_pooled_buffers.argtypes = [i32]
@@ -254,5 +262,5 @@ EXPORTED_SYMBOLS = [
     "plhip_agg_groups", "plhip_agg_groups_quantile", "plhip_result_record_bytes", "plhip_result_pack_by_owner", "plhip_records_to_frame", "plhip_merge_records", "plhip_finalize_partial", "plhip_slot_bytes", "plhip_result_pack_slots", "plhip_merge_slots",
     "plhip_group_by_agg_noalloc", "plhip_release_workspace", "plhip_pooled_buffers",
     "plhip_comm_unique_id", "plhip_comm_init_rccl", "plhip_comm_init_host", "plhip_comm_free", "plhip_group_by_agg_sharded",
-    "plhip_sharded_last_stats",
+    "plhip_sharded_last_stats", "plhip_group_by_agg_chunked",
 ]

@@ -1965,6 +1965,81 @@ int32_t plhip_group_by_agg_opts(const plhip_column_t *keys, int32_t n_keys, cons
   return rc;
 }
 
+namespace {
+// One chunked column -> one single-chunk DEVICE column (owned by `st` unless the column had a single chunk).
+int rechunk_column(const plhip_chunked_column_t &cc, plhip_column_t &out, Staging &st, hipStream_t s) {
+  if (cc.n_chunks < 1 || !cc.chunks) return fail(PLHIP_ERR_INVALID, "a chunked column needs at least one chunk");
+  if (cc.n_chunks == 1) { out = cc.chunks[0]; return PLHIP_OK; }
+  const int dt = cc.chunks[0].dtype;
+  const int w = dtype_width(dt);
+  if (!w) return fail(PLHIP_ERR_UNSUPPORTED_DTYPE, "unsupported dtype code " + std::to_string(dt));
+  int64_t total = 0;
+  bool any_valid = false;
+  for (int i = 0; i < cc.n_chunks; i++) {
+    const plhip_column_t &c = cc.chunks[i];
+    if (c.dtype != dt) return fail(PLHIP_ERR_INVALID, "the chunks of a column differ in dtype");
+    if (c.length < 0 || c.offset < 0) return fail(PLHIP_ERR_INVALID, "negative column offset/length");
+    if (c.length > 0 && !c.values) return fail(PLHIP_ERR_INVALID, "column values pointer is NULL");
+    if (c.location != PLHIP_HOST && c.location != PLHIP_DEVICE) return fail(PLHIP_ERR_INVALID, "bad column location");
+    total += c.length;
+    any_valid |= c.validity != nullptr;
+  }
+  void *dv = nullptr, *db = nullptr;
+  HIP_TRY(hipMalloc(&dv, (size_t)std::max<int64_t>(total, 1) * w));
+  st.owned.push_back(dv);
+  const size_t bm_bytes = (((size_t)total + 31) / 32) * 4 + 8;
+  if (any_valid) {
+    HIP_TRY(hipMalloc(&db, bm_bytes));
+    st.owned.push_back(db);
+    HIP_TRY(hipMemsetAsync(db, 0, bm_bytes, s));
+  }
+  int64_t pos = 0;
+  for (int i = 0; i < cc.n_chunks; i++) {
+    const plhip_column_t &c = cc.chunks[i];
+    if (!c.length) continue;
+    const hipMemcpyKind kind = c.location == PLHIP_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    HIP_TRY(hipMemcpyAsync((uint8_t *)dv + (size_t)pos * w, (const uint8_t *)c.values + (size_t)c.offset * w, (size_t)c.length * w, kind, s));
+    if (any_valid) {
+      const uint8_t *src = c.validity;
+      int64_t src_off = c.offset;
+      if (src && c.location == PLHIP_HOST) { // the bitmap's bytes that cover the chunk travel to the device first
+        const int64_t b0 = c.offset >> 3, b1 = (c.offset + c.length + 7) >> 3;
+        void *tmp = nullptr;
+        HIP_TRY(hipMalloc(&tmp, (size_t)(b1 - b0) + 8));
+        st.owned.push_back(tmp);
+        HIP_TRY(hipMemcpyAsync(tmp, c.validity + b0, (size_t)(b1 - b0), hipMemcpyHostToDevice, s));
+        src = (const uint8_t *)tmp; src_off = c.offset & 7;
+      }
+      launch_copy_bits((uint32_t *)db, pos, src, src_off, c.length, s);
+      HIP_TRY(hipGetLastError());
+    }
+    pos += c.length;
+  }
+  out = plhip_column_t{};
+  out.values = dv; out.validity = (const uint8_t *)db; out.offset = 0; out.length = total; out.dtype = dt; out.location = PLHIP_DEVICE;
+  return PLHIP_OK;
+}
+} // namespace
+
+int32_t plhip_group_by_agg_chunked(const plhip_chunked_column_t *keys, int32_t n_keys, const plhip_chunked_column_t *values,
+                                   int32_t n_values, const plhip_agg_t *aggs, int32_t n_aggs, uint32_t flags,
+                                   const plhip_options_t *opts, plhip_result_t **out) {
+  if (!out) return fail(PLHIP_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  if (n_keys < 1 || !keys) return fail(PLHIP_ERR_COMPUTE, "at least one key is required in a group_by operation");
+  if (n_keys > PLHIP_MAX_KEYS) return fail(PLHIP_ERR_INVALID, "too many key columns (max 16)");
+  if (n_values < 0 || n_values > PLHIP_MAX_VALS || (n_values > 0 && !values)) return fail(PLHIP_ERR_INVALID, "bad value columns");
+  int rc = ensure_ctx();
+  if (rc) return rc;
+  Staging st; // the rechunked buffers live until the query has returned (the group-by ends with the stream drained)
+  std::vector<plhip_column_t> k(n_keys), v(std::max(n_values, 1));
+  for (int i = 0; i < n_keys; i++) if ((rc = rechunk_column(keys[i], k[i], st, g_ctx.stream))) return rc;
+  for (int i = 0; i < n_values; i++) if ((rc = rechunk_column(values[i], v[i], st, g_ctx.stream))) return rc;
+  rc = plhip_group_by_agg_opts(k.data(), n_keys, v.data(), n_values, aggs, n_aggs, flags, opts, out);
+  if (rc) hipStreamSynchronize(g_ctx.stream); // the copies may still be queued: the buffers are freed on the way out
+  return rc;
+}
+
 int32_t plhip_group_by_agg_noalloc(const plhip_column_t *keys, int32_t n_keys, const plhip_column_t *values, int32_t n_values,
                                    const plhip_agg_t *aggs, int32_t n_aggs, uint32_t flags, int64_t n_groups_hint,
                                    const plhip_column_t *out_cols, int32_t n_out_cols, int64_t *n_groups) {

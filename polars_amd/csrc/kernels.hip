@@ -358,6 +358,33 @@ void launch_key_minmax(const Plan &p, uint64_t *minmax, uint64_t *partials, hipS
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// rechunk: a chunk's validity bits copied to bit position dst_off of the single-chunk bitmap (zeroed before)
+// ---------------------------------------------------------------------------------------------------------
+// A thread builds one destination 32-bit word from up to 32 source bits (src == nullptr: the chunk has no nulls, all ones).
+// Words that the chunk only partly covers (its first and last) are shared with the neighbouring chunks: atomicOr.
+__global__ void __launch_bounds__(256) k_copy_bits(uint32_t *__restrict__ dst, int64_t dst_off, const uint8_t *__restrict__ src, int64_t src_off,
+                                                   int64_t n) {
+  const int64_t w0 = dst_off >> 5, w1 = (dst_off + n + 31) >> 5; // destination words touched
+  const int64_t w = w0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= w1) return;
+  const int64_t b0 = w << 5;
+  const int64_t lo = b0 > dst_off ? b0 : dst_off, hi = b0 + 32 < dst_off + n ? b0 + 32 : dst_off + n; // destination bits [lo, hi)
+  uint32_t word = 0;
+  for (int64_t b = lo; b < hi; b++) {
+    const int64_t sb = src_off + (b - dst_off);
+    const uint32_t bit = src ? (src[sb >> 3] >> (sb & 7)) & 1u : 1u;
+    word |= bit << (uint32_t)(b - b0);
+  }
+  if (hi - lo == 32) dst[w] = word;
+  else if (word) atomicOr(&dst[w], word);
+}
+void launch_copy_bits(uint32_t *dst, int64_t dst_off, const uint8_t *src, int64_t src_off, int64_t n, hipStream_t s) {
+  if (n <= 0) return;
+  const int64_t words = ((dst_off + n + 31) >> 5) - (dst_off >> 5);
+  hipLaunchKernelGGL(k_copy_bits, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, dst, dst_off, src, src_off, n);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // VecHash (crates/polars-core/src/hashing/vector_hasher.rs:78-139, 467-483)
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_vec_hash(Plan P, uint64_t null_h, uint64_t *out) {

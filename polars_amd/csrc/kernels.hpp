@@ -67,6 +67,8 @@ void launch_sample_keys(const Plan &p, TableRef t, int64_t n_sample, int64_t str
 size_t key_minmax_scratch_bytes(int n_keys);
 void launch_key_minmax(const Plan &p, uint64_t *minmax, uint64_t *partials, hipStream_t s); // minmax[2k] = ~min, [2k + 1] = max
 void launch_vec_hash(const Plan &p, uint64_t null_hash, uint64_t *out, hipStream_t s);
+// rechunk: n validity bits from bit src_off of `src` (nullptr = all valid) to bit dst_off of the zeroed bitmap `dst`
+void launch_copy_bits(uint32_t *dst, int64_t dst_off, const uint8_t *src, int64_t src_off, int64_t n, hipStream_t s);
 hipError_t sort_pairs_u64(uint64_t *keys, uint64_t *vals, uint64_t n, int end_bit, hipStream_t s);
 
 // two-step API

@@ -363,6 +363,42 @@ def group_by_agg_raw(keys: Sequence[Column], values: Sequence[Column], aggs: Seq
     return handle, cols
 
 
+def group_by_agg_chunked_raw(keys: Sequence[Sequence[Column]], values: Sequence[Sequence[Column]], aggs: Sequence[tuple[int, int]],
+                             flags: int = 0, n_groups_hint: int = 0):
+    """plhip_group_by_agg_chunked: every column is a list of chunks (Columns of one dtype, host or device, each with its own
+    offset / validity); the library lays them end to end in HBM as the reference's rechunk does (executors/group_by.rs:66).
+    Returns (handle, [ColumnStruct ...]) like group_by_agg_raw."""
+    L = _ffi.lib()
+    for col in list(keys) + list(values):
+        for c in col:
+            if c.location == _ffi.DEVICE and type(c.values).__module__.startswith("torch"):
+                import torch
+
+                torch.cuda.current_stream(c.values.device).synchronize()
+                break
+    keep = []
+
+    def chunked(cols):
+        arr = (_ffi.ChunkedColumnStruct * max(1, len(cols)))()
+        for i, chunks in enumerate(cols):
+            ca = (_ffi.ColumnStruct * max(1, len(chunks)))(*[c.struct() for c in chunks])
+            keep.append(ca)
+            arr[i].chunks, arr[i].n_chunks = ca, len(chunks)
+        return arr
+
+    karr, varr = chunked(keys), chunked(values)
+    aarr = (_ffi.AggStruct * max(1, len(aggs)))(*[_ffi.AggStruct(c, k) for c, k in aggs])
+    handle = C.c_void_p()
+    opts = _ffi.OptionsStruct(C.sizeof(_ffi.OptionsStruct), int(n_groups_hint))
+    _ffi.check(L.plhip_group_by_agg_chunked(karr, len(keys), varr, len(values), aarr, len(aggs), flags, C.byref(opts), C.byref(handle)))
+    cols = []
+    for i in range(L.plhip_result_num_columns(handle)):
+        cs = _ffi.ColumnStruct()
+        _ffi.check(L.plhip_result_column(handle, i, C.byref(cs)))
+        cols.append(cs)
+    return handle, cols
+
+
 def _host_column(name: str, cs: _ffi.ColumnStruct) -> Column:
     n, off = cs.length, cs.offset  # a sliced frame's columns carry an Arrow offset
     dt = _ffi.code_np_dtype(cs.dtype)
