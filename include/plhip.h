@@ -446,7 +446,16 @@ void plhip_comm_free(plhip_comm_t *comm);
  * With opts->n_groups_hint (a bound on the groups of the whole job, the same on every rank) the buckets travel in
  * fixed-capacity slots: ONE equal-split exchange, no counts round trip; a bucket that does not fit says so in its slot
  * header, every rank sees it and all fall back to the exact protocol (counts, then a variable-size exchange).
- * PLHIP_FLAG_EXACT_EXCHANGE forces the exact protocol.  flags: PLHIP_FLAG_OUTPUT_DEVICE, PLHIP_FLAG_EXACT_EXCHANGE.
+ * PLHIP_FLAG_EXACT_EXCHANGE forces the exact protocol.  flags: PLHIP_FLAG_OUTPUT_DEVICE, PLHIP_FLAG_EXACT_EXCHANGE,
+ * PLHIP_FLAG_KEYS_DENSE.
+ * With PLHIP_FLAG_KEYS_DENSE (one u32 / i32 key whose values are codes < opts->n_groups_hint on every rank: a Categorical
+ * with a global rev-map, perfect.rs:190-227) the owners are code RANGES -- rank r owns [r * per, (r + 1) * per), the null key
+ * sits behind the last code -- and nothing is packed, hashed or regrouped: every rank adds up its dense partial arrays, sends
+ * each owner its range of them raw (ONE equal-split exchange of hint * state bytes, no keys on the wire; a reduce-scatter made
+ * of point-to-point sends), the owner adds the `world` copies up and finalizes.  The host waits for the device ONCE per call
+ * (RCCL transport).  A rank that cannot keep the promise (a code >= hint, misaligned buffers) flags its slot headers; every
+ * rank sees the flag and all fall back to the hashed protocols above together.  The sums of a group are added in a fixed
+ * order (slices of a rank, then ranks 0 .. world - 1): results do not change from run to run.
  * Collective: every rank of the communicator must call it with the same query. */
 #define PLHIP_FLAG_EXACT_EXCHANGE 32u
 int32_t plhip_group_by_agg_sharded(plhip_comm_t *comm, const plhip_column_t *keys, int32_t n_keys, const plhip_column_t *values,
@@ -461,8 +470,8 @@ typedef struct plhip_sharded_stats {
   float partial_kernel_ms, partial_dominant_ms;                  /* device time of the local pass's kernels */
   float partial_breakdown_ms[3];                                  /* as plhip_last_kernel_breakdown */
   int64_t shuffle_bytes;                                          /* bytes this rank handed to the transport */
-  int64_t partial_groups;                                         /* groups of the local pass */
-  int32_t protocol;                                               /* 1: slots (one exchange); 2: exact (counts + variable) */
+  int64_t partial_groups;                                         /* groups of the local pass (-1 under protocol 3: never counted) */
+  int32_t protocol;                                               /* 1: slots (one exchange); 2: exact (counts + variable); 3: dense code ranges (one exchange) */
   int32_t host_syncs;                                             /* times the host waited for the device in the call */
   char partial_strategy[16];
   char partial_dominant_kernel[32];

@@ -71,6 +71,7 @@ struct Ctx {
   bool hot_clean = false;  // the heavy-hitter words behind the flag block (FLAGS_HOT_OFF ..) are zero
   int timing_pending = 0; // 1: direct, 2: tilesort (S == 1), 3: tilesort + merge -- event times not read yet
   Scratch xsend, xrecv, xcnt; // the sharded path's exchange buffers
+  plhip_comm *dense_comm = nullptr; // set by sharded_impl around its dense attempt (group_by_agg_impl reads it)
   plhip_sharded_stats_t shard_stats{};
   uint8_t *na_scratch = nullptr; // device address of this GPU's static scratch array (plhip_group_by_agg_noalloc)
   // the grow-only workspace of this thread (roughly the largest query's working set): back to the driver
@@ -1252,17 +1253,27 @@ int run_direct_noalloc(Lowered &L, const std::vector<DevCol> &dk, int64_t groups
 // outside the promise raises the overflow flag and the hashed strategies redo the query: time, never correctness.
 // key_bias: a plain 32-bit integer key whose measured range [min, max] is compact is a dense code after subtracting its minimum
 // (group_by_agg_impl): codes = raw bits - key_bias, groups_hint = max - min + 1.
+// With `comm` (the sharded dense path, dense.hpp DenseXchg): every rank of the communicator makes this call with the same schema
+// and hint.  Whatever depends on the schema alone declines as usual (handled = false on EVERY rank, nothing was exchanged);
+// what depends on this rank's data (alignment, an empty shard, a code beyond the hint) must not leave the peers waiting: the
+// rank takes part in the exchange with a flagged header, and all ranks decline together afterwards.
 int run_dense(const Lowered &L0, const std::vector<DevCol> &dk, uint32_t flags, int64_t groups_hint, bool forced, plhip_result_t **out, bool &handled,
-              uint32_t key_bias = 0) {
+              uint32_t key_bias = 0, plhip_comm *comm = nullptr) {
   handled = false;
   Ctx &c = g_ctx;
   const int64_t n = L0.P.n_rows;
+  using clk = std::chrono::steady_clock;
+  auto t0 = clk::now();
+  auto lap = [&](float &slot) { const auto t1 = clk::now(); slot += std::chrono::duration<float, std::milli>(t1 - t0).count(); t0 = t1; };
+  if (comm) forced = true;
+  bool local_bad = false; // (comm only)
   if ((flags & PLHIP_FLAG_MAINTAIN_ORDER) || L0.KG.enabled || L0.first_acc >= 0) return PLHIP_OK;
   if (!L0.P.single_key || (dk[0].dtype != PLHIP_U32 && dk[0].dtype != PLHIP_I32) || groups_hint < 1 || groups_hint > 0x7FFFFFF0ll) return PLHIP_OK;
-  if (n < 1 || (!forced && n < (1 << 15))) return PLHIP_OK;
-  if (((uintptr_t)dk[0].values & 15u) != 0) return PLHIP_OK; // the row loop reads aligned quads
+  if (!comm && (n < 1 || (!forced && n < (1 << 15)))) return PLHIP_OK;
+  bool misaligned = ((uintptr_t)dk[0].values & 15u) != 0; // the row loop reads aligned quads
   for (int v = 0; v < L0.P.n_vals; v++)
-    if (((uintptr_t)L0.P.vals[v].values % (size_t)(4 * dtype_width((int)L0.P.vals[v].dtype))) != 0) return PLHIP_OK;
+    if (((uintptr_t)L0.P.vals[v].values % (size_t)(4 * dtype_width((int)L0.P.vals[v].dtype))) != 0) misaligned = true;
+  if (misaligned && n > 0) { if (!comm) return PLHIP_OK; local_bad = true; }
   Lowered L = L0; // (a count is added below: the hashed strategies keep the query as it was lowered)
   Plan &P = L.P;
   const int cnt_acc = add_acc(P, ACC_CNT_ALL, CONV_NONE, -1, 4, 0); // a code that never occurs is not a group
@@ -1407,7 +1418,10 @@ int run_dense(const Lowered &L0, const std::vector<DevCol> &dk, uint32_t flags, 
     slot += D.n_slices;
     const int64_t per = (n + D.n_slices - 1) / D.n_slices;
     D.rows_per_slice = (per + DENSE_BATCH - 1) / DENSE_BATCH * DENSE_BATCH;
-    if ((uint64_t)D.rows_per_slice * 8u >= 0xFFFFFFFFull) return PLHIP_OK; // the row loop addresses a slice with 32-bit byte offsets
+    if ((uint64_t)D.rows_per_slice * 8u >= 0xFFFFFFFFull) { // the row loop addresses a slice with 32-bit byte offsets
+      if (!comm) return PLHIP_OK;
+      local_bad = true;
+    }
     D.dump_off = dump_bytes;
     dump_bytes += D.slice_stride * D.n_slices;
   }
@@ -1418,7 +1432,38 @@ int run_dense(const Lowered &L0, const std::vector<DevCol> &dk, uint32_t flags, 
   A.dump = (uint8_t *)c.dump.p;
   uint32_t *dflags = (uint32_t *)c.flags.p;
   A.flags = dflags;
-  const uint64_t out_cap = A.n_slots; // (< 2^31: groups_hint is bounded in run_dense's first line, and the signal word holds 31 bits)
+  uint64_t out_cap = A.n_slots; // (< 2^31: groups_hint is bounded in run_dense's first line, and the signal word holds 31 bits)
+  // ---- sharded: the owners' slots and the view k_dense_merge gets of the received ones ---------------------------------
+  DenseXchg X{};
+  DenseArgs A2{};
+  const bool fold_runs = n > 0 && !local_bad;
+  if (comm) {
+    const uint32_t world = (uint32_t)comm->world;
+    X.world = world;
+    X.per = (((A.n_slots + world - 1) / world) + 3u) & ~3u;
+    uint64_t off = DENSE_SLOT_HEADER;
+    for (uint32_t p = 0; p < A.n_parts; p++)
+      for (uint32_t i = 0; i < A.part[p].n_accs; i++) { X.xoff[p][i] = (uint32_t)off; off += ((uint64_t)X.per * A.part[p].lw[i] + 15u) & ~15ull; }
+    if (off > 0xFFFFFF00ull) return PLHIP_OK; // (a property of the schema and the hint: every rank declines)
+    X.slot_bytes = (off + 255) & ~255ull;
+    X.local_bad = local_bad ? 1u : 0u;
+    HIP_TRY(c.xsend.reserve(X.slot_bytes * world + 256));
+    HIP_TRY(c.xrecv.reserve(X.slot_bytes * world + 256));
+    X.send = (uint8_t *)c.xsend.p;
+    if (!fold_runs) for (uint32_t p = 0; p < A.n_parts; p++) A.part[p].n_slices = 0; // nothing folded: the slots carry the accumulators' initial values
+    A2 = A;
+    A2.dump = (uint8_t *)c.xrecv.p;
+    A2.R = 1; A2.gpr = X.per;
+    A2.slot_base = (uint32_t)comm->rank * X.per;
+    A2.n_slots = A2.slot_base >= A.n_slots ? 0u : std::min<uint32_t>(X.per, A.n_slots - A2.slot_base);
+    A2.n_hdr = world;
+    for (uint32_t p = 0; p < A2.n_parts; p++) {
+      DensePart &D = A2.part[p];
+      D.dump_off = 0; D.slice_stride = X.slot_bytes; D.n_slices = world;
+      for (uint32_t i = 0; i < D.n_accs; i++) D.doff[i] = X.xoff[p][i];
+    }
+    out_cap = X.per;
+  }
   // ---- outputs --------------------------------------------------------------------------------------------------
   std::unique_ptr<plhip_result> R_(new (std::nothrow) plhip_result());
   if (!R_) return fail(PLHIP_ERR_OOM, "host allocation failed");
@@ -1445,17 +1490,31 @@ int run_dense(const Lowered &L0, const std::vector<DevCol> &dk, uint32_t flags, 
   if (++c.seq == 0) c.seq = 1;
   const uint32_t seq = c.seq;
   hipEventRecord(c.ev[1], c.stream);
-  launch_dense_fold(P, A, n_wgs, lds_bytes, c.stream);
+  if (fold_runs) launch_dense_fold(P, A, n_wgs, lds_bytes, c.stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail_hip(e, "k_dense_fold launch");
   hipEventRecord(c.ev[5], c.stream);
-  launch_dense_merge(P, A, OP, out_cap, c.host_sig_dev, seq, c.stream);
+  if (comm) {
+    plhip_sharded_stats_t &S = c.shard_stats;
+    lap(S.partial_ms);
+    launch_dense_scatter(P, A, X, c.stream);
+    if ((e = hipGetLastError()) != hipSuccess) return fail_hip(e, "k_dense_scatter launch");
+    lap(S.pack_ms);
+    std::string err;
+    const int xrc = comm_all_to_all(comm, c.xsend.p, c.xrecv.p, (size_t)X.slot_bytes, c.stream, err);
+    if (xrc) return fail(xrc, err);
+    lap(S.exchange_ms);
+    S.shuffle_bytes = (int64_t)(X.slot_bytes * X.world);
+    S.host_syncs = comm->nccl ? 0 : 1; // (the host's transport drains the stream before it moves the bytes)
+  }
+  launch_dense_merge(P, comm ? A2 : A, OP, out_cap, c.host_sig_dev, seq, c.stream);
   if ((e = hipGetLastError()) != hipSuccess) return fail_hip(e, "k_dense_merge launch");
   hipEventRecord(c.ev[2], c.stream);
   uint32_t fl[16] = {0};
   TableRef t{nullptr, 0, dflags};
   const int rc = wait_signal(t, seq, fl);
   if (rc) return rc;
+  if (comm) { c.shard_stats.host_syncs++; lap(c.shard_stats.merge_ms); }
   if (hipMemsetAsync(dflags, 0, 64, c.stream) == hipSuccess) c.flags_clean = true;
   c.timing_pending = 4;
   c.strategy = "dense";
@@ -2137,6 +2196,13 @@ int32_t group_by_agg_impl(const plhip_column_t *keys, int32_t n_keys, const plhi
         if (handled) return PLHIP_OK;
       }
     }
+  }
+  if (c.dense_comm) { // the sharded dense path (sharded_impl): the whole query or nothing -- *out stays NULL when every rank declines
+    bool handled = false;
+    int64_t hint = 0;
+    if (opts && opts->struct_size >= offsetof(plhip_options_t, n_groups_hint) + sizeof(int64_t)) hint = opts->n_groups_hint;
+    if (!(flags & PLHIP_FLAG_KEYS_DENSE) || (strategy != PLHIP_STRATEGY_AUTO && strategy != PLHIP_STRATEGY_DENSE)) return PLHIP_OK;
+    return run_dense(L, dk, flags, hint, true, out, handled, 0, c.dense_comm);
   }
   if ((flags & PLHIP_FLAG_KEYS_DENSE) && (strategy == PLHIP_STRATEGY_AUTO || strategy == PLHIP_STRATEGY_DENSE)) {
     int64_t hint = 0;
@@ -2942,6 +3008,25 @@ int sharded_impl(plhip_comm *comm, const plhip_column_t *keys, int32_t n_keys, c
   const int world = comm->world;
   const int64_t hint = (opts && opts->struct_size >= 16 && opts->n_groups_hint > 0) ? opts->n_groups_hint : 0;
   if (opts && opts->struct_size >= sizeof(plhip_options_t) && opts->has_slice) return fail(PLHIP_ERR_INVALID, "a slice cannot be pushed into the sharded path");
+  // ---- dense codes: owners by code range, one exchange of raw dense arrays, no regroup (dense.hpp) -----------------------
+  if ((flags & PLHIP_FLAG_KEYS_DENSE) && hint > 0 && !(flags & PLHIP_FLAG_EXACT_EXCHANGE) && n_keys == 1 && !getenv("PLHIP_NO_DENSE_EXCHANGE")) {
+    c.dense_comm = comm;
+    const int drc = group_by_agg_impl(keys, n_keys, values, n_values, aggs, n_aggs, flags & (PLHIP_FLAG_KEYS_DENSE | PLHIP_FLAG_OUTPUT_DEVICE), opts, out);
+    c.dense_comm = nullptr;
+    if (drc) return drc;
+    if (*out) {
+      resolve_timing();
+      S.partial_kernel_ms = c.total_ms; S.partial_dominant_ms = c.dom_ms;
+      S.partial_breakdown_ms[0] = c.k_ms[0]; S.partial_breakdown_ms[1] = c.k_ms[1]; S.partial_breakdown_ms[2] = c.k_ms[2];
+      snprintf(S.partial_strategy, sizeof(S.partial_strategy), "%s", c.strategy.c_str());
+      snprintf(S.partial_dominant_kernel, sizeof(S.partial_dominant_kernel), "%s", c.dom_kernel.c_str());
+      S.partial_groups = -1; // (the local pass never counts its groups: its arrays stay dense until the owners have merged them)
+      S.protocol = 3;
+      return PLHIP_OK;
+    }
+    S = plhip_sharded_stats_t{}; // every rank declined together (schema, or a flagged header): the hashed protocols below
+    t0 = clk::now();
+  }
   // ---- local pass: mergeable partials, device-resident -------------------------------------------------------------
   FrameGuard part;
   const uint32_t pflags = PLHIP_FLAG_PARTIAL | PLHIP_FLAG_OUTPUT_DEVICE | (flags & PLHIP_FLAG_KEYS_DENSE) | FLAG_INTERNAL_WRAP32;

@@ -60,11 +60,31 @@ struct DenseArgs {
   uint32_t cnt_acc; // Plan::accs index of ACC_CNT_ALL (a group exists iff its count is not 0)
   uint32_t key_bias; // code = the key's raw 32 bits - key_bias (0 for Categorical codes; the column's minimum for a plain integer key
                      // whose measured value range is compact)
+  uint32_t slot_base; // k_dense_merge over received owner slots: entry s is global slot slot_base + s (0 otherwise)
+  uint32_t n_hdr;     // ... and the n_hdr slots (part[0].slice_stride apart in `dump`) start with a header whose first word flags a sender
+                      // that could not keep the dense promise (0: `dump` holds k_dense_fold's partial arrays, no headers)
   uint8_t *dump;
   uint32_t *flags;
   DensePart part[DENSE_MAX_PARTS];
+};
+
+// The sharded dense path (plhip_group_by_agg_sharded with PLHIP_FLAG_KEYS_DENSE): rank r owns the code range
+// [r * per, (r + 1) * per).  k_dense_scatter adds up the slices' partial arrays like k_dense_merge and writes every owner's
+// entries, still dense and raw, into that owner's slot of the send buffer: [header 256 B][accumulator arrays, `per` entries each].
+// One equal-split all-to-all later every rank holds `world` such slots for its own range and k_dense_merge runs over them as if
+// they were `world` row slices: a reduce-scatter made of point-to-point sends, no packing, no keys on the wire, no regroup.
+#define DENSE_SLOT_HEADER 256u
+struct DenseXchg {
+  uint8_t *send;
+  uint64_t slot_bytes; // multiple of 256
+  uint32_t per;        // slots per owner (multiple of 4)
+  uint32_t world;
+  uint32_t local_bad;  // this rank could not run its fold (alignment, size): flagged in its headers, every rank then falls back
+  uint32_t pad;
+  uint32_t xoff[DENSE_MAX_PARTS][DENSE_MAX_PART_ACCS]; // byte offset of an accumulator's array inside a slot
 };
 static_assert(sizeof(Plan) + sizeof(OutPlan) + sizeof(DenseArgs) + 32 <= 4096, "k_dense_merge's arguments must fit the 4 KB kernel-argument segment");
 
 void launch_dense_fold(const Plan &p, const DenseArgs &a, uint32_t n_wgs, size_t lds_bytes, hipStream_t s);
 void launch_dense_merge(const Plan &p, const DenseArgs &a, const OutPlan &o, uint64_t out_cap, uint32_t *host_sig, uint32_t seq, hipStream_t s);
+void launch_dense_scatter(const Plan &p, const DenseArgs &a, const DenseXchg &x, hipStream_t s);

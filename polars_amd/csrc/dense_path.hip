@@ -412,13 +412,9 @@ __global__ void __launch_bounds__(DENSE_BLOCK) k_dense_fold(Plan P, DenseArgs A)
 // dependent rounds of loads -- every slice is a far-away, freshly written page -- ~4 the reservation atomics, which
 // serialise on one address; spreading accumulators over threads to get one round of loads was measured and was slower.)
 #define MG_U 4
-__global__ void __launch_bounds__(DENSE_BLOCK) k_dense_merge(Plan P, DenseArgs A, OutPlan O, uint64_t out_cap, uint32_t *host_sig, uint32_t seq, uint32_t gb,
-                                                             uint32_t W) {
-  __shared__ __align__(16) uint32_t tmp[DENSE_BLOCK / 64];
-  __shared__ uint32_t s_base, s_n;
-  uint64_t *part = (uint64_t *)dsm;                                       // [n_accs][W][gb]; way 0 ends up holding the finals
-  uint32_t *list = (uint32_t *)(dsm + (size_t)P.n_accs * W * gb * 8u);    // [gb]
-  const uint32_t tid = threadIdx.x, lane = tid & 63;
+// the slices' partial arrays of this workgroup's gb groups, added up: part[a][0][0 .. gb) holds the finals afterwards
+__device__ __forceinline__ void dense_sum_slices(const Plan &P, const DenseArgs &A, uint64_t *part, uint32_t gb, uint32_t W) {
+  const uint32_t tid = threadIdx.x;
   const uint32_t q4 = gb >> 2;                // quads of groups per workgroup
   const uint32_t j = tid % q4, w4 = tid / q4; // (w4 < W: blockDim = q4 * W)
   const uint32_t g0 = blockIdx.x * gb + 4u * j;
@@ -473,6 +469,16 @@ __global__ void __launch_bounds__(DENSE_BLOCK) k_dense_merge(Plan P, DenseArgs A
     }
   }
   __syncthreads();
+}
+
+__global__ void __launch_bounds__(DENSE_BLOCK) k_dense_merge(Plan P, DenseArgs A, OutPlan O, uint64_t out_cap, uint32_t *host_sig, uint32_t seq, uint32_t gb,
+                                                             uint32_t W) {
+  __shared__ __align__(16) uint32_t tmp[DENSE_BLOCK / 64];
+  __shared__ uint32_t s_base, s_n;
+  uint64_t *part = (uint64_t *)dsm;                                       // [n_accs][W][gb]; way 0 ends up holding the finals
+  uint32_t *list = (uint32_t *)(dsm + (size_t)P.n_accs * W * gb * 8u);    // [gb]
+  const uint32_t tid = threadIdx.x, lane = tid & 63;
+  dense_sum_slices(P, A, part, gb, W);
   const uint32_t gl = tid, w = tid < gb ? 0u : 1u; // from here on: one thread per group (the first gb threads)
   const uint32_t g = blockIdx.x * gb + (tid < gb ? tid : 0u);
   const bool live = tid < gb && g < A.n_slots;
@@ -501,7 +507,7 @@ __global__ void __launch_bounds__(DENSE_BLOCK) k_dense_merge(Plan P, DenseArgs A
       const uint32_t k = k0 + tid;
       const bool livek = k < n;
       const uint32_t s = livek ? list[k] : 0u;
-      const uint32_t gg = blockIdx.x * gb + s;
+      const uint32_t gg = A.slot_base + blockIdx.x * gb + s;
       const uint64_t i = gbase + k;
       for (int o = 0; o < O.n_outs; o++) {
         const OutSpec &S = O.outs[o];
@@ -535,12 +541,38 @@ __global__ void __launch_bounds__(DENSE_BLOCK) k_dense_merge(Plan P, DenseArgs A
   if (tid == 0) {
     if (over) atomicOr(&A.flags[FLAG_OVERFLOW], 1u);
     if (s_n == gridDim.x - 1 && host_sig) { // every other workgroup has reserved its rows: the total is known
-      const uint32_t o = atomicAdd(&A.flags[FLAG_OVERFLOW], 0u) | (over ? 1u : 0u);
+      uint32_t o = atomicAdd(&A.flags[FLAG_OVERFLOW], 0u) | (over ? 1u : 0u);
+      for (uint32_t h = 0; h < A.n_hdr; h++) o |= *(const uint32_t *)(A.dump + (uint64_t)h * A.part[0].slice_stride); // a sender off the dense path
       const uint64_t groups = gbase + n;
       A.flags[FLAG_NGROUPS] = (uint32_t)groups; // (for a host that reads the flag block instead of the signal)
       __hip_atomic_store((uint64_t *)host_sig, ((uint64_t)seq << 32) | (o ? 0x80000000u : 0u) | ((uint32_t)groups & 0x7FFFFFFFu), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_SYSTEM);
     }
+  }
+}
+
+// The sharded dense path's send side: the same sums, written raw and dense into the owners' slots (dense.hpp).
+__global__ void __launch_bounds__(DENSE_BLOCK) k_dense_scatter(Plan P, DenseArgs A, DenseXchg X, uint32_t gb, uint32_t W) {
+  uint64_t *part = (uint64_t *)dsm; // [n_accs][W][gb]
+  const uint32_t tid = threadIdx.x;
+  dense_sum_slices(P, A, part, gb, W);
+  const uint32_t g = blockIdx.x * gb + tid;
+  if (tid < gb && g < X.per * X.world) {
+    const uint32_t owner = g / X.per, s = g - owner * X.per;
+    uint8_t *slot = X.send + (uint64_t)owner * X.slot_bytes;
+    for (uint32_t p = 0; p < A.n_parts; p++) {
+      const DensePart &D = A.part[p];
+      for (uint32_t i = 0; i < D.n_accs; i++) {
+        const uint64_t v = part[(size_t)D.acc[i] * W * gb + tid];
+        if (D.lw[i] == 8) *(uint64_t *)(slot + X.xoff[p][i] + (uint64_t)s * 8u) = v;
+        else *(uint32_t *)(slot + X.xoff[p][i] + (uint64_t)s * 4u) = (uint32_t)v;
+      }
+    }
+  }
+  if (blockIdx.x == 0 && tid < X.world) { // the header every peer receives: did this rank keep the dense promise?
+    uint32_t *h = (uint32_t *)(X.send + (uint64_t)tid * X.slot_bytes);
+    h[0] = (A.flags[FLAG_OVERFLOW] | X.local_bad) ? 1u : 0u;
+    h[1] = 0u; h[2] = X.per; h[3] = X.world;
   }
 }
 
@@ -564,15 +596,30 @@ void launch_dense_fold(const Plan &p, const DenseArgs &a, uint32_t n_wgs, size_t
   else { if (kv) launch_dense_fold_t<false, true>(p, a, n_wgs, lds_bytes, s); else launch_dense_fold_t<false, false>(p, a, n_wgs, lds_bytes, s); }
 }
 
-void launch_dense_merge(const Plan &p, const DenseArgs &a, const OutPlan &o, uint64_t out_cap, uint32_t *host_sig, uint32_t seq, hipStream_t s) {
+static void dense_merge_shape(const Plan &p, uint32_t groups, uint32_t &gb, uint32_t &W) {
   // gb groups per workgroup (about 512 workgroups when there are that many groups), W >= 4 ways of gb / 4 threads each
-  uint32_t gb = 16;
-  while (gb < 1024 && (a.n_slots + gb - 1) / gb > 512) gb <<= 1;
-  uint32_t W = DENSE_BLOCK / (gb / 4);
+  gb = 16;
+  while (gb < 1024 && (groups + gb - 1) / gb > 512) gb <<= 1;
+  W = DENSE_BLOCK / (gb / 4);
   if (W > 64) W = 64;
   while (W > 4 && (size_t)p.n_accs * W * gb * 8 + gb * 4 > 64 * 1024) W >>= 1; // the ways' partial results of every accumulator live in LDS
   while (gb > 16 && (size_t)p.n_accs * W * gb * 8 + gb * 4 > 64 * 1024) gb >>= 1;
+}
+
+void launch_dense_merge(const Plan &p, const DenseArgs &a, const OutPlan &o, uint64_t out_cap, uint32_t *host_sig, uint32_t seq, hipStream_t s) {
+  uint32_t gb, W;
+  dense_merge_shape(p, a.n_slots, gb, W);
   const uint32_t block = (gb / 4) * W; // >= gb
   const size_t lds = (size_t)p.n_accs * W * gb * 8 + (size_t)gb * 4;
-  hipLaunchKernelGGL(k_dense_merge, dim3((a.n_slots + gb - 1) / gb), dim3(block), lds, s, p, a, o, out_cap, host_sig, seq, gb, W);
+  const uint32_t grid = std::max<uint32_t>(1u, (a.n_slots + gb - 1) / gb); // (a rank that owns no slot still reports its zero groups)
+  hipLaunchKernelGGL(k_dense_merge, dim3(grid), dim3(block), lds, s, p, a, o, out_cap, host_sig, seq, gb, W);
+}
+
+void launch_dense_scatter(const Plan &p, const DenseArgs &a, const DenseXchg &x, hipStream_t s) {
+  uint32_t gb, W;
+  const uint32_t groups = x.per * x.world;
+  dense_merge_shape(p, groups, gb, W);
+  const uint32_t block = (gb / 4) * W;
+  const size_t lds = (size_t)p.n_accs * W * gb * 8 + (size_t)gb * 4;
+  hipLaunchKernelGGL(k_dense_scatter, dim3((groups + gb - 1) / gb), dim3(block), lds, s, p, a, x, gb, W);
 }

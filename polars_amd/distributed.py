@@ -435,7 +435,8 @@ class HipEngine:
         self.last_shuffle_bytes = int(st.shuffle_bytes)
         self.last_host_syncs = int(st.host_syncs)
         self.last_protocol = {1: "slots: one equal-split exchange (ncclSend/ncclRecv per peer)",
-                              2: "exact: counts exchange + variable-size exchange"}.get(st.protocol, "none")
+                              2: "exact: counts exchange + variable-size exchange",
+                              3: "dense: one equal-split exchange of the owners' code ranges (raw partial arrays, ncclSend/ncclRecv per peer)"}.get(st.protocol, "none")
         out = C.c_void_p(handle.value)
         cols = []
         for i in range(L.plhip_result_num_columns(out)):

@@ -93,10 +93,52 @@ def test_sharded_rccl_world1_dense_codes_and_device_inputs(oracle, rccl_world1):
     eng.dense_keys = True
     res = pd_.group_by_agg_sharded(keys, vals, aggs, device=dev, engine=eng, n_groups_hint=ncat, force_exchange=True)
     assert eng.last_partial_strategy == "dense", eng.last_partial_strategy
+    assert eng.last_protocol.startswith("dense") and eng.last_host_syncs == 1, (eng.last_protocol, eng.last_host_syncs)
     hk = [Column("id3", kt.cpu().numpy().view(np.uint32))]
     hv = [Column("v1", v1.cpu().numpy()), Column("v3", v3.cpu().numpy())]
     want, _ = oracle.group_by_agg(hk, hv, aggs)
     util.assert_frames_match(_frame(res), util.oracle_to_np(want), 1, what="sharded, dense local pass")
+
+
+@pytest.mark.parametrize("case", ["nullable", "code_beyond_hint", "misaligned", "tiny", "hashed_forced"])
+def test_sharded_dense_exchange_world1(oracle, rccl_world1, case, monkeypatch):
+    """Protocol 3 (owners by code range, raw partial arrays through ncclSend / ncclRecv) against the oracle: null key, nullable
+    values, every aggregation; what breaks the dense promise on this rank falls back to the hashed protocols."""
+    import torch
+
+    from polars_amd import distributed as pd_
+
+    rng = np.random.default_rng(41)
+    n, ncat = (700, 50) if case == "tiny" else (1_500_000, 30_011)
+    k = rng.integers(0, ncat, n + 1).astype(np.uint32)
+    km = rng.random(n + 1) >= 0.02
+    v1 = rng.integers(-5, 6, n + 1).astype(np.int32)
+    v3 = np.round(rng.uniform(0, 100, n + 1), 6)
+    v3m = rng.random(n + 1) >= 0.05
+    if case == "code_beyond_hint":
+        k[n // 2] = ncat + 5
+    sl = slice(1, n + 1) if case == "misaligned" else slice(0, n)
+    if case == "hashed_forced":
+        monkeypatch.setenv("PLHIP_NO_DENSE_EXCHANGE", "1")
+    keys = [Column("k", k[sl], km[sl]).set_categories(ncat)]
+    vals = [Column("v1", v1[sl]), Column("v3", v3[sl], v3m[sl])]
+    if case == "misaligned":  # (host columns are staged into fresh allocations: only device-resident buffers can be misaligned)
+        dev = torch.device("cuda:0")
+        dk = [Column("k", torch.from_numpy(k.view(np.int32)).to(dev)[1:], dtype=_ffi.U32).set_categories(ncat)]
+        dv = [Column("v1", torch.from_numpy(v1).to(dev)[1:]), Column("v3", torch.from_numpy(v3).to(dev)[1:])]
+        keys, vals = [Column("k", k[sl])], [Column("v1", v1[sl]), Column("v3", v3[sl])]
+    else:
+        dk, dv = keys, vals
+    aggs = [(0, "sum"), (1, "mean"), (1, "min"), (1, "max"), (0, "count"), (1, "sum"), (0, "mean"), (0, "min")]
+    eng = pd_.HipEngine(torch.device("cuda:0"))
+    eng.dense_keys = True
+    res = pd_.group_by_agg_sharded(dk, dv, aggs, device=torch.device("cuda:0"), engine=eng, n_groups_hint=ncat, force_exchange=True)
+    want, _ = oracle.group_by_agg(keys, vals, aggs)
+    util.assert_frames_match(_frame(res), util.oracle_to_np(want), 1, what=f"sharded dense exchange, {case}")
+    if case in ("code_beyond_hint", "misaligned", "hashed_forced"):
+        assert not eng.last_protocol.startswith("dense"), eng.last_protocol
+    else:
+        assert eng.last_protocol.startswith("dense") and eng.last_host_syncs == 1, (eng.last_protocol, eng.last_host_syncs)
 
 
 def test_sharded_torch_transport_fallback(oracle, rccl_world1, monkeypatch):
@@ -143,4 +185,4 @@ def test_sharded_ranks_on_one_gpu(world):
     env.pop("MASTER_PORT", None)
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
-    assert p.stdout.count("ok:") == 6, p.stdout[-3000:]
+    assert p.stdout.count("ok:") == 10, p.stdout[-3000:]
