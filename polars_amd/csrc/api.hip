@@ -61,7 +61,9 @@ struct Ctx {
   int forced_strategy = -1; // -1: not set by the API (env / auto)
   Scratch table, slots, sortkeys, flags, misc, rank, plans, items, part, dump, hdr, offs;
   float k_ms[3] = {0.f, 0.f, 0.f}; // fast path: tile sort, fold, merge+emit
-  bool flags_clean = false;        // the 64-byte flag block is zero (re-zeroed behind every read, off the next query's critical path)
+  bool signal_seen = false;        // wait_signal: the last query's count came through the pinned signal word (not the flag block)
+  int flags_clean = 0;             // 1: the 64-byte flag block is zero (re-zeroed behind every read, off the next query's critical path);
+                                   // 2: zero but for FLAG_NGROUPS (k_dense_merge's last workgroup cleans up after itself: good for the next dense query)
   uint32_t *host_flags = nullptr; // pinned, 64 bytes
   // fast path: the last kernel publishes the flag block here (pinned, coherent, device-visible) and the host
   // spins on its first 64-bit word instead of queueing a device-to-host copy and waiting for the stream
@@ -605,6 +607,7 @@ int read_flags(TableRef t, uint32_t *out8) {
 int wait_signal(TableRef t, uint32_t seq, uint32_t *out8) {
   Ctx &c = g_ctx;
   c.flags_clean = false;
+  c.signal_seen = false;
   const uint64_t *sig = (const uint64_t *)c.host_sig;
   uint64_t v;
   for (uint64_t spin = 1;; spin++) {
@@ -619,6 +622,7 @@ int wait_signal(TableRef t, uint32_t seq, uint32_t *out8) {
     }
     __builtin_ia32_pause();
   }
+  c.signal_seen = true;
   memset(out8, 0, 32);
   out8[FLAG_OVERFLOW] = (uint32_t)(v >> 31) & 1u;
   out8[FLAG_NGROUPS] = (uint32_t)v & 0x7FFFFFFFu;
@@ -1038,7 +1042,7 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
   R->device = c.device;
   OutPlan OP{};
   OP.n_outs = (int)L.outs.size();
-  if (!c.flags_clean) HIP_TRY(hipMemsetAsync(dflags, 0, 64, c.stream));
+  if (c.flags_clean != 1) HIP_TRY(hipMemsetAsync(dflags, 0, 64, c.stream));
   c.flags_clean = false;
   uint32_t *self_hot = (uint32_t *)((uint8_t *)dflags + FLAGS_HOT_OFF) + 2; // [-2] any, [-1] queue, rows[n_pg], done[n_pg]
   if (hot_self) {
@@ -1471,7 +1475,7 @@ int run_dense(const Lowered &L0, const std::vector<DevCol> &dk, uint32_t flags, 
   OutPlan OP{};
   OP.n_outs = (int)L.outs.size();
   (void)hipGetLastError();
-  if (!c.flags_clean) HIP_TRY(hipMemsetAsync(dflags, 0, 64, c.stream));
+  if (c.flags_clean == 0) HIP_TRY(hipMemsetAsync(dflags, 0, 64, c.stream));
   c.flags_clean = false;
   for (size_t i = 0; i < L.outs.size(); i++) {
     OutSpec o = L.outs[i];
@@ -1515,7 +1519,8 @@ int run_dense(const Lowered &L0, const std::vector<DevCol> &dk, uint32_t flags, 
   const int rc = wait_signal(t, seq, fl);
   if (rc) return rc;
   if (comm) { c.shard_stats.host_syncs++; lap(c.shard_stats.merge_ms); }
-  if (hipMemsetAsync(dflags, 0, 64, c.stream) == hipSuccess) c.flags_clean = true;
+  if (!fl[FLAG_OVERFLOW] && c.signal_seen) c.flags_clean = 2; // (the signal was seen: the kernel's last workgroup has zeroed its counters)
+  else if (hipMemsetAsync(dflags, 0, 64, c.stream) == hipSuccess) c.flags_clean = true;
   c.timing_pending = 4;
   c.strategy = "dense";
   if (getenv("PLHIP_DENSE_VERBOSE"))
@@ -1661,7 +1666,7 @@ int run_two_level(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, uint64_t 
   OutPlan OP{};
   OP.n_outs = (int)L.outs.size();
   (void)hipGetLastError();
-  if (!c.flags_clean) HIP_TRY(hipMemsetAsync(dflags, 0, 64, c.stream));
+  if (c.flags_clean != 1) HIP_TRY(hipMemsetAsync(dflags, 0, 64, c.stream));
   c.flags_clean = false;
   for (size_t i = 0; i < L.outs.size(); i++) {
     OutSpec o = L.outs[i];

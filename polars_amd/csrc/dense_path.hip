@@ -545,6 +545,9 @@ __global__ void __launch_bounds__(DENSE_BLOCK) k_dense_merge(Plan P, DenseArgs A
       for (uint32_t h = 0; h < A.n_hdr; h++) o |= *(const uint32_t *)(A.dump + (uint64_t)h * A.part[0].slice_stride); // a sender off the dense path
       const uint64_t groups = gbase + n;
       A.flags[FLAG_NGROUPS] = (uint32_t)groups; // (for a host that reads the flag block instead of the signal)
+      // this workgroup reserved last: nobody touches the counters any more, and `o` is final (had any workgroup run past out_cap, the
+      // last reservation would have too).  A clean run leaves the flag block ready for the next dense query (api.hip flags_clean = 2).
+      if (!o) { A.flags[8] = 0u; A.flags[9] = 0u; }
       __hip_atomic_store((uint64_t *)host_sig, ((uint64_t)seq << 32) | (o ? 0x80000000u : 0u) | ((uint32_t)groups & 0x7FFFFFFFu), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_SYSTEM);
     }
