@@ -412,6 +412,35 @@ int32_t plhip_finalize_partial(const plhip_result_t *merged, int32_t n_keys, con
                                const plhip_column_t *out_cols);
 
 
+/* ---- string keys ----------------------------------------------------------------------------------
+ * IntoGroupsProxy for Utf8Chunked / BinaryChunked (crates/polars-core/src/frame/group_by/into_groups.rs:232-290): the
+ * reference hashes every string once and groups the (hash, bytes) pairs -- BytesHash, hashing/vector_hasher.rs:422-446,
+ * equal when the hashes and then the bytes are equal; all nulls form one group.  plhip_utf8_encode does the same on the
+ * device and hands back what a Categorical holds: dense u32 codes (code = index of the string's group; null rows keep the
+ * column's validity) and the dictionary (string g = the string at group g's first row; it has one null entry when the
+ * column has nulls -- no valid row carries that code).  The codes are then an ordinary key column for every entry point
+ * of this header; as a single key with PLHIP_FLAG_KEYS_DENSE and n_groups_hint = plhip_dictionary_len they take the
+ * dense-code path (perfect.rs:190-227), and the host decodes the result's key codes through the dictionary the way a
+ * Categorical's rev-map does.  Every row's bytes are compared with its group's first row's (a 64-bit collision between
+ * different strings makes the encoder start over with another seed), so groups are exact, never probabilistic. */
+typedef struct plhip_utf8_column { /* one single-chunk Arrow LargeUtf8 / LargeBinary array (i64 offsets: Utf8Chunked in 0.33) */
+  const int64_t *offsets;  /* offsets buffer start: entries offset .. offset + length are read */
+  const uint8_t *data;     /* values buffer the offsets index */
+  const uint8_t *validity; /* LSB-first bitmap over the buffer, or NULL */
+  int64_t offset;          /* Arrow array offset in elements */
+  int64_t length;
+  int32_t location;        /* plhip_location_t, of all three buffers */
+  int32_t pad;
+} plhip_utf8_column_t;
+typedef struct plhip_dictionary plhip_dictionary_t;
+/* `codes`: a device-resident u32 column of col->length rows (validity: a copy of the column's, or NULL), owned by *dict
+ * and valid until plhip_dictionary_free. */
+int32_t plhip_utf8_encode(const plhip_utf8_column_t *col, plhip_dictionary_t **dict, plhip_column_t *codes);
+int64_t plhip_dictionary_len(const plhip_dictionary_t *dict); /* entries (= groups of the column, the null group included) */
+/* The dictionary as a LargeUtf8 array in device memory or (copied on first request) host memory; owned by the dictionary. */
+int32_t plhip_dictionary_strings(plhip_dictionary_t *dict, int32_t location, plhip_utf8_column_t *out);
+void plhip_dictionary_free(plhip_dictionary_t *dict);
+
 /* ---- the sharded path: one rank per GPU, the exchange inside the library ------------------------------ */
 
 /* The reference's partitioned group-by (crates/polars-lazy/src/physical_plan/executors/group_by_partitioned.rs:273-361) runs

@@ -823,3 +823,47 @@ int orc_sink_group_by(const plhip_column_t *key, const plhip_column_t *values, i
   free(sinks); free(jobs); free(tids);
   return rc;
 }
+
+/* ---- string keys (into_groups.rs:232-290) ------------------------------------------------------------------ */
+static uint64_t bytes_hash(const uint8_t *p, int64_t len) { /* any hash does: the reference's (ahash, random seeds) is not observable */
+  uint64_t h = 0xcbf29ce484222325ull ^ (uint64_t)len;
+  for (int64_t i = 0; i < len; i++) { h ^= p[i]; h *= 0x100000001b3ull; }
+  return orc_folded_multiply(h, 0x9E3779B97F4A7C15ull);
+}
+
+int64_t orc_utf8_group_codes(const int64_t *offsets, const uint8_t *data, const uint8_t *validity, int64_t offset, int64_t n,
+                             uint32_t *codes, uint32_t *first) {
+  uint64_t cap = 16;
+  while (cap < (uint64_t)n * 2 + 2) cap <<= 1;
+  int64_t *slot = (int64_t *)malloc(cap * sizeof(int64_t)); /* group index or -1 */
+  uint64_t *hs = (uint64_t *)malloc((n > 0 ? n : 1) * sizeof(uint64_t)); /* hash of group g */
+  if (!slot || !hs) { free(slot); free(hs); return -1; }
+  for (uint64_t i = 0; i < cap; i++) slot[i] = -1;
+  const uint64_t null_h = 0x5851F42D4C957F2Dull;
+  int64_t G = 0;
+  for (int64_t i = 0; i < n; i++) {
+    const int64_t r = offset + i;
+    const int valid = !validity || ((validity[r >> 3] >> (r & 7)) & 1);
+    const uint8_t *p = valid ? data + offsets[r] : NULL;
+    const int64_t len = valid ? offsets[r + 1] - offsets[r] : 0;
+    const uint64_t h = valid ? bytes_hash(p, len) : null_h; /* into_groups.rs:257-260 */
+    uint64_t s = h & (cap - 1);
+    for (;;) {
+      const int64_t g = slot[s];
+      if (g < 0) { slot[s] = G; hs[G] = h; first[G] = (uint32_t)i; codes[i] = (uint32_t)G; G++; break; }
+      if (hs[g] == h) { /* BytesHash::eq (vector_hasher.rs:437-446): hashes, then payloads */
+        const int64_t fr = offset + first[g];
+        const int fvalid = !validity || ((validity[fr >> 3] >> (fr & 7)) & 1);
+        int same = fvalid == valid;
+        if (same && valid) {
+          const int64_t flen = offsets[fr + 1] - offsets[fr];
+          same = flen == len && memcmp(data + offsets[fr], p, (size_t)len) == 0;
+        }
+        if (same) { codes[i] = (uint32_t)g; break; }
+      }
+      s = (s + 1) & (cap - 1);
+    }
+  }
+  free(slot); free(hs);
+  return G;
+}

@@ -69,6 +69,13 @@ int orc_agg_partitioned(const plhip_column_t *values, int kind, const orc_groups
 int orc_sink_group_by(const plhip_column_t *key, const plhip_column_t *values, int n_values, const int *agg_col, const int *agg_kind,
                       int n_aggs, int n_threads, int64_t morsel, int64_t max_groups, uint64_t *out_keys, uint8_t *out_key_valid,
                       double *out_vals, uint8_t *out_valid, int64_t *n_groups);
+/* IntoGroupsProxy for Utf8Chunked / BinaryChunked (into_groups.rs:232-290): every string is hashed once (nulls get one
+ * constant, null_h), the (hash, bytes) pairs are grouped with BytesHash equality (vector_hasher.rs:422-446: hash first, then
+ * the bytes; two nulls are equal); groups are numbered by first occurrence as `group_by(.., sorted = true)` leaves them
+ * (hashing.rs:32-79).  codes[i] = group of row i, first[g] = first row of group g (capacity n).  Returns the group count. */
+int64_t orc_utf8_group_codes(const int64_t *offsets, const uint8_t *data, const uint8_t *validity, int64_t offset, int64_t n,
+                             uint32_t *codes, uint32_t *first);
+
 int orc_take_keys(const plhip_column_t *key, const orc_groups_t *g, void *out_values, uint8_t *out_valid);
 
 #ifdef __cplusplus

@@ -49,6 +49,8 @@ def lib():
         L.orc_agg_out_dtype.argtypes = [C.c_int, C.c_int]
         L.orc_agg.argtypes = [P(_ffi.ColumnStruct), C.c_int, P(_Groups), C.c_void_p, C.c_void_p, C.c_int]
         L.orc_agg_partitioned.argtypes = [P(_ffi.ColumnStruct), C.c_int, P(_Groups), C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_utf8_group_codes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+        L.orc_utf8_group_codes.restype = C.c_int64
         L.orc_take_keys.argtypes = [P(_ffi.ColumnStruct), P(_Groups), C.c_void_p, C.c_void_p]
         L.orc_sink_group_by.argtypes = [P(_ffi.ColumnStruct), P(_ffi.ColumnStruct), C.c_int, P(C.c_int), P(C.c_int), C.c_int, C.c_int,
                                         C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, P(C.c_int64)]
@@ -316,3 +318,18 @@ def agg_ext(values: Column, kind: str, groups: Groups, ddof: int = 1):
             v = m2 / (count - ddof)
             out[g], valid[g] = (v ** 0.5 if kind == "std" else v), True
     return out, valid
+
+
+def utf8_group_codes(offsets: np.ndarray, data: np.ndarray, valid: np.ndarray | None):
+    """orc_utf8_group_codes: (codes[n] u32, first[G] u32) of a LargeUtf8 column (into_groups.rs:232-290), groups numbered by
+    first occurrence; `valid` is a bool mask or None."""
+    n = len(offsets) - 1
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    bits = None if valid is None else np.packbits(np.asarray(valid, dtype=bool), bitorder="little")
+    codes, first = np.zeros(max(n, 1), np.uint32), np.zeros(max(n, 1), np.uint32)
+    g = lib().orc_utf8_group_codes(offsets.ctypes.data, data.ctypes.data if len(data) else None, None if bits is None else bits.ctypes.data, 0, n,
+                                   codes.ctypes.data, first.ctypes.data)
+    if g < 0:
+        raise MemoryError("orc_utf8_group_codes")
+    return codes[:n], first[:g]

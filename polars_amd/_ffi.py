@@ -110,6 +110,12 @@ class ChunkedColumnStruct(C.Structure):
     _fields_ = [("chunks", C.POINTER(ColumnStruct)), ("n_chunks", C.c_int32), ("pad", C.c_int32)]
 
 
+class Utf8ColumnStruct(C.Structure):
+    """plhip_utf8_column_t"""
+    _fields_ = [("offsets", C.c_void_p), ("data", C.c_void_p), ("validity", C.c_void_p), ("offset", C.c_int64), ("length", C.c_int64),
+                ("location", C.c_int32), ("pad", C.c_int32)]
+
+
 class ShardedStats(C.Structure):
     """plhip_sharded_stats_t"""
     _fields_ = [("partial_ms", C.c_float), ("pack_ms", C.c_float), ("exchange_ms", C.c_float), ("merge_ms", C.c_float),
@@ -200,6 +206,14 @@ def lib():
     L.plhip_group_by_agg_chunked.argtypes = [P(ChunkedColumnStruct), i32, P(ChunkedColumnStruct), i32, P(AggStruct), i32, u32,
                                              P(OptionsStruct), P(vp)]
     L.plhip_group_by_agg_chunked.restype = i32
+    L.plhip_utf8_encode.argtypes = [P(Utf8ColumnStruct), P(vp), P(ColumnStruct)]
+    L.plhip_utf8_encode.restype = i32
+    L.plhip_dictionary_len.argtypes = [vp]
+    L.plhip_dictionary_len.restype = C.c_int64
+    L.plhip_dictionary_strings.argtypes = [vp, i32, P(Utf8ColumnStruct)]
+    L.plhip_dictionary_strings.restype = i32
+    L.plhip_dictionary_free.argtypes = [vp]
+    L.plhip_dictionary_free.restype = None
     L.plhip_release_workspace.argtypes = []
     L.plhip_release_workspace.restype = i32
     L.plhip_pooled_buffers.argtypes = [i32]
@@ -263,4 +277,5 @@ EXPORTED_SYMBOLS = [
     "plhip_group_by_agg_noalloc", "plhip_release_workspace", "plhip_pooled_buffers",
     "plhip_comm_unique_id", "plhip_comm_init_rccl", "plhip_comm_init_host", "plhip_comm_free", "plhip_group_by_agg_sharded",
     "plhip_sharded_last_stats", "plhip_group_by_agg_chunked",
+    "plhip_utf8_encode", "plhip_dictionary_len", "plhip_dictionary_strings", "plhip_dictionary_free",
 ]

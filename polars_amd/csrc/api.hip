@@ -22,6 +22,7 @@
 #include "comm.hpp"
 #include "fast.hpp"
 #include "kernels.hpp"
+#include "utf8.hpp"
 
 // Scratch of plhip_group_by_agg_noalloc (flag block, dump headers, table dumps): a file-scope device array, so that the
 // entry point never calls hipMalloc.  Every GPU the library runs on holds its own copy until the process ends.  In host
@@ -73,6 +74,7 @@ struct Ctx {
   bool hot_clean = false;  // the heavy-hitter words behind the flag block (FLAGS_HOT_OFF ..) are zero
   int timing_pending = 0; // 1: direct, 2: tilesort (S == 1), 3: tilesort + merge -- event times not read yet
   Scratch xsend, xrecv, xcnt; // the sharded path's exchange buffers
+  Scratch str_a, str_b;       // plhip_utf8_encode: hashes + row ids; lookup table + dictionary lengths + scan space
   plhip_comm *dense_comm = nullptr; // set by sharded_impl around its dense attempt (group_by_agg_impl reads it)
   plhip_sharded_stats_t shard_stats{};
   uint8_t *na_scratch = nullptr; // device address of this GPU's static scratch array (plhip_group_by_agg_noalloc)
@@ -81,7 +83,7 @@ struct Ctx {
     if (device < 0) return;
     if (hipSetDevice(device) != hipSuccess) return;
     if (stream) hipStreamSynchronize(stream);
-    for (Scratch *b : {&table, &slots, &sortkeys, &flags, &misc, &rank, &plans, &items, &part, &dump, &hdr, &offs, &xsend, &xrecv, &xcnt}) b->release();
+    for (Scratch *b : {&table, &slots, &sortkeys, &flags, &misc, &rank, &plans, &items, &part, &dump, &hdr, &offs, &xsend, &xrecv, &xcnt, &str_a, &str_b}) b->release();
     flags_clean = false; hot_clean = false; timing_pending = 0;
   }
   // A thread that ends gives back what it holds: workspace, stream, events, pinned words.  (Threads still alive when the
@@ -2103,6 +2105,174 @@ int32_t plhip_group_by_agg_chunked(const plhip_chunked_column_t *keys, int32_t n
   if (rc) hipStreamSynchronize(g_ctx.stream); // the copies may still be queued: the buffers are freed on the way out
   return rc;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// string keys: LargeUtf8 -> dense codes + dictionary (utf8.hpp)
+// ---------------------------------------------------------------------------------------------------------
+struct plhip_dictionary {
+  int device = 0;
+  int64_t n = 0, G = 0, total = 0;
+  uint32_t *codes = nullptr, *cvalid = nullptr, *dvalid = nullptr;
+  int64_t *offs = nullptr;
+  uint8_t *data = nullptr;
+  size_t cap[5] = {0, 0, 0, 0, 0}; // pool capacities of codes, cvalid, dvalid, offs, data
+  int64_t *h_offs = nullptr; uint8_t *h_data = nullptr, *h_valid = nullptr;
+  ~plhip_dictionary() { // device buffers go back to the result pool (hipMalloc / hipFree cost more than the encoder's kernels)
+    g_pool.put(device, codes, cap[0]); g_pool.put(device, cvalid, cap[1]); g_pool.put(device, dvalid, cap[2]);
+    g_pool.put(device, offs, cap[3]); g_pool.put(device, data, cap[4]);
+    free(h_offs); free(h_data); free(h_valid);
+  }
+};
+
+int32_t plhip_utf8_encode(const plhip_utf8_column_t *col, plhip_dictionary_t **dict, plhip_column_t *codes) {
+  if (!col || !dict || !codes) return fail(PLHIP_ERR_INVALID, "NULL pointer");
+  *dict = nullptr;
+  const int64_t n = col->length;
+  if (n < 0 || col->offset < 0) return fail(PLHIP_ERR_INVALID, "negative column offset/length");
+  if (n > 0xFFFFFFFFll) return fail(PLHIP_ERR_COMPUTE, "more than u32::MAX rows (IdxSize is u32)");
+  if (!col->offsets || (n > 0 && !col->data)) return fail(PLHIP_ERR_INVALID, "offsets / data pointer is NULL");
+  if (col->location != PLHIP_HOST && col->location != PLHIP_DEVICE) return fail(PLHIP_ERR_INVALID, "bad column location");
+  int rc = ensure_ctx();
+  if (rc) return rc;
+  Ctx &c = g_ctx;
+  Staging st; // every temporary of the call
+  auto dmalloc = [&](void **p, size_t bytes) -> hipError_t {
+    const hipError_t e = hipMalloc(p, bytes ? bytes : 8);
+    if (e == hipSuccess) st.owned.push_back(*p);
+    return e;
+  };
+  std::unique_ptr<plhip_dictionary> D(new (std::nothrow) plhip_dictionary());
+  if (!D) return fail(PLHIP_ERR_OOM, "host allocation failed");
+  D->device = c.device; D->n = n;
+  // ---- the column in HBM -------------------------------------------------------------------------------------------
+  Utf8View V{};
+  V.n = n;
+  if (col->location == PLHIP_DEVICE) {
+    V.offsets = col->offsets + col->offset; V.data = col->data; V.validity = col->validity; V.boff = col->offset;
+  } else {
+    const int64_t o0 = col->offsets[col->offset], o1 = col->offsets[col->offset + n];
+    if (o1 < o0) return fail(PLHIP_ERR_INVALID, "offsets are not monotonic");
+    void *doff = nullptr, *ddat = nullptr;
+    HIP_TRY(dmalloc(&doff, (size_t)(n + 1) * 8));
+    HIP_TRY(hipMemcpyAsync(doff, col->offsets + col->offset, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c.stream));
+    HIP_TRY(dmalloc(&ddat, (size_t)(o1 - o0)));
+    if (o1 > o0) HIP_TRY(hipMemcpyAsync(ddat, col->data + o0, (size_t)(o1 - o0), hipMemcpyHostToDevice, c.stream));
+    V.offsets = (const int64_t *)doff;
+    V.data = (const uint8_t *)ddat - o0; // the offsets index the host buffer: the staged range starts at o0
+    if (col->validity) {
+      const int64_t b0 = col->offset >> 3, b1 = (col->offset + n + 7) >> 3;
+      void *db = nullptr;
+      HIP_TRY(dmalloc(&db, (size_t)(b1 - b0) + 8));
+      if (b1 > b0) HIP_TRY(hipMemcpyAsync(db, col->validity + b0, (size_t)(b1 - b0), hipMemcpyHostToDevice, c.stream));
+      V.validity = (const uint8_t *)db; V.boff = col->offset & 7;
+    }
+  }
+  // ---- hash -> distinct hashes with their first rows -> codes -> verify ---------------------------------------------
+  const size_t h_bytes = ((size_t)n * 8 + 255) & ~(size_t)255, i_bytes = ((size_t)n * 4 + 255) & ~(size_t)255;
+  HIP_TRY(c.str_a.reserve(h_bytes + i_bytes + 256));
+  void *h = c.str_a.p, *iota = (uint8_t *)c.str_a.p + h_bytes, *bad_d = (uint8_t *)c.str_a.p + h_bytes + i_bytes;
+  HIP_TRY(g_pool.get(c.device, n ? (size_t)n * 4 : 8, (void **)&D->codes, &D->cap[0]));
+  struct Groups { plhip_result_t *p = nullptr; ~Groups() { delete p; } } groups; // (device-resident frame: back to the pool on every path out)
+  uint64_t G = 0;
+  static const uint64_t seeds[3] = {0x243F6A8885A308D3ull, 0x13198A2E03707344ull, 0xA4093822299F31D0ull};
+  for (int attempt = 0;; attempt++) {
+    if (attempt == 3) return fail(PLHIP_ERR_COMPUTE, "string hashes collided under three seeds");
+    if (groups.p) { delete groups.p; groups.p = nullptr; }
+    G = 0;
+    if (n == 0) break;
+    launch_utf8_hash(V, seeds[attempt], (uint64_t *)h, (uint32_t *)iota, c.stream);
+    HIP_TRY(hipGetLastError());
+    plhip_column_t kc{}, vc{};
+    kc.values = h; kc.length = n; kc.dtype = PLHIP_U64; kc.location = PLHIP_DEVICE;
+    vc.values = iota; vc.length = n; vc.dtype = PLHIP_U32; vc.location = PLHIP_DEVICE;
+    const plhip_agg_t first_row{0, PLHIP_AGG_MIN};
+    if ((rc = group_by_agg_impl(&kc, 1, &vc, 1, &first_row, 1, PLHIP_FLAG_OUTPUT_DEVICE, nullptr, &groups.p))) return rc;
+    G = (uint64_t)groups.p->n_rows;
+    if (G == 0 || G > 0x7FFFFFF0ull || groups.p->cols.size() != 2 || groups.p->cols[1].dtype != PLHIP_U32)
+      return fail(PLHIP_ERR_COMPUTE, "the group-by over the string hashes came back malformed");
+    const uint64_t cap = next_pow2(std::max<uint64_t>(2 * G, 1024));
+    HIP_TRY(c.str_b.reserve(cap * 12 + 256));
+    void *tkeys = c.str_b.p, *tvals = (uint8_t *)c.str_b.p + cap * 8;
+    uint32_t bad = 0;
+    HIP_TRY(hipMemsetAsync(tkeys, 0xFF, cap * 8, c.stream));
+    HIP_TRY(hipMemsetAsync(bad_d, 0, 8, c.stream));
+    launch_ht_build((const uint64_t *)groups.p->cols[0].values, (uint32_t)G, (uint64_t *)tkeys, (uint32_t *)tvals, cap - 1, c.stream);
+    launch_ht_probe_verify(V, (const uint64_t *)h, (const uint64_t *)tkeys, (const uint32_t *)tvals, cap - 1, (const uint32_t *)groups.p->cols[1].values,
+                           D->codes, (uint32_t *)bad_d, c.stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(c.host_flags, bad_d, 4, hipMemcpyDeviceToHost, c.stream)); // (pinned)
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    bad = c.host_flags[0];
+    if (bad & 2u) return fail(PLHIP_ERR_COMPUTE, "a row's hash is missing from the lookup table");
+    if (!bad) break; // every row equals its group's first row byte for byte
+  }
+  D->G = (int64_t)G;
+  // ---- the dictionary: the strings at the groups' first rows ---------------------------------------------------------
+  HIP_TRY(g_pool.get(c.device, (size_t)(G + 1) * 8, (void **)&D->offs, &D->cap[3]));
+  HIP_TRY(g_pool.get(c.device, (size_t)(G / 32 + 2) * 4, (void **)&D->dvalid, &D->cap[2]));
+  HIP_TRY(hipMemsetAsync(D->dvalid, 0, (size_t)(G / 32 + 2) * 4, c.stream));
+  if (G > 0) {
+    const uint32_t *first = (const uint32_t *)groups.p->cols[1].values;
+    const size_t tb = utf8_scan_temp_bytes((uint32_t)G), l_bytes = ((size_t)(G + 1) * 8 + 255) & ~(size_t)255;
+    HIP_TRY(c.str_b.reserve(l_bytes + tb + 256)); // (the lookup table is done with)
+    void *lens = c.str_b.p, *tmp = (uint8_t *)c.str_b.p + l_bytes;
+    launch_utf8_lengths(V, first, (uint32_t)G, (int64_t *)lens, c.stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(utf8_scan(tmp, tb, (const int64_t *)lens, D->offs, (uint32_t)G, c.stream));
+    HIP_TRY(hipMemcpyAsync(c.host_flags, D->offs + G, 8, hipMemcpyDeviceToHost, c.stream));
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    memcpy(&D->total, c.host_flags, 8);
+    HIP_TRY(g_pool.get(c.device, D->total > 0 ? (size_t)D->total : 8, (void **)&D->data, &D->cap[4]));
+    launch_utf8_gather(V, first, (uint32_t)G, D->offs, D->data, D->dvalid, c.stream);
+    HIP_TRY(hipGetLastError());
+  } else {
+    HIP_TRY(hipMemsetAsync(D->offs, 0, 8, c.stream));
+    HIP_TRY(g_pool.get(c.device, 8, (void **)&D->data, &D->cap[4]));
+  }
+  if (V.validity) { // the codes' validity: the column's bitmap, re-based at bit 0
+    const size_t words = (size_t)((n + 31) / 32) + 2;
+    HIP_TRY(g_pool.get(c.device, words * 4, (void **)&D->cvalid, &D->cap[1]));
+    HIP_TRY(hipMemsetAsync(D->cvalid, 0, words * 4, c.stream));
+    if (n > 0) { launch_copy_bits(D->cvalid, 0, V.validity, V.boff, n, c.stream); HIP_TRY(hipGetLastError()); }
+  }
+  HIP_TRY(hipStreamSynchronize(c.stream));
+  *codes = plhip_column_t{};
+  codes->values = D->codes; codes->validity = (const uint8_t *)D->cvalid; codes->offset = 0; codes->length = n;
+  codes->dtype = PLHIP_U32; codes->location = PLHIP_DEVICE;
+  *dict = D.release();
+  return PLHIP_OK;
+}
+
+int64_t plhip_dictionary_len(const plhip_dictionary_t *d) { return d ? d->G : -1; }
+
+int32_t plhip_dictionary_strings(plhip_dictionary_t *d, int32_t location, plhip_utf8_column_t *out) {
+  if (!d || !out) return fail(PLHIP_ERR_INVALID, "NULL pointer");
+  *out = plhip_utf8_column_t{};
+  out->length = d->G; out->location = location;
+  if (location == PLHIP_DEVICE) {
+    out->offsets = d->offs; out->data = d->data; out->validity = (const uint8_t *)d->dvalid;
+    return PLHIP_OK;
+  }
+  if (location != PLHIP_HOST) return fail(PLHIP_ERR_INVALID, "bad location");
+  if (!d->h_offs) {
+    int rc = ensure_ctx();
+    if (rc) return rc;
+    if (g_ctx.device != d->device) return fail(PLHIP_ERR_INVALID, "the dictionary belongs to another device than the calling thread's");
+    const size_t vb = (size_t)(d->G / 32 + 2) * 4;
+    int64_t *ho = (int64_t *)malloc((size_t)(d->G + 1) * 8);
+    uint8_t *hd = (uint8_t *)malloc(d->total > 0 ? (size_t)d->total : 8), *hv = (uint8_t *)malloc(vb);
+    hipError_t e = (ho && hd && hv) ? hipSuccess : hipErrorOutOfMemory;
+    if (e == hipSuccess) e = hipMemcpy(ho, d->offs, (size_t)(d->G + 1) * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && d->total > 0) e = hipMemcpy(hd, d->data, (size_t)d->total, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(hv, d->dvalid, vb, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { free(ho); free(hd); free(hv); return fail_hip(e, "dictionary copy"); }
+    d->h_offs = ho; d->h_data = hd; d->h_valid = hv;
+  }
+  out->offsets = d->h_offs; out->data = d->h_data; out->validity = d->h_valid;
+  return PLHIP_OK;
+}
+
+void plhip_dictionary_free(plhip_dictionary_t *d) { delete d; }
 
 int32_t plhip_group_by_agg_noalloc(const plhip_column_t *keys, int32_t n_keys, const plhip_column_t *values, int32_t n_values,
                                    const plhip_agg_t *aggs, int32_t n_aggs, uint32_t flags, int64_t n_groups_hint,

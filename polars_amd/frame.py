@@ -105,6 +105,10 @@ class DataFrame:
         if isinstance(v, tuple):  # (values, valid_mask)
             return Column(name, v[0], v[1])
         if isinstance(v, list):
+            if any(isinstance(x, (str, bytes)) for x in v):  # a Utf8 column (group-by key only: strings.py)
+                from .strings import Utf8Column
+
+                return Utf8Column.from_list(name, v)
             if any(x is None for x in v):
                 mask = np.array([x is not None for x in v])
                 vals = np.array([0 if x is None else x for x in v])
@@ -420,6 +424,15 @@ def _execute(df: DataFrame, by: list[str], exprs: list[Expr], maintain_order: bo
     if not by:
         raise _ffi.ComputeError(1, "at least one key is required in a group_by operation")
     keys = [df.get_column(n) for n in by]
+    dicts = {}
+    for i, k in enumerate(keys):  # Utf8 keys: dense codes + dictionary on the device (into_groups.rs:232-290), encoded once per column
+        if type(k).__name__ == "Utf8Column":
+            from .strings import encode
+
+            if getattr(k, "_encoded", None) is None:
+                k._encoded = encode(k)
+            keys[i] = k._encoded
+            dicts[i] = k._encoded.dictionary
     vals: list[Column] = []
     index: dict[str, int] = {}
     aggs: list[tuple[int, int]] = []
@@ -431,6 +444,8 @@ def _execute(df: DataFrame, by: list[str], exprs: list[Expr], maintain_order: bo
             aggs.append((-1, _ffi.AGG_COUNT))
         else:
             c = df.get_column(e.column)
+            if type(c).__name__ == "Utf8Column":
+                raise _ffi.PlHipError(4, f"aggregating the string column {e.column!r} is not on the accelerated path")
             if e.column not in index:
                 index[e.column] = len(vals)
                 vals.append(c)
@@ -447,10 +462,14 @@ def _execute(df: DataFrame, by: list[str], exprs: list[Expr], maintain_order: bo
         hint = keys[0].n_categories
     handle, cols = group_by_agg_raw(keys, vals, aggs, flags, hint, slice_=slice_)
     try:
-        out = DataFrame([_host_column(nm, cs) for nm, cs in zip(names, cols)])
+        host = [_host_column(nm, cs) for nm, cs in zip(names, cols)]
     finally:
         _ffi.lib().plhip_result_free(handle)
-    return out
+    for i, d in dicts.items():  # the key codes back to their strings, as a Categorical's rev-map does at output
+        from .strings import DecodedColumn
+
+        host[i] = DecodedColumn(names[i], d.decode(host[i].to_numpy(), host[i].valid_mask()))
+    return DataFrame(host)
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -1,0 +1,152 @@
+"""String key columns: Arrow LargeUtf8 on the host side, dense u32 codes + a dictionary on the device side.
+
+Mirrors Utf8Chunked as a group-by key (crates/polars-core/src/frame/group_by/into_groups.rs:232-290): the library hashes
+every string, groups (hash, bytes) pairs exactly and returns what a Categorical holds -- physical codes and the strings they
+stand for (plhip_utf8_encode, include/plhip.h).  The group-by then runs on the codes (a single string key takes the
+dense-code path, perfect.rs:190-227) and the result's key codes are decoded through the dictionary, as a Categorical's
+rev-map would.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from .column import Column, pack_validity, unpack_validity
+
+
+class Utf8Column:
+    """One single-chunk LargeUtf8 array: int64 offsets (length + 1), uint8 data, optional validity."""
+
+    def __init__(self, name: str, offsets, data, validity=None, *, offset: int = 0, length: int | None = None):
+        self.name = name
+        self.offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        self.data = np.ascontiguousarray(data, dtype=np.uint8)
+        self.offset = int(offset)
+        self.length = int(len(self.offsets) - 1 - offset if length is None else length)
+        if self.offset < 0 or self.length < 0 or self.offset + self.length + 1 > len(self.offsets):
+            raise _ffi.PlHipError(6, "offset/length outside the offsets buffer")
+        self.validity = None
+        if validity is not None:
+            v = np.asarray(validity)
+            if v.dtype == np.bool_:
+                if len(v) != len(self.offsets) - 1:
+                    raise _ffi.PlHipError(2, "validity mask length differs from the column's")
+                v = pack_validity(v)
+            self.validity = np.ascontiguousarray(v, dtype=np.uint8)
+
+    @classmethod
+    def from_list(cls, name: str, values) -> "Utf8Column":
+        enc = [b"" if v is None else (v if isinstance(v, bytes) else str(v).encode()) for v in values]
+        offsets = np.zeros(len(enc) + 1, np.int64)
+        np.cumsum([len(b) for b in enc], out=offsets[1:])
+        data = np.frombuffer(b"".join(enc), dtype=np.uint8)
+        mask = np.array([v is not None for v in values], dtype=bool)
+        return cls(name, offsets, data, None if mask.all() else mask)
+
+    def __len__(self) -> int:
+        return self.length
+
+    def struct(self) -> _ffi.Utf8ColumnStruct:
+        return _ffi.Utf8ColumnStruct(self.offsets.ctypes.data, self.data.ctypes.data if len(self.data) else self.offsets.ctypes.data,
+                                     None if self.validity is None else self.validity.ctypes.data, self.offset, self.length, _ffi.HOST, 0)
+
+    def valid_mask(self):
+        return None if self.validity is None else unpack_validity(self.validity, self.length, self.offset)
+
+    def to_list(self) -> list:
+        m = self.valid_mask()
+        o, d = self.offsets[self.offset:self.offset + self.length + 1], self.data.tobytes()
+        return [d[o[i]:o[i + 1]].decode() if m is None or m[i] else None for i in range(self.length)]
+
+    def __repr__(self) -> str:
+        return f"Utf8Column({self.name!r}, len={self.length})"
+
+
+class Dictionary:
+    """plhip_dictionary_t: owns the device-resident codes and strings of one encoded column."""
+
+    def __init__(self, handle):
+        self._h = handle
+        self.n_categories = int(_ffi.lib().plhip_dictionary_len(handle))
+        self._strings = None
+
+    def strings(self) -> list:
+        """The dictionary on the host: entry g is the string all rows with code g hold (None: the null group's entry)."""
+        if self._strings is None:
+            cs = _ffi.Utf8ColumnStruct()
+            _ffi.check(_ffi.lib().plhip_dictionary_strings(self._h, _ffi.HOST, C.byref(cs)))
+            g = self.n_categories
+            offs = np.ctypeslib.as_array(C.cast(cs.offsets, C.POINTER(C.c_int64)), shape=(g + 1,)).copy()
+            total = int(offs[g]) if g else 0
+            data = bytes(np.ctypeslib.as_array(C.cast(cs.data, C.POINTER(C.c_uint8)), shape=(max(total, 1),))[:total])
+            valid = unpack_validity(np.ctypeslib.as_array(C.cast(cs.validity, C.POINTER(C.c_uint8)), shape=((g + 7) // 8 + 1,)), g, 0)
+            self._strings = [data[offs[i]:offs[i + 1]].decode() if valid[i] else None for i in range(g)]
+        return self._strings
+
+    def decode(self, codes: np.ndarray, valid: np.ndarray | None = None) -> list:
+        s = self.strings()
+        return [s[int(c)] if valid is None or valid[i] else None for i, c in enumerate(codes)]
+
+    def __del__(self):
+        try:
+            if self._h:
+                _ffi.lib().plhip_dictionary_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class CodesColumn(Column):
+    """The u32 codes of an encoded string column: device memory owned by the Dictionary (kept alive through `dictionary`)."""
+
+    def __init__(self, name: str, cs: _ffi.ColumnStruct, dictionary: Dictionary):
+        self.name = name
+        self.sorted_flag = None
+        self.dictionary = dictionary
+        self.n_categories = dictionary.n_categories if dictionary.n_categories > 0 else None
+        self.location = _ffi.DEVICE
+        self.dtype = _ffi.U32
+        self._ptr, self._vptr = cs.values, cs.validity
+        self.values = None
+        self.validity = None if not cs.validity else True
+        self.offset, self.length = 0, int(cs.length)
+
+    def to_numpy(self) -> np.ndarray:
+        out = np.empty(self.length, np.uint32)
+        if self.length:
+            _ffi.check(_ffi.lib().plhip_memcpy(out.ctypes.data, _ffi.HOST, self._ptr, _ffi.DEVICE, out.nbytes))
+        return out
+
+    def valid_mask(self):
+        if not self._vptr:
+            return None
+        bits = np.empty((self.length + 7) // 8 + 1, np.uint8)
+        _ffi.check(_ffi.lib().plhip_memcpy(bits.ctypes.data, _ffi.HOST, self._vptr, _ffi.DEVICE, (self.length + 7) // 8))
+        return unpack_validity(bits, self.length, 0)
+
+
+def encode(col: Utf8Column) -> CodesColumn:
+    """plhip_utf8_encode: the column's dense codes (device-resident, `.dictionary` holds the strings)."""
+    L = _ffi.lib()
+    handle, cs = C.c_void_p(), _ffi.ColumnStruct()
+    st = col.struct()
+    _ffi.check(L.plhip_utf8_encode(C.byref(st), C.byref(handle), C.byref(cs)))
+    return CodesColumn(col.name, cs, Dictionary(handle))
+
+
+class DecodedColumn:
+    """A result key column of strings (what the frame shows for a Utf8 key)."""
+
+    def __init__(self, name: str, values: list):
+        self.name, self._values = name, values
+
+    def __len__(self) -> int:
+        return len(self._values)
+
+    def to_list(self) -> list:
+        return list(self._values)
+
+    def __repr__(self) -> str:
+        return f"DecodedColumn({self.name!r}, utf8, len={len(self._values)})"
