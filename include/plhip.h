@@ -441,6 +441,24 @@ int64_t plhip_dictionary_len(const plhip_dictionary_t *dict); /* entries (= grou
 int32_t plhip_dictionary_strings(plhip_dictionary_t *dict, int32_t location, plhip_utf8_column_t *out);
 void plhip_dictionary_free(plhip_dictionary_t *dict);
 
+/* ---- hash join on one integer key ---------------------------------------------------------------------
+ * The row-index pairs of crates/polars-ops/src/frame/join/hash_join/: hash_join_tuples_inner (single_keys_inner.rs:38-140)
+ * and hash_join_tuples_left (single_keys_left.rs:109-).  Inner: the table is built over the SHORTER relation
+ * (det_hash_prone_order!, hash_join/mod.rs:42-58: the left one when the lengths are equal), the longer one probes in row
+ * order, a probe row's matches come in ascending build-row order, and the pairs are swapped back so that left stays left --
+ * the order of the pairs is the reference's.  Left: the left relation probes; a row without a match yields
+ * (row, PLHIP_JOIN_NONE).  Keys are Option<T>: nulls join nulls (crates/polars/tests/it/core/joins.rs:574-586).  Both keys
+ * must have the same integer dtype.  The host layer gathers the payload columns with the two index arrays
+ * (DataFrame::_finish_join), which is outside this path. */
+typedef enum plhip_join_how { PLHIP_JOIN_INNER = 0, PLHIP_JOIN_LEFT = 1 } plhip_join_how_t;
+#define PLHIP_JOIN_NONE 0xFFFFFFFFu
+typedef struct plhip_join plhip_join_t;
+int32_t plhip_hash_join(const plhip_column_t *left, const plhip_column_t *right, int32_t how, int32_t out_location, plhip_join_t **out);
+int64_t plhip_join_num_rows(const plhip_join_t *j);
+/* u32 = IdxSize pairs, owned by the handle, in `*location` memory */
+int32_t plhip_join_buffers(const plhip_join_t *j, const uint32_t **left_idx, const uint32_t **right_idx, int32_t *location);
+void plhip_join_free(plhip_join_t *j);
+
 /* ---- the sharded path: one rank per GPU, the exchange inside the library ------------------------------ */
 
 /* The reference's partitioned group-by (crates/polars-lazy/src/physical_plan/executors/group_by_partitioned.rs:273-361) runs

@@ -867,3 +867,70 @@ int64_t orc_utf8_group_codes(const int64_t *offsets, const uint8_t *data, const 
   free(slot); free(hs);
   return G;
 }
+
+/* ---- hash join on one integer key (polars-ops/src/frame/join/hash_join) ------------------------------------- */
+static uint64_t jkey(const plhip_column_t *c, int64_t i, int *valid) {
+  const int64_t r = c->offset + i;
+  *valid = !c->validity || ((c->validity[r >> 3] >> (r & 7)) & 1);
+  switch (c->dtype) {
+    case PLHIP_I8: case PLHIP_U8: return ((const uint8_t *)c->values)[r];
+    case PLHIP_I16: case PLHIP_U16: return ((const uint16_t *)c->values)[r];
+    case PLHIP_I32: case PLHIP_U32: return ((const uint32_t *)c->values)[r];
+    default: return ((const uint64_t *)c->values)[r];
+  }
+}
+
+int64_t orc_hash_join(const plhip_column_t *left, const plhip_column_t *right, int how, uint32_t *out_left, uint32_t *out_right) {
+  if (left->dtype != right->dtype || left->dtype == PLHIP_F32 || left->dtype == PLHIP_F64) return -1;
+  /* the shorter relation builds (mod.rs:42-58: `left_first = self.len() > other.len()`); left join: the right one */
+  const int swapped = how == 0 && !(left->length > right->length);
+  const plhip_column_t *probe = swapped ? right : left, *build = swapped ? left : right;
+  const int64_t nb = build->length, np = probe->length;
+  /* build_tables (single_keys.rs:3-57): key -> Vec<idx>, rows pushed in ascending order.  Chained: head[slot] -> first row,
+   * next[row] -> the next row with the same key; a separate chain for None. */
+  uint64_t cap = 16;
+  while (cap < (uint64_t)nb * 2 + 2) cap <<= 1;
+  int64_t *head = (int64_t *)malloc(cap * sizeof(int64_t)), *tail = (int64_t *)malloc(cap * sizeof(int64_t));
+  int64_t *next = (int64_t *)malloc((nb > 0 ? nb : 1) * sizeof(int64_t));
+  if (!head || !tail || !next) { free(head); free(tail); free(next); return -1; }
+  for (uint64_t i = 0; i < cap; i++) head[i] = -1;
+  int64_t null_head = -1, null_tail = -1;
+  for (int64_t i = 0; i < nb; i++) {
+    int v;
+    const uint64_t k = jkey(build, i, &v);
+    next[i] = -1;
+    if (!v) { if (null_head < 0) null_head = i; else next[null_tail] = i; null_tail = i; continue; }
+    uint64_t s = orc_folded_multiply(k, 0x9E3779B97F4A7C15ull) & (cap - 1);
+    for (;;) {
+      if (head[s] < 0) { head[s] = tail[s] = i; break; }
+      int hv;
+      if (jkey(build, head[s], &hv) == k) { next[tail[s]] = i; tail[s] = i; break; }
+      s = (s + 1) & (cap - 1);
+    }
+  }
+  /* probe_inner (single_keys_inner.rs:8-36) / the left join's probe: rows in order, matches in the table's order */
+  int64_t m = 0;
+  for (int64_t i = 0; i < np; i++) {
+    int v;
+    const uint64_t k = jkey(probe, i, &v);
+    int64_t row = -1;
+    if (!v) row = null_head;
+    else {
+      uint64_t s = orc_folded_multiply(k, 0x9E3779B97F4A7C15ull) & (cap - 1);
+      for (; head[s] >= 0; s = (s + 1) & (cap - 1)) {
+        int hv;
+        if (jkey(build, head[s], &hv) == k) { row = head[s]; break; }
+      }
+    }
+    if (row < 0) {
+      if (how == 1) { if (out_left) { out_left[m] = (uint32_t)i; out_right[m] = 0xFFFFFFFFu; } m++; }
+      continue;
+    }
+    for (; row >= 0; row = next[row]) {
+      if (out_left) { (swapped ? out_right : out_left)[m] = (uint32_t)i; (swapped ? out_left : out_right)[m] = (uint32_t)row; }
+      m++;
+    }
+  }
+  free(head); free(tail); free(next);
+  return m;
+}

@@ -76,6 +76,13 @@ int orc_sink_group_by(const plhip_column_t *key, const plhip_column_t *values, i
 int64_t orc_utf8_group_codes(const int64_t *offsets, const uint8_t *data, const uint8_t *validity, int64_t offset, int64_t n,
                              uint32_t *codes, uint32_t *first);
 
+/* hash_join_tuples_inner (polars-ops/src/frame/join/hash_join/single_keys_inner.rs:38-140) and hash_join_tuples_left
+ * (single_keys_left.rs:109-) for one integer key column pair of the same dtype: build_tables over the shorter relation
+ * (inner; det_hash_prone_order!, hash_join/mod.rs:42-58) or over the right one (left join), key -> rows in ascending
+ * order; the other relation probes in row order.  Keys are Option<T>: null == null.  how: 0 inner, 1 left (no match:
+ * right index 0xFFFFFFFF).  Pass out_left = NULL to get the pair count only.  Returns the number of pairs, -1 on error. */
+int64_t orc_hash_join(const plhip_column_t *left, const plhip_column_t *right, int how, uint32_t *out_left, uint32_t *out_right);
+
 int orc_take_keys(const plhip_column_t *key, const orc_groups_t *g, void *out_values, uint8_t *out_valid);
 
 #ifdef __cplusplus

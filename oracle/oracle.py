@@ -51,6 +51,8 @@ def lib():
         L.orc_agg_partitioned.argtypes = [P(_ffi.ColumnStruct), C.c_int, P(_Groups), C.c_int, C.c_void_p, C.c_void_p]
         L.orc_utf8_group_codes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
         L.orc_utf8_group_codes.restype = C.c_int64
+        L.orc_hash_join.argtypes = [P(_ffi.ColumnStruct), P(_ffi.ColumnStruct), C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_hash_join.restype = C.c_int64
         L.orc_take_keys.argtypes = [P(_ffi.ColumnStruct), P(_Groups), C.c_void_p, C.c_void_p]
         L.orc_sink_group_by.argtypes = [P(_ffi.ColumnStruct), P(_ffi.ColumnStruct), C.c_int, P(C.c_int), P(C.c_int), C.c_int, C.c_int,
                                         C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, P(C.c_int64)]
@@ -333,3 +335,15 @@ def utf8_group_codes(offsets: np.ndarray, data: np.ndarray, valid: np.ndarray | 
     if g < 0:
         raise MemoryError("orc_utf8_group_codes")
     return codes[:n], first[:g]
+
+
+def hash_join(left: Column, right: Column, how: str = "inner"):
+    """orc_hash_join: (left_idx, right_idx) u32 arrays in the reference's pair order; right_idx 0xFFFFFFFF = no match (left join)."""
+    h = {"inner": 0, "left": 1}[how]
+    ls, rs = left.struct(), right.struct()
+    m = lib().orc_hash_join(C.byref(ls), C.byref(rs), h, None, None)
+    if m < 0:
+        raise ValueError("orc_hash_join: unsupported key columns")
+    li, ri = np.zeros(max(m, 1), np.uint32), np.zeros(max(m, 1), np.uint32)
+    lib().orc_hash_join(C.byref(ls), C.byref(rs), h, li.ctypes.data, ri.ctypes.data)
+    return li[:m], ri[:m]

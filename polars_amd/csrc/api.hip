@@ -23,6 +23,7 @@
 #include "fast.hpp"
 #include "kernels.hpp"
 #include "utf8.hpp"
+#include "join.hpp"
 
 // Scratch of plhip_group_by_agg_noalloc (flag block, dump headers, table dumps): a file-scope device array, so that the
 // entry point never calls hipMalloc.  Every GPU the library runs on holds its own copy until the process ends.  In host
@@ -2273,6 +2274,114 @@ int32_t plhip_dictionary_strings(plhip_dictionary_t *d, int32_t location, plhip_
 }
 
 void plhip_dictionary_free(plhip_dictionary_t *d) { delete d; }
+
+// ---------------------------------------------------------------------------------------------------------
+// hash join on one integer key (join.hpp)
+// ---------------------------------------------------------------------------------------------------------
+struct plhip_join {
+  int device = 0;
+  int64_t n = 0;
+  bool on_device = true;
+  uint32_t *left = nullptr, *right = nullptr;
+  size_t capl = 0, capr = 0;
+  ~plhip_join() {
+    if (on_device) { g_pool.put(device, left, capl); g_pool.put(device, right, capr); }
+    else { free(left); free(right); }
+  }
+};
+
+int32_t plhip_hash_join(const plhip_column_t *left, const plhip_column_t *right, int32_t how, int32_t out_location, plhip_join_t **out) {
+  if (!left || !right || !out) return fail(PLHIP_ERR_INVALID, "NULL pointer");
+  *out = nullptr;
+  if (how != PLHIP_JOIN_INNER && how != PLHIP_JOIN_LEFT) return fail(PLHIP_ERR_INVALID, "bad join kind");
+  if (out_location != PLHIP_HOST && out_location != PLHIP_DEVICE) return fail(PLHIP_ERR_INVALID, "bad output location");
+  if (left->dtype != right->dtype) return fail(PLHIP_ERR_COMPUTE, "datatypes of join keys don't match");
+  if (dt_is_float(left->dtype) || !dtype_width(left->dtype)) return fail(PLHIP_ERR_UNSUPPORTED_DTYPE, "the join key must be an integer column");
+  if (left->length > 0xFFFFFFFEll || right->length > 0xFFFFFFFEll) return fail(PLHIP_ERR_COMPUTE, "more than u32::MAX rows (IdxSize is u32)");
+  int rc = ensure_ctx();
+  if (rc) return rc;
+  Ctx &c = g_ctx;
+  Staging st;
+  DevCol dl, dr;
+  if ((rc = stage_column(*left, dl, st, c.stream)) || (rc = stage_column(*right, dr, st, c.stream))) return rc;
+  // the shorter relation builds (hash_join/mod.rs:42-58); a left join always probes with the left one
+  const bool swapped = how == PLHIP_JOIN_INNER && !(left->length > right->length);
+  const DevCol &dp = swapped ? dr : dl, &db = swapped ? dl : dr;
+  const uint32_t w = (uint32_t)dtype_width(left->dtype);
+  const int64_t n = dp.length, nb = db.length;
+  // ---- the build side's key -> rows map: the group-by seam's CSR (lists ascending) ------------------------------------
+  struct GroupsGuard { plhip_groups_t *p = nullptr; ~GroupsGuard() { delete p; } } gr;
+  const uint32_t *first = nullptr, *offsets = nullptr, *indices = nullptr;
+  uint64_t G = 0;
+  if (nb > 0) {
+    plhip_column_t bc{};
+    bc.values = db.values - (size_t)db.boff * w; bc.validity = db.validity; bc.offset = db.boff; bc.length = nb; // (values + offset * w = element 0)
+    bc.dtype = left->dtype; bc.location = PLHIP_DEVICE;
+    if ((rc = plhip_group_tuples(&bc, 1, 0, PLHIP_DEVICE, &gr.p))) return rc;
+    int32_t loc = 0;
+    if ((rc = plhip_groups_buffers(gr.p, &first, &offsets, &indices, &loc))) return rc;
+    G = (uint64_t)gr.p->n_groups;
+  }
+  const uint64_t cap = next_pow2(std::max<uint64_t>(2 * G, 1024));
+  HIP_TRY(c.str_b.reserve(cap * 16 + 512));
+  JoinTable T{};
+  T.used = (uint32_t *)c.str_b.p; T.keys = (uint64_t *)((uint8_t *)c.str_b.p + cap * 4); T.vals = (uint32_t *)((uint8_t *)c.str_b.p + cap * 12);
+  T.g_null = (uint32_t *)((uint8_t *)c.str_b.p + cap * 16); T.mask = cap - 1;
+  HIP_TRY(hipMemsetAsync(T.used, 0, cap * 4, c.stream));
+  HIP_TRY(hipMemsetAsync(T.g_null, 0xFF, 256, c.stream));
+  JoinKey KB{db.values, db.validity, db.boff, nb, w, 0}, KP{dp.values, dp.validity, dp.boff, n, w, 0};
+  launch_join_build(KB, first, (uint32_t)G, T, c.stream);
+  HIP_TRY(hipGetLastError());
+  // ---- probe: count, scan, fill -----------------------------------------------------------------------------------------
+  const size_t g_bytes = ((size_t)n * 4 + 255) & ~(size_t)255, c_bytes = ((size_t)(n + 1) * 8 + 255) & ~(size_t)255, tb = join_scan_temp_bytes(n);
+  HIP_TRY(c.str_a.reserve(g_bytes + 2 * c_bytes + tb + 256));
+  uint32_t *gid = (uint32_t *)c.str_a.p;
+  uint64_t *cnt = (uint64_t *)((uint8_t *)c.str_a.p + g_bytes), *pos = (uint64_t *)((uint8_t *)c.str_a.p + g_bytes + c_bytes);
+  void *tmp = (uint8_t *)c.str_a.p + g_bytes + 2 * c_bytes;
+  launch_join_count(KP, T, offsets, how == PLHIP_JOIN_LEFT, gid, cnt, c.stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(join_scan(tmp, tb, cnt, pos, n, c.stream));
+  HIP_TRY(hipMemcpyAsync(c.host_flags, pos + n, 8, hipMemcpyDeviceToHost, c.stream));
+  HIP_TRY(hipStreamSynchronize(c.stream));
+  uint64_t total = 0;
+  memcpy(&total, c.host_flags, 8);
+  if (total > 0xFFFFFFFEull) return fail(PLHIP_ERR_COMPUTE, "the join yields more than u32::MAX rows (IdxSize is u32)");
+  std::unique_ptr<plhip_join> J(new (std::nothrow) plhip_join());
+  if (!J) return fail(PLHIP_ERR_OOM, "host allocation failed");
+  J->device = c.device; J->n = (int64_t)total;
+  uint32_t *out_probe = nullptr, *out_build = nullptr;
+  size_t cp = 0, cb = 0;
+  HIP_TRY(g_pool.get(c.device, std::max<size_t>((size_t)total * 4, 8), (void **)&out_probe, &cp));
+  (swapped ? J->right : J->left) = out_probe; (swapped ? J->capr : J->capl) = cp;
+  HIP_TRY(g_pool.get(c.device, std::max<size_t>((size_t)total * 4, 8), (void **)&out_build, &cb));
+  (swapped ? J->left : J->right) = out_build; (swapped ? J->capl : J->capr) = cb;
+  launch_join_fill(n, gid, pos, offsets, indices, out_probe, out_build, c.stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c.stream));
+  c.strategy = "hash_join";
+  if (out_location == PLHIP_HOST) {
+    uint32_t *hl = (uint32_t *)malloc(std::max<size_t>((size_t)total * 4, 8)), *hr = (uint32_t *)malloc(std::max<size_t>((size_t)total * 4, 8));
+    hipError_t e = (hl && hr) ? hipSuccess : hipErrorOutOfMemory;
+    if (e == hipSuccess && total) e = hipMemcpy(hl, J->left, (size_t)total * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && total) e = hipMemcpy(hr, J->right, (size_t)total * 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { free(hl); free(hr); return fail_hip(e, "join result copy"); }
+    g_pool.put(c.device, J->left, J->capl); g_pool.put(c.device, J->right, J->capr);
+    J->left = hl; J->right = hr; J->capl = J->capr = 0; J->on_device = false;
+  }
+  *out = J.release();
+  return PLHIP_OK;
+}
+
+int64_t plhip_join_num_rows(const plhip_join_t *j) { return j ? j->n : -1; }
+
+int32_t plhip_join_buffers(const plhip_join_t *j, const uint32_t **left_idx, const uint32_t **right_idx, int32_t *location) {
+  if (!j || !left_idx || !right_idx) return fail(PLHIP_ERR_INVALID, "NULL pointer");
+  *left_idx = j->left; *right_idx = j->right;
+  if (location) *location = j->on_device ? PLHIP_DEVICE : PLHIP_HOST;
+  return PLHIP_OK;
+}
+
+void plhip_join_free(plhip_join_t *j) { delete j; }
 
 int32_t plhip_group_by_agg_noalloc(const plhip_column_t *keys, int32_t n_keys, const plhip_column_t *values, int32_t n_values,
                                    const plhip_agg_t *aggs, int32_t n_aggs, uint32_t flags, int64_t n_groups_hint,

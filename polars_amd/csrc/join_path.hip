@@ -1,0 +1,98 @@
+// join_path.hip — kernels of the single-key hash join (join.hpp has the design and the reference lines).
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <rocprim/rocprim.hpp>
+
+#include "join.hpp"
+
+namespace {
+
+#define JOIN_BLOCK 256
+
+__device__ __forceinline__ uint64_t jk_load(const JoinKey &k, int64_t i) {
+  switch (k.width) {
+    case 1: return k.values[i];
+    case 2: return ((const uint16_t *)k.values)[i];
+    case 4: return ((const uint32_t *)k.values)[i];
+    default: return ((const uint64_t *)k.values)[i];
+  }
+}
+
+__device__ __forceinline__ bool jk_valid(const JoinKey &k, int64_t i) {
+  if (!k.validity) return true;
+  const int64_t b = k.boff + i;
+  return (k.validity[b >> 3] >> (b & 7)) & 1u;
+}
+
+__device__ __forceinline__ uint64_t jk_slot(uint64_t key, uint64_t mask) {
+  const uint64_t m = key * 0x9E3779B97F4A7C15ull;
+  return (m ^ (m >> 32)) & mask;
+}
+
+__global__ void __launch_bounds__(JOIN_BLOCK) k_join_build(JoinKey b, const uint32_t *first, uint32_t G, JoinTable t) {
+  const uint32_t g = blockIdx.x * JOIN_BLOCK + threadIdx.x;
+  if (g >= G) return;
+  const int64_t f = first[g];
+  if (!jk_valid(b, f)) { *t.g_null = g; return; } // (one group at most)
+  const uint64_t key = jk_load(b, f);
+  for (uint64_t s = jk_slot(key, t.mask), tries = 0; tries <= t.mask; s = (s + 1) & t.mask, tries++)
+    if (atomicCAS(&t.used[s], 0u, 1u) == 0u) { t.keys[s] = key; t.vals[s] = g; return; } // the groups' keys are distinct: nothing to compare
+}
+
+__global__ void __launch_bounds__(JOIN_BLOCK) k_join_count(JoinKey p, JoinTable t, const uint32_t *offsets, int left_join, uint32_t *gid, uint64_t *cnt) {
+  const int64_t i = (int64_t)blockIdx.x * JOIN_BLOCK + threadIdx.x;
+  if (i > p.n) return;
+  if (i == p.n) { cnt[i] = 0; return; }
+  uint32_t g = JOIN_NONE;
+  if (!jk_valid(p, i)) g = *t.g_null; // Option<T>: None == None (joins.rs:574-586)
+  else {
+    const uint64_t key = jk_load(p, i);
+    for (uint64_t s = jk_slot(key, t.mask), tries = 0; tries <= t.mask; s = (s + 1) & t.mask, tries++) {
+      if (!t.used[s]) break;
+      if (t.keys[s] == key) { g = t.vals[s]; break; }
+    }
+  }
+  gid[i] = g;
+  cnt[i] = g != JOIN_NONE ? (uint64_t)(offsets[g + 1] - offsets[g]) : (left_join ? 1ull : 0ull);
+}
+
+__global__ void __launch_bounds__(JOIN_BLOCK) k_join_fill(int64_t n, const uint32_t *gid, const uint64_t *pos, const uint32_t *offsets,
+                                                          const uint32_t *indices, uint32_t *out_probe, uint32_t *out_build) {
+  const int64_t i = (int64_t)blockIdx.x * JOIN_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t g = gid[i];
+  const uint64_t p0 = pos[i];
+  if (g == JOIN_NONE) {
+    if (pos[i + 1] > p0) { out_probe[p0] = (uint32_t)i; out_build[p0] = JOIN_NONE; } // left join: (row, None)
+    return;
+  }
+  const uint32_t o0 = offsets[g], o1 = offsets[g + 1];
+  for (uint32_t j = o0; j < o1; j++) { out_probe[p0 + (j - o0)] = (uint32_t)i; out_build[p0 + (j - o0)] = indices[j]; }
+}
+
+} // namespace
+
+void launch_join_build(const JoinKey &build, const uint32_t *first, uint32_t G, const JoinTable &t, hipStream_t s) {
+  if (!G) return;
+  hipLaunchKernelGGL(k_join_build, dim3((G + JOIN_BLOCK - 1) / JOIN_BLOCK), dim3(JOIN_BLOCK), 0, s, build, first, G, t);
+}
+
+void launch_join_count(const JoinKey &probe, const JoinTable &t, const uint32_t *offsets, int left_join, uint32_t *gid, uint64_t *cnt, hipStream_t s) {
+  hipLaunchKernelGGL(k_join_count, dim3((unsigned)((probe.n + 1 + JOIN_BLOCK - 1) / JOIN_BLOCK)), dim3(JOIN_BLOCK), 0, s, probe, t, offsets, left_join, gid, cnt);
+}
+
+size_t join_scan_temp_bytes(int64_t n) {
+  size_t b = 0;
+  if (rocprim::exclusive_scan(nullptr, b, (const uint64_t *)nullptr, (uint64_t *)nullptr, (uint64_t)0, (size_t)n + 1, rocprim::plus<uint64_t>()) != hipSuccess) return 0;
+  return b + 256;
+}
+
+hipError_t join_scan(void *temp, size_t temp_bytes, const uint64_t *cnt, uint64_t *pos, int64_t n, hipStream_t s) {
+  return rocprim::exclusive_scan(temp, temp_bytes, cnt, pos, (uint64_t)0, (size_t)n + 1, rocprim::plus<uint64_t>(), s);
+}
+
+void launch_join_fill(int64_t n, const uint32_t *gid, const uint64_t *pos, const uint32_t *offsets, const uint32_t *indices, uint32_t *out_probe,
+                      uint32_t *out_build, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_join_fill, dim3((unsigned)((n + JOIN_BLOCK - 1) / JOIN_BLOCK)), dim3(JOIN_BLOCK), 0, s, n, gid, pos, offsets, indices, out_probe, out_build);
+}

@@ -157,6 +157,26 @@ class DataFrame:
     def group_by(self, *by, maintain_order: bool = False) -> "GroupBy":
         return GroupBy(self, _flatten(by), maintain_order)
 
+    def join(self, other: "DataFrame", on: str | None = None, how: str = "inner", *, left_on: str | None = None,
+             right_on: str | None = None, suffix: str = "_right") -> "DataFrame":
+        """DataFrame.join on one integer key, `how` = 'inner' | 'left' (py-polars/polars/dataframe/frame.py:5856): the index
+        pairs come from plhip_hash_join in the reference's order; the payload gather (`_finish_join`: left columns, then the
+        right ones without the key, clashing names suffixed) runs on the host."""
+        from .join import join_indices, take
+
+        if on is not None:
+            left_on = right_on = on
+        if left_on is None or right_on is None:
+            raise ValueError("you should pass the column to join on as an argument")
+        li, ri = join_indices(self.get_column(left_on), other.get_column(right_on), how)
+        out = [take(c, li, n) for n, c in self._cols.items()]
+        taken = set(self._cols)
+        for n, c in other._cols.items():
+            if n == right_on:
+                continue
+            out.append(take(c, ri, n + suffix if n in taken else n))
+        return DataFrame(out)
+
     def group_by_stable(self, *by) -> "GroupBy":
         """DataFrame::group_by_stable (group_by/mod.rs:122-129)."""
         return GroupBy(self, _flatten(by), True)

@@ -1,0 +1,61 @@
+"""Hash join on one integer key: the row-index pairs (plhip_hash_join, include/plhip.h), and the gather a host layer does
+with them (DataFrame::_finish_join in the reference; numpy here -- the payload gather is outside the accelerated path).
+
+Mirrors crates/polars-ops/src/frame/join/hash_join/single_keys_inner.rs / single_keys_left.rs: pair order, build side
+and null == null semantics are the reference's."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from .column import Column
+
+NONE = 0xFFFFFFFF
+
+
+def join_indices(left: Column, right: Column, how: str = "inner") -> tuple[np.ndarray, np.ndarray]:
+    """(left_idx, right_idx) as host u32 arrays; right_idx == NONE where a left-join row has no match."""
+    L = _ffi.lib()
+    h = {"inner": 0, "left": 1}.get(how)
+    if h is None:
+        raise _ffi.PlHipError(6, f"join kind {how!r} is not on the accelerated path (inner, left)")
+    for c in (left, right):
+        if c.location == _ffi.DEVICE and type(c.values).__module__.startswith("torch"):
+            import torch
+
+            torch.cuda.current_stream(c.values.device).synchronize()
+            break
+    handle = C.c_void_p()
+    ls, rs = left.struct(), right.struct()
+    _ffi.check(L.plhip_hash_join(C.byref(ls), C.byref(rs), h, _ffi.HOST, C.byref(handle)))
+    try:
+        m = L.plhip_join_num_rows(handle)
+        lp, rp, loc = C.c_void_p(), C.c_void_p(), C.c_int32()
+        _ffi.check(L.plhip_join_buffers(handle, C.byref(lp), C.byref(rp), C.byref(loc)))
+        if m == 0:
+            return np.zeros(0, np.uint32), np.zeros(0, np.uint32)
+        li = np.ctypeslib.as_array(C.cast(lp, C.POINTER(C.c_uint32)), shape=(m,)).copy()
+        ri = np.ctypeslib.as_array(C.cast(rp, C.POINTER(C.c_uint32)), shape=(m,)).copy()
+        return li, ri
+    finally:
+        L.plhip_join_free(handle)
+
+
+def take(col, idx: np.ndarray, name: str | None = None):
+    """Gathers a column's rows; idx == NONE yields null (the right side of a left join)."""
+    name = name or col.name
+    miss = idx == NONE
+    safe = np.where(miss, 0, idx).astype(np.int64)
+    if type(col).__name__ in ("Utf8Column", "DecodedColumn"):
+        from .strings import DecodedColumn
+
+        vals = col.to_list()
+        return DecodedColumn(name, [None if m else vals[i] for i, m in zip(safe.tolist(), miss.tolist())])
+    if len(col) == 0:
+        return Column(name, np.zeros(len(idx), _ffi.code_np_dtype(col.dtype)), ~miss if len(idx) else None)
+    v = col.to_numpy()[safe]
+    m = col.valid_mask()
+    valid = ~miss if m is None else (m[safe] & ~miss)
+    return Column(name, v, None if valid.all() else valid)

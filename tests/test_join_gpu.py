@@ -1,0 +1,74 @@
+"""Hash join on one integer key (plhip_hash_join) against the oracle: the same pairs in the same order (the
+reference's order is deterministic: probe rows in order, matches in ascending build-row order), every integer dtype, nulls
+that join nulls, duplicate-heavy and unique keys, empty sides, device-resident keys; and the reference's own known answers."""
+import numpy as np
+import pytest
+
+import polars_amd as pa
+from polars_amd import _ffi
+from polars_amd.column import Column
+from polars_amd.join import join_indices
+from tests.test_oracle_join import NP, check_case, gold_cases
+
+pytestmark = pytest.mark.gpu
+
+
+def test_reference_known_answers_on_the_gpu():
+    for case in gold_cases():
+        for dt in case["dtypes"]:
+            check_case(case, dt, join_indices)
+
+
+@pytest.mark.parametrize("how", ["inner", "left"])
+@pytest.mark.parametrize("dtype", [np.int8, np.uint8, np.int16, np.uint16, np.int32, np.uint32, np.int64, np.uint64])
+def test_join_matches_the_oracle_pair_for_pair(oracle, how, dtype):
+    rng = np.random.default_rng(np.dtype(dtype).itemsize * 7 + (how == "left"))
+    info = np.iinfo(dtype)
+    for nl, nr, span, nulls in ((0, 9, 5, 0.0), (9, 0, 5, 0.0), (1000, 1000, 50, 0.1), (50_000, 20_000, 30_000, 0.02), (20_000, 50_000, 100, 0.0)):
+        lo = max(int(info.min), -span)
+        hi = min(int(info.max), span)
+        lk = rng.integers(lo, hi + 1, nl).astype(dtype)
+        rk = rng.integers(lo, hi + 1, nr).astype(dtype)
+        if nl > 10:
+            lk[:3] = [info.min, info.max, 0]  # the extremes are ordinary keys (u64 max is not a sentinel)
+            rk[-3:] = [info.max, info.min, 0]
+        lm = rng.random(nl) >= nulls if nulls else None
+        rm = rng.random(nr) >= nulls if nulls else None
+        left, right = Column("k", lk, lm), Column("k", rk, rm)
+        gl, gr = join_indices(left, right, how)
+        wl, wr = oracle.hash_join(left, right, how)
+        assert len(gl) == len(wl), (how, dtype, nl, nr)
+        assert np.array_equal(gl, wl) and np.array_equal(gr, wr), (how, dtype, nl, nr)
+
+
+def test_join_large_and_device_resident(oracle):
+    import torch
+
+    rng = np.random.default_rng(9)
+    nl, nr = 3_000_000, 1_000_000
+    lk = rng.integers(0, 1_500_000, nl).astype(np.int64)
+    rk = rng.permutation(2_000_000)[:nr].astype(np.int64)  # unique build keys: at most one match per probe row
+    dev = torch.device("cuda:0")
+    left, right = Column("k", torch.from_numpy(lk).to(dev)), Column("k", torch.from_numpy(rk).to(dev))
+    for how in ("inner", "left"):
+        gl, gr = join_indices(left, right, how)
+        wl, wr = oracle.hash_join(Column("k", lk), Column("k", rk), how)
+        assert np.array_equal(gl, wl) and np.array_equal(gr, wr), how
+    assert _ffi.lib().plhip_last_strategy() == b"hash_join"
+
+
+def test_join_errors():
+    with pytest.raises(_ffi.PlHipError):
+        join_indices(Column("k", np.zeros(3, np.int32)), Column("k", np.zeros(3, np.int64)))
+    with pytest.raises(_ffi.PlHipError):
+        join_indices(Column("k", np.zeros(3, np.float64)), Column("k", np.zeros(3, np.float64)))
+
+
+def test_frame_join():
+    """DataFrame.join end to end (payload gather on the host), the reference's docstring frame with integer keys."""
+    df = pa.DataFrame({"foo": np.array([1, 2, 3], np.int64), "bar": np.array([6.0, 7.0, 8.0]), "ham": np.array([10, 20, 30], np.int32)})
+    other = pa.DataFrame({"apple": ["x", "y", "z"], "ham": np.array([10, 20, 40], np.int32)})
+    out = df.join(other, on="ham")
+    assert out.to_dict() == {"foo": [1, 2], "bar": [6.0, 7.0], "ham": [10, 20], "apple": ["x", "y"]}
+    out = df.join(other, on="ham", how="left")
+    assert out.to_dict() == {"foo": [1, 2, 3], "bar": [6.0, 7.0, 8.0], "ham": [10, 20, 30], "apple": ["x", "y", None]}
