@@ -63,7 +63,13 @@ typedef enum plhip_dtype {
   PLHIP_U32 = 6,
   PLHIP_U64 = 7,
   PLHIP_F32 = 8,
-  PLHIP_F64 = 9
+  PLHIP_F64 = 9,
+  /* Arrow boolean array: `values` is an LSB-first bitmap (one bit per row, `offset` in bits).  Accepted by plhip_group_by_agg /
+   * plhip_group_by_agg_opts as a key and as a value column, with the reference's casts: a Boolean key groups as UInt8
+   * (into_groups.rs:215-230) and comes back as a Boolean key column; sum(bool) is the u32 sum of the column cast to IdxSize
+   * (aggregations/boolean.rs:107-109), mean(bool) the f64 mean of its cast (aggregations/dispatch.rs:164), min / max stay
+   * Boolean (boolean.rs:20-106), count is a count.  Other entry points reject the dtype. */
+  PLHIP_BOOL = 10
 } plhip_dtype_t;
 
 typedef enum plhip_location { PLHIP_HOST = 0, PLHIP_DEVICE = 1 } plhip_location_t;

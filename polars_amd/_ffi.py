@@ -13,6 +13,7 @@ import numpy as np
 
 # plhip_dtype_t
 I8, I16, I32, I64, U8, U16, U32, U64, F32, F64 = range(10)
+BOOL = 10  # Arrow boolean array: the values buffer is a bitmap (group_by_agg / group_by_agg_opts only)
 _NP_TO_CODE = {
     np.dtype(np.int8): I8, np.dtype(np.int16): I16, np.dtype(np.int32): I32, np.dtype(np.int64): I64,
     np.dtype(np.uint8): U8, np.dtype(np.uint16): U16, np.dtype(np.uint32): U32, np.dtype(np.uint64): U64,
@@ -20,7 +21,7 @@ _NP_TO_CODE = {
 }
 _CODE_TO_NP = {v: k for k, v in _NP_TO_CODE.items()}
 DTYPE_NAMES = {I8: "i8", I16: "i16", I32: "i32", I64: "i64", U8: "u8", U16: "u16", U32: "u32", U64: "u64",
-               F32: "f32", F64: "f64"}
+               F32: "f32", F64: "f64", BOOL: "bool"}
 
 HOST, DEVICE = 0, 1
 
@@ -102,7 +103,7 @@ def np_dtype_code(dt) -> int:
 
 
 def code_np_dtype(code: int):
-    return _CODE_TO_NP[code]
+    return np.dtype(np.bool_) if code == BOOL else _CODE_TO_NP[code]
 
 
 class ChunkedColumnStruct(C.Structure):

@@ -62,17 +62,20 @@ class Column:
             self.location = _ffi.DEVICE if values.is_cuda else _ffi.HOST
             self.dtype = _torch_code(values) if dtype is None else dtype
             self._ptr = values.data_ptr()
-            buf_len = values.numel()
+            buf_len = values.numel() * (8 if self.dtype == _ffi.BOOL else 1)  # (a boolean column's buffer is a bitmap: uint8 tensor, dtype=BOOL)
         else:
             values = np.ascontiguousarray(values)
             if values.ndim != 1:
                 raise _ffi.PlHipError(6, "column buffers must be 1-D")
-            if values.dtype == np.bool_:
-                raise _ffi.PlHipError(4, "boolean columns: cast to u8/u32 first")
             self.location = _ffi.HOST
-            self.dtype = _ffi.np_dtype_code(values.dtype) if dtype is None else dtype
-            self._ptr = values.ctypes.data
             buf_len = values.shape[0]
+            if values.dtype == np.bool_:  # an Arrow boolean array: the values buffer is a bitmap (PLHIP_BOOL)
+                self._bool = values
+                values = np.concatenate([np.packbits(values, bitorder="little"), np.zeros(8, np.uint8)])
+                self.dtype = _ffi.BOOL
+            else:
+                self.dtype = _ffi.np_dtype_code(values.dtype) if dtype is None else dtype
+            self._ptr = values.ctypes.data
         self.values = values
         self.offset = int(offset)
         self.length = int(buf_len - offset if length is None else length)
@@ -129,6 +132,8 @@ class Column:
 
     def to_numpy(self) -> np.ndarray:
         """Values of the logical slice as a host numpy array (nulls keep whatever the buffer holds)."""
+        if self.dtype == _ffi.BOOL:
+            return self._bool[self.offset:self.offset + self.length]
         v = self.values
         if _is_torch(v):
             v = v.cpu().numpy()

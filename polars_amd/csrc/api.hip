@@ -808,7 +808,7 @@ int finish_result(plhip_result *R, uint64_t G, uint32_t flags, plhip_result_t **
     for (auto &col : R->cols) {
       ResultCol h;
       h.dtype = col.dtype;
-      rc = copy_out(col.values, (size_t)G * dtype_width(col.dtype), &h.values);
+      rc = copy_out(col.values, col.dtype == PLHIP_BOOL ? (size_t)((G + 63) / 64) * 8 : (size_t)G * dtype_width(col.dtype), &h.values);
       if (!rc && col.validity) rc = copy_out(col.validity, (G / 64 + 1) * 8, (void **)&h.validity);
       H->cols.push_back(h);
       if (rc) { delete R; delete H; return rc; }
@@ -2011,10 +2011,91 @@ int32_t plhip_group_by_agg(const plhip_column_t *keys, int32_t n_keys, const plh
   return plhip_group_by_agg_opts(keys, n_keys, values, n_values, aggs, n_aggs, flags, nullptr, out);
 }
 
+namespace {
+// Boolean columns (PLHIP_BOOL): lowered at the boundary with the reference's own casts -- a key to UInt8 (into_groups.rs:215-230), a
+// value column to IdxSize = u32 (boolean.rs:107-109 for sum; the f64 mean of the cast is dispatch.rs:164's) -- and the Boolean outputs
+// (keys, min, max) packed back into bitmaps.
+int bool_group_by(const plhip_column_t *keys, int32_t n_keys, const plhip_column_t *values, int32_t n_values, const plhip_agg_t *aggs,
+                  int32_t n_aggs, uint32_t flags, const plhip_options_t *opts, plhip_result_t **out) {
+  if (flags & PLHIP_FLAG_PARTIAL) return fail(PLHIP_ERR_UNSUPPORTED_DTYPE, "Boolean columns have no partial (mergeable) form");
+  if (n_keys < 1 || n_keys > PLHIP_MAX_KEYS || n_values < 0 || n_values > PLHIP_MAX_VALS) return fail(PLHIP_ERR_INVALID, "bad column counts");
+  int rc = ensure_ctx();
+  if (rc) return rc;
+  Ctx &c = g_ctx;
+  Staging st;
+  std::vector<plhip_column_t> lk(keys, keys + n_keys), lv(values, values + n_values);
+  auto lower = [&](plhip_column_t &col, uint32_t w, int dt) -> int {
+    if (col.length < 0 || col.offset < 0) return fail(PLHIP_ERR_INVALID, "negative column offset/length");
+    if (col.length > 0 && !col.values) return fail(PLHIP_ERR_INVALID, "column values pointer is NULL");
+    const int64_t n = col.length, b0 = col.offset >> 3, b1 = (col.offset + n + 7) >> 3;
+    const uint8_t *bits = (const uint8_t *)col.values, *valid = col.validity;
+    int64_t boff = col.offset;
+    if (col.location == PLHIP_HOST) { // bitmaps travel as bytes; the bit offset inside the first byte stays
+      void *db = nullptr;
+      HIP_TRY(hipMalloc(&db, (size_t)(b1 - b0) + 8)); st.owned.push_back(db);
+      if (b1 > b0) HIP_TRY(hipMemcpyAsync(db, bits + b0, (size_t)(b1 - b0), hipMemcpyHostToDevice, c.stream));
+      bits = (const uint8_t *)db; boff = col.offset & 7;
+      if (valid) {
+        void *dvb = nullptr;
+        HIP_TRY(hipMalloc(&dvb, (size_t)(b1 - b0) + 8)); st.owned.push_back(dvb);
+        if (b1 > b0) HIP_TRY(hipMemcpyAsync(dvb, valid + b0, (size_t)(b1 - b0), hipMemcpyHostToDevice, c.stream));
+        valid = (const uint8_t *)dvb;
+      }
+    } else if (col.location != PLHIP_DEVICE) return fail(PLHIP_ERR_INVALID, "bad column location");
+    void *vals = nullptr;
+    HIP_TRY(hipMalloc(&vals, n > 0 ? (size_t)n * w : 8)); st.owned.push_back(vals);
+    launch_unpack_bool(bits, boff, n, vals, w, c.stream);
+    HIP_TRY(hipGetLastError());
+    // one Arrow offset serves values and validity: row 0 of the unpacked column must sit `boff` elements into `values`
+    col.values = (const void *)((uintptr_t)vals - (uintptr_t)boff * w);
+    col.validity = valid; col.offset = boff; col.dtype = dt; col.location = PLHIP_DEVICE;
+    return PLHIP_OK;
+  };
+  std::vector<char> bool_out;
+  for (int i = 0; i < n_keys; i++) {
+    const bool b = keys[i].dtype == PLHIP_BOOL;
+    bool_out.push_back(b);
+    if (b && (rc = lower(lk[i], 1, PLHIP_U8))) return rc;
+  }
+  for (int i = 0; i < n_values; i++)
+    if (values[i].dtype == PLHIP_BOOL && (rc = lower(lv[i], 4, PLHIP_U32))) return rc;
+  for (int i = 0; i < n_aggs; i++) {
+    const bool on_bool = aggs[i].kind != PLHIP_AGG_COUNT && aggs[i].column >= 0 && aggs[i].column < n_values && values[aggs[i].column].dtype == PLHIP_BOOL;
+    bool_out.push_back(on_bool && (aggs[i].kind == PLHIP_AGG_MIN || aggs[i].kind == PLHIP_AGG_MAX));
+  }
+  plhip_result_t *R = nullptr;
+  if ((rc = group_by_agg_impl(lk.data(), n_keys, lv.data(), n_values, aggs, n_aggs, flags | PLHIP_FLAG_OUTPUT_DEVICE, opts, &R))) return rc;
+  std::unique_ptr<plhip_result> Rg(R);
+  const int64_t G = R->n_rows;
+  if (R->cols.size() != bool_out.size()) return fail(PLHIP_ERR_COMPUTE, "the result frame does not match the query");
+  for (size_t i = 0; i < R->cols.size(); i++) {
+    if (!bool_out[i]) continue;
+    ResultCol &col = R->cols[i];
+    const uint32_t w = (uint32_t)dtype_width(col.dtype);
+    if (w != 1 && w != 4) return fail(PLHIP_ERR_COMPUTE, "a Boolean output came back with an unexpected type");
+    void *bits = nullptr;
+    size_t cap = 0;
+    HIP_TRY(g_pool.get(c.device, (size_t)((G + 63) / 64) * 8 + 8, &bits, &cap));
+    launch_pack_bool(col.values, w, G, (uint64_t *)bits, c.stream);
+    const hipError_t e = hipGetLastError() == hipSuccess ? hipStreamSynchronize(c.stream) : hipErrorLaunchFailure;
+    if (e != hipSuccess) { g_pool.put(c.device, bits, cap); return fail_hip(e, "k_pack_bool"); }
+    if (col.vcap) g_pool.put(c.device, col.values, col.vcap); else hipFree(col.values);
+    col.values = bits; col.vcap = cap; col.dtype = PLHIP_BOOL;
+  }
+  HIP_TRY(hipStreamSynchronize(c.stream));
+  return finish_result(Rg.release(), (uint64_t)G, flags, out);
+}
+} // namespace
+
 int32_t plhip_group_by_agg_opts(const plhip_column_t *keys, int32_t n_keys, const plhip_column_t *values,
                                 int32_t n_values, const plhip_agg_t *aggs, int32_t n_aggs, uint32_t flags,
                                 const plhip_options_t *opts, plhip_result_t **out) {
-  const int rc = group_by_agg_impl(keys, n_keys, values, n_values, aggs, n_aggs, flags & ~FLAG_INTERNAL_WRAP32, opts, out);
+  bool any_bool = false;
+  if (keys && n_keys > 0 && n_keys <= PLHIP_MAX_KEYS) for (int i = 0; i < n_keys; i++) any_bool |= keys[i].dtype == PLHIP_BOOL;
+  if (values && n_values > 0 && n_values <= PLHIP_MAX_VALS) for (int i = 0; i < n_values; i++) any_bool |= values[i].dtype == PLHIP_BOOL;
+  if (any_bool && out) *out = nullptr;
+  const int rc = any_bool && out ? bool_group_by(keys, n_keys, values, n_values, aggs, n_aggs, flags & ~FLAG_INTERNAL_WRAP32, opts, out)
+                                 : group_by_agg_impl(keys, n_keys, values, n_values, aggs, n_aggs, flags & ~FLAG_INTERNAL_WRAP32, opts, out);
   // slice pushdown (GroupByExec's `slice`, executors/group_by.rs:79-82; offsets as slice_offsets, utils/mod.rs:199-218)
   if (!rc && out && *out && opts && opts->struct_size >= offsetof(plhip_options_t, has_slice) + sizeof(uint32_t) && opts->has_slice) {
     plhip_result *R = *out;

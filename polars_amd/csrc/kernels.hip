@@ -378,6 +378,32 @@ __global__ void __launch_bounds__(256) k_copy_bits(uint32_t *__restrict__ dst, i
   if (hi - lo == 32) dst[w] = word;
   else if (word) atomicOr(&dst[w], word);
 }
+namespace {
+__global__ void __launch_bounds__(256) k_unpack_bool(const uint8_t *bits, int64_t bit_off, int64_t n, void *out, uint32_t width) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int64_t b = bit_off + i;
+  const uint32_t v = (bits[b >> 3] >> (b & 7)) & 1u;
+  if (width == 1) ((uint8_t *)out)[i] = (uint8_t)v; else ((uint32_t *)out)[i] = v;
+}
+__global__ void __launch_bounds__(256) k_pack_bool(const void *src, uint32_t width, int64_t n, uint64_t *dst) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; // (a wave covers 64 consecutive rows: one output word)
+  const bool v = i < n && (width == 1 ? ((const uint8_t *)src)[i] != 0 : ((const uint32_t *)src)[i] != 0u);
+  const unsigned long long m = __ballot(v);
+  if ((threadIdx.x & 63) == 0 && (i & ~63ll) < n) dst[i >> 6] = m;
+}
+} // namespace
+
+void launch_unpack_bool(const uint8_t *bits, int64_t bit_off, int64_t n, void *out, uint32_t width, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_unpack_bool, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, bits, bit_off, n, out, width);
+}
+
+void launch_pack_bool(const void *src, uint32_t width, int64_t n, uint64_t *dst, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_pack_bool, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, width, n, dst);
+}
+
 void launch_copy_bits(uint32_t *dst, int64_t dst_off, const uint8_t *src, int64_t src_off, int64_t n, hipStream_t s) {
   if (n <= 0) return;
   const int64_t words = ((dst_off + n + 31) >> 5) - (dst_off >> 5);

@@ -428,7 +428,11 @@ def _host_column(name: str, cs: _ffi.ColumnStruct) -> Column:
     dt = _ffi.code_np_dtype(cs.dtype)
     if n == 0:
         return Column(name, np.empty(0, dtype=dt))
-    vals = np.ctypeslib.as_array(C.cast(cs.values, C.POINTER(C.c_uint8)), shape=((off + n) * dt.itemsize,)).view(dt)[off:].copy()
+    if cs.dtype == _ffi.BOOL:  # a bitmap: one bit per row
+        bits = np.ctypeslib.as_array(C.cast(cs.values, C.POINTER(C.c_uint8)), shape=((off + n + 7) // 8,))
+        vals = np.unpackbits(bits, bitorder="little")[off:off + n].astype(np.bool_)
+    else:
+        vals = np.ctypeslib.as_array(C.cast(cs.values, C.POINTER(C.c_uint8)), shape=((off + n) * dt.itemsize,)).view(dt)[off:].copy()
     validity = None
     if cs.validity:
         nb = (off + n + 7) // 8

@@ -1,0 +1,76 @@
+"""Boolean columns at the ABI (PLHIP_BOOL: the values buffer is a bitmap).  The reference's casts: a Boolean key groups as
+UInt8 and stays Boolean (into_groups.rs:215-230); sum -> u32 (aggregations/boolean.rs:107-109: cast to IdxSize), mean -> f64
+(dispatch.rs:164), min / max -> Boolean (boolean.rs:20-106).  Checked against the oracle run on the cast columns, and against the
+reference's own `bool_sum: UInt32 == 1` (py-polars/tests/unit/streaming/test_streaming_group_by.py:35-105)."""
+import numpy as np
+import pytest
+
+import polars_amd as pa
+from polars_amd import _ffi
+from polars_amd.column import Column
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def test_reference_bool_sum_is_u32():
+    df = pa.DataFrame({"person_id": np.array([1, 1], np.int64), "bool": np.array([True, False])})
+    out = df.group_by("person_id").agg(pa.col("bool").sum().alias("bool_sum"), pa.col("bool").max().alias("bool_max"), pa.col("bool").mean().alias("m"))
+    assert out["bool_sum"].dtype == _ffi.U32 and out["bool_sum"].to_list() == [1]
+    assert out["bool_max"].dtype == _ffi.BOOL and out["bool_max"].to_list() == [True]
+    assert out["m"].dtype == _ffi.F64 and out["m"].to_list() == [0.5]
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 300_000])
+@pytest.mark.parametrize("offset", [0, 3])
+def test_bool_key_and_values_vs_oracle(oracle, n, offset):
+    rng = np.random.default_rng(n + offset)
+    tot = n + offset + 5
+    kb, kbm = rng.random(tot) < 0.4, rng.random(tot) >= 0.1
+    k2 = rng.integers(0, 5, tot).astype(np.int64)
+    vb, vbm = rng.random(tot) < 0.7, rng.random(tot) >= 0.2
+    w = rng.integers(-50, 50, tot).astype(np.int32)
+    sl = slice(offset, offset + n)
+    keys = [Column("kb", kb, kbm, offset=offset, length=n), Column("k2", k2, offset=offset, length=n)]
+    vals = [Column("vb", vb, vbm, offset=offset, length=n), Column("w", w, offset=offset, length=n)]
+    aggs = [(0, "sum"), (0, "mean"), (0, "min"), (0, "max"), (0, "count"), (1, "sum")]
+    df = pa.DataFrame({"kb": keys[0], "k2": keys[1], "vb": vals[0], "w": vals[1]})
+    out = df.group_by("kb", "k2").agg(pa.col("vb").sum().alias("s"), pa.col("vb").mean().alias("m"), pa.col("vb").min().alias("lo"),
+                                      pa.col("vb").max().alias("hi"), pa.col("vb").count().alias("c"), pa.col("w").sum().alias("ws"))
+    assert [out[c].dtype for c in out.columns] == [_ffi.BOOL, _ffi.I64, _ffi.U32, _ffi.F64, _ffi.BOOL, _ffi.BOOL, _ffi.U32, _ffi.I32]
+    ok = [Column("kb", kb[sl].astype(np.uint8), kbm[sl]), Column("k2", k2[sl])]
+    ov = [Column("vb", vb[sl].astype(np.uint32), vbm[sl]), Column("w", w[sl])]
+    want, _ = oracle.group_by_agg(ok, ov, aggs)
+    got = []
+    for name in out.columns:
+        c = out[name]
+        v = c.to_numpy()
+        got.append((v.astype(np.uint8 if name == "kb" else np.uint32) if c.dtype == _ffi.BOOL else v, c.valid_mask()))
+    util.assert_frames_match(got, util.oracle_to_np(want), 2, what=f"bool key + values, n={n}, offset={offset}")
+
+
+def test_bool_device_column_and_single_key(oracle):
+    import torch
+
+    rng = np.random.default_rng(8)
+    n = 2_000_000
+    kb = rng.random(n) < 0.5
+    v = np.round(rng.uniform(0, 10, n), 6)
+    bits = np.concatenate([np.packbits(kb, bitorder="little"), np.zeros(8, np.uint8)])
+    dev = torch.device("cuda:0")
+    kcol = Column("kb", torch.from_numpy(bits).to(dev), dtype=_ffi.BOOL, length=n)
+    from polars_amd.frame import _host_column, group_by_agg_raw
+
+    handle, cols = group_by_agg_raw([kcol], [Column("v", torch.from_numpy(v).to(dev))], [(0, _ffi.AGG_SUM), (-1, _ffi.AGG_COUNT)])
+    try:
+        got = [_host_column(str(i), cs) for i, cs in enumerate(cols)]
+    finally:
+        _ffi.lib().plhip_result_free(handle)
+    want, _ = oracle.group_by_agg([Column("kb", kb.astype(np.uint8))], [Column("v", v)], [(0, "sum"), (0, "count")])
+    g = [(got[0].to_numpy().astype(np.uint8), got[0].valid_mask()), (got[1].to_numpy(), got[1].valid_mask()), (got[2].to_numpy(), got[2].valid_mask())]
+    util.assert_frames_match(g, util.oracle_to_np(want), 1, what="device-resident bool key")
+
+
+def test_bool_rejected_elsewhere():
+    with pytest.raises(_ffi.PlHipError):
+        pa.DataFrame({"k": np.array([True, False, True])}).group_by("k").groups()
