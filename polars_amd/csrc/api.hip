@@ -2273,14 +2273,13 @@ int32_t plhip_utf8_encode(const plhip_utf8_column_t *col, plhip_dictionary_t **d
     if (G == 0 || G > 0x7FFFFFF0ull || groups.p->cols.size() != 2 || groups.p->cols[1].dtype != PLHIP_U32)
       return fail(PLHIP_ERR_COMPUTE, "the group-by over the string hashes came back malformed");
     const uint64_t cap = next_pow2(std::max<uint64_t>(2 * G, 1024));
-    HIP_TRY(c.str_b.reserve(cap * 12 + 256));
-    void *tkeys = c.str_b.p, *tvals = (uint8_t *)c.str_b.p + cap * 8;
+    HIP_TRY(c.str_b.reserve(cap * 16 + 256));
+    Utf8Slot *table = (Utf8Slot *)c.str_b.p;
     uint32_t bad = 0;
-    HIP_TRY(hipMemsetAsync(tkeys, 0xFF, cap * 8, c.stream));
+    HIP_TRY(hipMemsetAsync(table, 0xFF, cap * 16, c.stream));
     HIP_TRY(hipMemsetAsync(bad_d, 0, 8, c.stream));
-    launch_ht_build((const uint64_t *)groups.p->cols[0].values, (uint32_t)G, (uint64_t *)tkeys, (uint32_t *)tvals, cap - 1, c.stream);
-    launch_ht_probe_verify(V, (const uint64_t *)h, (const uint64_t *)tkeys, (const uint32_t *)tvals, cap - 1, (const uint32_t *)groups.p->cols[1].values,
-                           D->codes, (uint32_t *)bad_d, c.stream);
+    launch_ht_build((const uint64_t *)groups.p->cols[0].values, (const uint32_t *)groups.p->cols[1].values, (uint32_t)G, table, cap - 1, c.stream);
+    launch_ht_probe_verify(V, (const uint64_t *)h, table, cap - 1, D->codes, (uint32_t *)bad_d, c.stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(c.host_flags, bad_d, 4, hipMemcpyDeviceToHost, c.stream)); // (pinned)
     HIP_TRY(hipStreamSynchronize(c.stream));
@@ -2406,9 +2405,8 @@ int32_t plhip_hash_join(const plhip_column_t *left, const plhip_column_t *right,
   const uint64_t cap = next_pow2(std::max<uint64_t>(2 * G, 1024));
   HIP_TRY(c.str_b.reserve(cap * 16 + 512));
   JoinTable T{};
-  T.used = (uint32_t *)c.str_b.p; T.keys = (uint64_t *)((uint8_t *)c.str_b.p + cap * 4); T.vals = (uint32_t *)((uint8_t *)c.str_b.p + cap * 12);
-  T.g_null = (uint32_t *)((uint8_t *)c.str_b.p + cap * 16); T.mask = cap - 1;
-  HIP_TRY(hipMemsetAsync(T.used, 0, cap * 4, c.stream));
+  T.slots = (JoinSlot *)c.str_b.p; T.g_null = (uint32_t *)((uint8_t *)c.str_b.p + cap * 16); T.mask = cap - 1;
+  HIP_TRY(hipMemsetAsync(T.slots, 0, cap * 16, c.stream));
   HIP_TRY(hipMemsetAsync(T.g_null, 0xFF, 256, c.stream));
   JoinKey KB{db.values, db.validity, db.boff, nb, w, 0}, KP{dp.values, dp.validity, dp.boff, n, w, 0};
   launch_join_build(KB, first, (uint32_t)G, T, c.stream);

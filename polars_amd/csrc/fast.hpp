@@ -15,7 +15,9 @@
 #include "plan.hpp"
 
 #define TS_BLOCK 1024
+#ifndef TS_R
 #define TS_R 8
+#endif
 #define TS_TILE (TS_BLOCK * TS_R) // rows per sorted tile
 #define TS_MAX_PBITS 9 // np + 1 histogram entries must not exceed TS_BLOCK (one per thread in the scan)
 

@@ -26,12 +26,16 @@ struct JoinKey {
   uint32_t pad;
 };
 
+struct JoinSlot { // 16 bytes: one load per probe step
+  uint64_t key;
+  uint32_t val;  // group index
+  uint32_t used; // claim flag (0: empty)
+};
+
 struct JoinTable {
-  uint32_t *used;  // cap claim flags, zeroed by the caller
-  uint64_t *keys;  // cap
-  uint32_t *vals;  // cap: group index
+  JoinSlot *slots;  // cap entries, zeroed by the caller
   uint32_t *g_null; // one word preset to JOIN_NONE: the group of the null key
-  uint64_t mask;   // cap - 1
+  uint64_t mask;    // cap - 1
 };
 
 #define JOIN_NONE 0xFFFFFFFFu

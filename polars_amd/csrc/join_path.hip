@@ -36,7 +36,7 @@ __global__ void __launch_bounds__(JOIN_BLOCK) k_join_build(JoinKey b, const uint
   if (!jk_valid(b, f)) { *t.g_null = g; return; } // (one group at most)
   const uint64_t key = jk_load(b, f);
   for (uint64_t s = jk_slot(key, t.mask), tries = 0; tries <= t.mask; s = (s + 1) & t.mask, tries++)
-    if (atomicCAS(&t.used[s], 0u, 1u) == 0u) { t.keys[s] = key; t.vals[s] = g; return; } // the groups' keys are distinct: nothing to compare
+    if (atomicCAS(&t.slots[s].used, 0u, 1u) == 0u) { t.slots[s].key = key; t.slots[s].val = g; return; } // the groups' keys are distinct: nothing to compare
 }
 
 __global__ void __launch_bounds__(JOIN_BLOCK) k_join_count(JoinKey p, JoinTable t, const uint32_t *offsets, int left_join, uint32_t *gid, uint64_t *cnt) {
@@ -48,8 +48,9 @@ __global__ void __launch_bounds__(JOIN_BLOCK) k_join_count(JoinKey p, JoinTable 
   else {
     const uint64_t key = jk_load(p, i);
     for (uint64_t s = jk_slot(key, t.mask), tries = 0; tries <= t.mask; s = (s + 1) & t.mask, tries++) {
-      if (!t.used[s]) break;
-      if (t.keys[s] == key) { g = t.vals[s]; break; }
+      const uint4 e = *(const uint4 *)&t.slots[s]; // {key lo, key hi, val, used}
+      if (!e.w) break;
+      if ((((uint64_t)e.y << 32) | e.x) == key) { g = e.z; break; }
     }
   }
   gid[i] = g;

@@ -31,12 +31,17 @@ struct Utf8View {
 
 #define UTF8_HT_EMPTY 0xFFFFFFFFFFFFFFFFull
 
+struct Utf8Slot { // 16 bytes: a probe step is one load and brings the group's first row along
+  uint64_t hash;  // UTF8_HT_EMPTY: free
+  uint32_t group;
+  uint32_t first; // first row of the group
+};
+
 void launch_utf8_hash(const Utf8View &v, uint64_t seed, uint64_t *h, uint32_t *iota, hipStream_t s);
-// `tkeys` holds cap = mask + 1 entries preset to UTF8_HT_EMPTY (memset 0xFF)
-void launch_ht_build(const uint64_t *keys, uint32_t G, uint64_t *tkeys, uint32_t *tvals, uint64_t mask, hipStream_t s);
+// `table` holds cap = mask + 1 entries preset to 0xFF bytes (hash == UTF8_HT_EMPTY)
+void launch_ht_build(const uint64_t *keys, const uint32_t *first, uint32_t G, Utf8Slot *table, uint64_t mask, hipStream_t s);
 // the row's code from the table, then its bytes against the bytes of its group's first row (bad |= 1: a collision; 2: a hash without an entry)
-void launch_ht_probe_verify(const Utf8View &v, const uint64_t *h, const uint64_t *tkeys, const uint32_t *tvals, uint64_t mask, const uint32_t *first,
-                            uint32_t *codes, uint32_t *bad, hipStream_t s);
+void launch_ht_probe_verify(const Utf8View &v, const uint64_t *h, const Utf8Slot *table, uint64_t mask, uint32_t *codes, uint32_t *bad, hipStream_t s);
 void launch_utf8_lengths(const Utf8View &v, const uint32_t *first, uint32_t G, int64_t *lens, hipStream_t s);
 size_t utf8_scan_temp_bytes(uint32_t G);
 hipError_t utf8_scan(void *temp, size_t temp_bytes, const int64_t *lens, int64_t *offs, uint32_t G, hipStream_t s); // exclusive, G + 1 entries

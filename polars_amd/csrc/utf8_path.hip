@@ -52,32 +52,33 @@ __global__ void __launch_bounds__(UTF8_BLOCK) k_utf8_hash(Utf8View v, uint64_t s
 
 __device__ __forceinline__ uint64_t slot_of(uint64_t h, uint64_t mask) { return (h ^ (h >> 29)) & mask; }
 
-__global__ void __launch_bounds__(UTF8_BLOCK) k_ht_build(const uint64_t *keys, uint32_t G, uint64_t *tkeys, uint32_t *tvals, uint64_t mask) {
+__global__ void __launch_bounds__(UTF8_BLOCK) k_ht_build(const uint64_t *keys, const uint32_t *first, uint32_t G, Utf8Slot *table, uint64_t mask) {
   const uint32_t g = blockIdx.x * UTF8_BLOCK + threadIdx.x;
   if (g >= G) return;
   const uint64_t h = keys[g];
   for (uint64_t s = slot_of(h, mask), tries = 0; tries <= mask; s = (s + 1) & mask, tries++) { // (load <= 0.5: an empty slot exists)
-    const unsigned long long old = atomicCAS((unsigned long long *)&tkeys[s], (unsigned long long)UTF8_HT_EMPTY, (unsigned long long)h);
-    if (old == UTF8_HT_EMPTY) { tvals[s] = g; return; }
+    const unsigned long long old = atomicCAS((unsigned long long *)&table[s].hash, (unsigned long long)UTF8_HT_EMPTY, (unsigned long long)h);
+    if (old == UTF8_HT_EMPTY) { table[s].group = g; table[s].first = first[g]; return; }
   }
 }
 
 // Every row looks its hash up (its code), then BytesHash equality (vector_hasher.rs:437-446) of the row against its group's first row
-__global__ void __launch_bounds__(UTF8_BLOCK) k_ht_probe_verify(Utf8View v, const uint64_t *h, const uint64_t *tkeys, const uint32_t *tvals, uint64_t mask,
-                                                                const uint32_t *first, uint32_t *codes, uint32_t *bad) {
+__global__ void __launch_bounds__(UTF8_BLOCK) k_ht_probe_verify(Utf8View v, const uint64_t *h, const Utf8Slot *table, uint64_t mask, uint32_t *codes,
+                                                                uint32_t *bad) {
   const int64_t i = (int64_t)blockIdx.x * UTF8_BLOCK + threadIdx.x;
   if (i >= v.n) return;
   const uint64_t x = h[i];
   uint32_t code = 0;
+  int64_t f = 0;
   bool found = false;
   for (uint64_t s = slot_of(x, mask), tries = 0; tries <= mask; s = (s + 1) & mask, tries++) {
-    const uint64_t k = tkeys[s];
-    if (k == x) { code = tvals[s]; found = true; break; }
+    const uint4 e = *(const uint4 *)&table[s]; // {hash lo, hash hi, group, first}
+    const uint64_t k = ((uint64_t)e.y << 32) | e.x;
+    if (k == x) { code = e.z; f = e.w; found = true; break; }
     if (k == UTF8_HT_EMPTY) break;
   }
   codes[i] = code;
   if (!found) { atomicOr(bad, 2u); return; } // every row's hash is one of the groups': cannot happen
-  const int64_t f = first[code];
   if (f == i) return;
   const bool vi = row_valid(v, i), vf = row_valid(v, f);
   bool same = vi == vf;
@@ -125,15 +126,14 @@ void launch_utf8_hash(const Utf8View &v, uint64_t seed, uint64_t *h, uint32_t *i
   hipLaunchKernelGGL(k_utf8_hash, dim3((unsigned)((v.n + UTF8_BLOCK - 1) / UTF8_BLOCK)), dim3(UTF8_BLOCK), 0, s, v, seed, h, iota);
 }
 
-void launch_ht_build(const uint64_t *keys, uint32_t G, uint64_t *tkeys, uint32_t *tvals, uint64_t mask, hipStream_t s) {
+void launch_ht_build(const uint64_t *keys, const uint32_t *first, uint32_t G, Utf8Slot *table, uint64_t mask, hipStream_t s) {
   if (!G) return;
-  hipLaunchKernelGGL(k_ht_build, dim3((G + UTF8_BLOCK - 1) / UTF8_BLOCK), dim3(UTF8_BLOCK), 0, s, keys, G, tkeys, tvals, mask);
+  hipLaunchKernelGGL(k_ht_build, dim3((G + UTF8_BLOCK - 1) / UTF8_BLOCK), dim3(UTF8_BLOCK), 0, s, keys, first, G, table, mask);
 }
 
-void launch_ht_probe_verify(const Utf8View &v, const uint64_t *h, const uint64_t *tkeys, const uint32_t *tvals, uint64_t mask, const uint32_t *first,
-                            uint32_t *codes, uint32_t *bad, hipStream_t s) {
+void launch_ht_probe_verify(const Utf8View &v, const uint64_t *h, const Utf8Slot *table, uint64_t mask, uint32_t *codes, uint32_t *bad, hipStream_t s) {
   if (v.n <= 0) return;
-  hipLaunchKernelGGL(k_ht_probe_verify, dim3((unsigned)((v.n + UTF8_BLOCK - 1) / UTF8_BLOCK)), dim3(UTF8_BLOCK), 0, s, v, h, tkeys, tvals, mask, first, codes, bad);
+  hipLaunchKernelGGL(k_ht_probe_verify, dim3((unsigned)((v.n + UTF8_BLOCK - 1) / UTF8_BLOCK)), dim3(UTF8_BLOCK), 0, s, v, h, table, mask, codes, bad);
 }
 
 void launch_utf8_lengths(const Utf8View &v, const uint32_t *first, uint32_t G, int64_t *lens, hipStream_t s) {
