@@ -351,9 +351,15 @@ def main():
     r_ms = (C.byref(f_tot), C.byref(f_dom), C.byref(f_name))
     r_bd = (C.byref(f_a), C.byref(f_b), C.byref(f_c))
     sharded = world > 1 or rehearse
+    # the library records its HIP events on every TIMING_EVERY-th query (three event records and their read-back cost ~5 % of a
+    # 0.1 ms step); the times below are those of the sampled steps INSIDE the timed region
+    TIMING_EVERY = max(1, min(8, steps // 4)) if not sharded else 1
+    L.plhip_set_timing_interval(TIMING_EVERY)
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for i_step in range(steps):
         g, out_widths = step()
+        if i_step % TIMING_EVERY != TIMING_EVERY - 1:
+            continue
         if sharded:
             # the sharded step makes several library calls: the engine kept the kernel times of the LOCAL partial pass
             # (the pass over this rank's rows) and the wall time of every phase of the step
@@ -370,6 +376,7 @@ def main():
         dom_names.append(dom_name)
     sync()
     dt = time.perf_counter() - t0
+    L.plhip_set_timing_interval(1)
     groups_total = g
     if world > 1:
         t = torch.tensor([dt, float(g)], device=dev, dtype=torch.float64)

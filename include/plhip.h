@@ -216,6 +216,12 @@ int32_t plhip_set_strategy(int32_t strategy /* plhip_strategy_t */);
  * (crates/polars-lazy/src/physical_plan/executors/group_by.rs:124-126). */
 const char *plhip_last_strategy(void);
 
+/* The single-launch pipelines (direct, tilesort, dense) bracket their kernels with HIP events for plhip_last_kernel_ms /
+ * _breakdown.  Three event records cost a few microseconds of a 50-100 us query: a host that runs many small queries has
+ * them recorded on every `every`-th query of the calling thread only (1 = every query, the default; 0 = never);
+ * plhip_last_kernel_ms then reports the last query that was timed.  No counterpart in the reference. */
+int32_t plhip_set_timing_interval(int32_t every);
+
 /* Milliseconds the device spent in the kernels of the last plhip_group_by_agg call on this thread
  * (HIP events on the library's own stream around the launches; staging copies excluded), and the
  * part of it spent in the dominant kernel.  Used by bench.py for `roofline.achieved`. */

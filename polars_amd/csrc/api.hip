@@ -73,6 +73,8 @@ struct Ctx {
   uint64_t *host_hdr = nullptr, *host_hdr_dev = nullptr; // pinned, device-mapped: the slot headers of the sharded path's exchange
   uint32_t seq = 0;
   bool hot_clean = false;  // the heavy-hitter words behind the flag block (FLAGS_HOT_OFF ..) are zero
+  int timing_every = 1, timing_tick = 0; // plhip_set_timing_interval: the fast paths record their events on every Nth query (0: never)
+  bool timed() { if (timing_every <= 0) return false; if (++timing_tick >= timing_every) { timing_tick = 0; return true; } return false; }
   int timing_pending = 0; // 1: direct, 2: tilesort (S == 1), 3: tilesort + merge -- event times not read yet
   Scratch xsend, xrecv, xcnt; // the sharded path's exchange buffers
   Scratch str_a, str_b;       // plhip_utf8_encode: hashes + row ids; lookup table + dictionary lengths + scan space
@@ -1072,7 +1074,8 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
   // ---- launches (events: [1] start, [4] tile sort done, [5] fold done, [2] merge done) ------------------------
   if (++c.seq == 0) c.seq = 1;
   const uint32_t seq = c.seq;
-  hipEventRecord(c.ev[1], c.stream);
+  const bool timed = c.timed();
+  if (timed) hipEventRecord(c.ev[1], c.stream);
   if (direct) {
     bool quad = true;
     auto aligned = [](const uint8_t *p, int wd) { return ((uintptr_t)p % (size_t)(4 * wd)) == 0; };
@@ -1088,7 +1091,7 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
     TileSortLevel1 HL{nullptr, nullptr, 0u, 0u, hot_self ? self_hot : nullptr, 4u * (uint32_t)TS_TILE / np, 0u, hot_self ? self_hot - 2 : nullptr};
     launch_tile_sort(P, O, pbits, n_tiles, (uint32_t *)c.offs.p, keymode, kxor, key_bytes, c.stream, &HL);
     if ((e = hipGetLastError()) != hipSuccess) { return fail_hip(e, "k_tile_sort launch"); }
-    hipEventRecord(c.ev[4], c.stream);
+    if (timed) hipEventRecord(c.ev[4], c.stream);
     Plan P2 = P; // the fold pass reads the sorted copies
     for (int v = 0; v < P.n_vals; v++) { // the key specs stay: k_fold_runs reads the packed keys from A.pkeys
       P2.vals[v].values = O.vals[v]; P2.vals[v].validity = O.valid[v]; P2.vals[v].boff = 0; P2.vals[v].valid_bytes = 1;
@@ -1108,7 +1111,7 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
     if ((e = hipGetLastError()) != hipSuccess) { return fail_hip(e, "k_fold_runs launch"); }
     c.strategy = "tilesort";
   }
-  hipEventRecord(c.ev[5], c.stream);
+  if (timed) hipEventRecord(c.ev[5], c.stream);
   MergeArgs M{};
   M.D = D; M.flags = dflags; M.out_cap = out_cap; M.lbits = lbits; M.S = S; M.mbits = mbits; M.pshift = direct ? 0u : pbits;
   M.host_sig = c.host_sig_dev; M.seq = seq;
@@ -1116,7 +1119,7 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
   if (merged) {
     launch_merge_emit(P, M, OP, key_bytes, direct ? 1u : n_pg, 1024, c.stream);
     if ((e = hipGetLastError()) != hipSuccess) { return fail_hip(e, "k_merge_emit launch"); }
-    hipEventRecord(c.ev[2], c.stream);
+    if (timed) hipEventRecord(c.ev[2], c.stream);
   }
   e = hipGetLastError();
   uint32_t fl[16] = {0};
@@ -1130,7 +1133,7 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
       if (hot_self) c.hot_clean = true;
     }
   } else { return fail_hip(e, "group-by kernels"); }
-  c.timing_pending = direct ? 1 : (merged ? 3 : 2);
+  if (timed) c.timing_pending = direct ? 1 : (merged ? 3 : 2);
   if (fl[FLAG_OVERFLOW]) { return PLHIP_OK; } // estimate too low: the general path redoes the query
   const uint64_t G = fl[FLAG_NGROUPS];
   R->n_rows = (int64_t)G;
@@ -1496,11 +1499,12 @@ int run_dense(const Lowered &L0, const std::vector<DevCol> &dk, uint32_t flags, 
   }
   if (++c.seq == 0) c.seq = 1;
   const uint32_t seq = c.seq;
-  hipEventRecord(c.ev[1], c.stream);
+  const bool timed = c.timed();
+  if (timed) hipEventRecord(c.ev[1], c.stream);
   if (fold_runs) launch_dense_fold(P, A, n_wgs, lds_bytes, c.stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail_hip(e, "k_dense_fold launch");
-  hipEventRecord(c.ev[5], c.stream);
+  if (timed) hipEventRecord(c.ev[5], c.stream);
   if (comm) {
     plhip_sharded_stats_t &S = c.shard_stats;
     lap(S.partial_ms);
@@ -1516,7 +1520,7 @@ int run_dense(const Lowered &L0, const std::vector<DevCol> &dk, uint32_t flags, 
   }
   launch_dense_merge(P, comm ? A2 : A, OP, out_cap, c.host_sig_dev, seq, c.stream);
   if ((e = hipGetLastError()) != hipSuccess) return fail_hip(e, "k_dense_merge launch");
-  hipEventRecord(c.ev[2], c.stream);
+  if (timed) hipEventRecord(c.ev[2], c.stream);
   uint32_t fl[16] = {0};
   TableRef t{nullptr, 0, dflags};
   const int rc = wait_signal(t, seq, fl);
@@ -1524,7 +1528,7 @@ int run_dense(const Lowered &L0, const std::vector<DevCol> &dk, uint32_t flags, 
   if (comm) { c.shard_stats.host_syncs++; lap(c.shard_stats.merge_ms); }
   if (!fl[FLAG_OVERFLOW] && c.signal_seen) c.flags_clean = 2; // (the signal was seen: the kernel's last workgroup has zeroed its counters)
   else if (hipMemsetAsync(dflags, 0, 64, c.stream) == hipSuccess) c.flags_clean = true;
-  c.timing_pending = 4;
+  if (timed) c.timing_pending = 4;
   c.strategy = "dense";
   if (getenv("PLHIP_DENSE_VERBOSE"))
     fprintf(stderr, "dense: parts %u R %u gpr %u lds %zu B wgs %u dump %llu B slices %u %u kinds %u %u\n", A.n_parts, R, A.gpr, lds_bytes, n_wgs,
@@ -1942,6 +1946,12 @@ int32_t plhip_set_strategy(int32_t strategy) {
 }
 
 const char *plhip_last_strategy(void) { return g_ctx.strategy.c_str(); }
+
+int32_t plhip_set_timing_interval(int32_t every) {
+  if (every < 0) return fail(PLHIP_ERR_INVALID, "the timing interval is >= 0");
+  g_ctx.timing_every = every; g_ctx.timing_tick = 0;
+  return PLHIP_OK;
+}
 
 int32_t plhip_last_kernel_ms(float *total_ms, float *dominant_ms, const char **dominant_kernel) {
   resolve_timing();
