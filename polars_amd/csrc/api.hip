@@ -853,6 +853,8 @@ int estimate_groups_sampled(const Plan &P, uint64_t &g_est) {
   // model's and GEE's (sqrt(n / s) * f1 + (d - f1), Charikar et al.), which is built for that case.
   int64_t ns = n <= (1 << 17) ? n : (1 << 17); // whole 256-row blocks when sampling
   g_est = (uint64_t)n;
+  static const int cap_log2 = getenv("PLHIP_EST_CAP_LOG2") ? std::max(18, std::min(24, atoi(getenv("PLHIP_EST_CAP_LOG2")))) : 22;
+  const int64_t ns2_cap = (int64_t)1 << cap_log2; // the second, larger sample
   for (int round = 0; round < 2; round++) {
     const uint32_t set_bits = (uint32_t)std::max(10, ceil_log2((uint64_t)ns * 4));
     const size_t set_bytes = ((size_t)4 << set_bits) + ((size_t)4 << set_bits) / 16; // fingerprints + 2 state bits per slot
@@ -870,7 +872,7 @@ int estimate_groups_sampled(const Plan &P, uint64_t &g_est) {
     if (getenv("PLHIP_DEBUG_EST")) fprintf(stderr, "estimate: round %d n %lld ns %lld d %.0f f1 %.0f flags %u %u %u %u %u %u %u %u\n", round, (long long)n, (long long)ns, d, f1, f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
     const bool more = round == 0 && n >= 32 * ns; // a second sample is possible and worth its time
     const bool saturated = d >= 0.95 * (double)ns;
-    if (saturated && more) { ns = std::min<int64_t>((n / 16) & ~(int64_t)255, (int64_t)1 << 22); continue; }
+    if (saturated && more) { ns = std::min<int64_t>((n / 16) & ~(int64_t)255, ns2_cap); continue; }
     // (almost) all distinct: the model still reads G ~ s^2 / (2 * repeats) while the sample holds enough repeated keys
     // for that count to mean something (4M samples of 1e9 rows over 1e8 ids: 8e4 repeats, +-0.4 %)
     if (saturated && (double)ns - d < 1024.0) {
@@ -884,7 +886,7 @@ int estimate_groups_sampled(const Plan &P, uint64_t &g_est) {
       double est = hi;
       const double f1_uniform = (double)ns * std::exp(-(double)ns / hi);
       if (ns < n && f1 > 1.25 * f1_uniform + 64) { // skewed
-        if (more) { ns = std::min<int64_t>((n / 16) & ~(int64_t)255, (int64_t)1 << 22); continue; }
+        if (more) { ns = std::min<int64_t>((n / 16) & ~(int64_t)255, ns2_cap); continue; }
         est = std::max(est, std::sqrt((double)n / (double)ns) * f1 + (d - f1));
       }
       g_est = (uint64_t)std::min<double>((double)n, std::ceil(est * 1.1));
