@@ -391,6 +391,8 @@ def main():
         strategy = pa.last_strategy() if world == 1 and not rehearse else eng.last_partial_strategy
         # the local pass of rank 0 (for N > 1: its partial aggregation over its n rows, the dominant kernels of the step)
         g_local = g if world == 1 and not rehearse else eng.last_partial_groups
+        if g_local < 0:  # the dense exchange never counts the local pass's groups: its partial arrays cover every code
+            g_local = hint
         abytes = algorithmic_bytes(n, g_local, keys, vals, out_widths)
         dom_avg = sum(dom_ms) / len(dom_ms)
         tot_avg = sum(kernel_ms) / len(kernel_ms)

@@ -2315,6 +2315,7 @@ int32_t plhip_utf8_encode(const plhip_utf8_column_t *col, plhip_dictionary_t **d
     HIP_TRY(hipMemcpyAsync(c.host_flags, D->offs + G, 8, hipMemcpyDeviceToHost, c.stream));
     HIP_TRY(hipStreamSynchronize(c.stream));
     memcpy(&D->total, c.host_flags, 8);
+    if (D->total < 0) return fail(PLHIP_ERR_INVALID, "the column's offsets are not monotonic");
     HIP_TRY(g_pool.get(c.device, D->total > 0 ? (size_t)D->total : 8, (void **)&D->data, &D->cap[4]));
     launch_utf8_gather(V, first, (uint32_t)G, D->offs, D->data, D->dvalid, c.stream);
     HIP_TRY(hipGetLastError());
