@@ -621,7 +621,11 @@ int wait_signal(TableRef t, uint32_t seq, uint32_t *out8) {
       const hipError_t q = hipStreamQuery(c.stream);
       if (q == hipSuccess) {
         if (((v = __atomic_load_n(sig, __ATOMIC_ACQUIRE)) >> 32) == seq) break;
-        return read_flags(t, out8);
+        // (never seen: a kernel that retired without its signal.  The flag block may have been zeroed by the kernel's last
+        // workgroup already, so a count of zero cannot be told from "no result": an error, not an empty frame)
+        const int frc = read_flags(t, out8);
+        if (!frc && !out8[FLAG_OVERFLOW] && out8[FLAG_NGROUPS] == 0) return fail(PLHIP_ERR_HIP, "the kernels retired without publishing their result");
+        return frc;
       }
       if (q != hipErrorNotReady) return fail_hip(q, "group-by kernels");
     }
@@ -1129,8 +1133,10 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
     TableRef t{nullptr, 0, dflags};
     int rc = wait_signal(t, seq, fl);
     if (rc) { return rc; }
-    // for the next query (the heavy-hitter words too: one memset)
-    if (hipMemsetAsync(dflags, 0, hot_self ? FLAGS_HOT_OFF + FLAGS_HOT_WORDS * 4 : 64, c.stream) == hipSuccess) {
+    // for the next query: the last workgroup has zeroed the words it used when the run was clean (publish_done); otherwise, and
+    // for the heavy-hitter words, one memset
+    if (c.signal_seen && !fl[FLAG_OVERFLOW] && !hot_self) c.flags_clean = true;
+    else if (hipMemsetAsync(dflags, 0, hot_self ? FLAGS_HOT_OFF + FLAGS_HOT_WORDS * 4 : 64, c.stream) == hipSuccess) {
       c.flags_clean = true;
       if (hot_self) c.hot_clean = true;
     }

@@ -783,6 +783,9 @@ DEVINL void publish_done(uint32_t *flags, const uint32_t *sh, uint32_t *host_sig
     if (old == gridDim.x - 1) {
       const uint32_t o = atomicAdd(&flags[FLAG_OVERFLOW], 0u); // this kernel's workgroups and earlier kernels'
       const uint32_t g = atomicAdd(&flags[FLAG_NGROUPS], 0u);
+      // every other workgroup has made its last flag access: a clean run leaves the block zeroed for the next query (api.hip
+      // skips its memset then); after an overflow the host zeroes it
+      if (!o) { flags[FLAG_NGROUPS] = 0u; flags[FLAG_DONE] = 0u; }
       // one 64-bit store carries everything: no ordering between host words to arrange
       __hip_atomic_store((uint64_t *)host_sig, ((uint64_t)seq << 32) | (o ? 0x80000000u : 0u) | (g & 0x7FFFFFFFu), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_SYSTEM);
