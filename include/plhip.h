@@ -424,6 +424,14 @@ int32_t plhip_finalize_partial(const plhip_result_t *merged, int32_t n_keys, con
                                const plhip_column_t *out_cols);
 
 
+/* ---- pinned host buffers ("pinned-host staging") -----------------------------------------------------
+ * Host columns are copied to HBM by every entry point that accepts PLHIP_HOST.  From pageable memory the runtime
+ * stages the copy through its own bounce buffers; from page-locked memory it is one DMA at PCIe rate.  A host layer
+ * whose Arrow buffers come from an allocator it controls (Polars' is pluggable) can take them from here.  The memory is
+ * ordinary host memory to the CPU; free it with plhip_free_pinned.  No counterpart in the reference. */
+int32_t plhip_alloc_pinned(size_t bytes, void **ptr);
+int32_t plhip_free_pinned(void *ptr);
+
 /* ---- string keys ----------------------------------------------------------------------------------
  * IntoGroupsProxy for Utf8Chunked / BinaryChunked (crates/polars-core/src/frame/group_by/into_groups.rs:232-290): the
  * reference hashes every string once and groups the (hash, bytes) pairs -- BytesHash, hashing/vector_hasher.rs:422-446,

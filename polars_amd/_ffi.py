@@ -225,6 +225,10 @@ def lib():
     L.plhip_join_free.restype = None
     L.plhip_set_timing_interval.argtypes = [i32]
     L.plhip_set_timing_interval.restype = i32
+    L.plhip_alloc_pinned.argtypes = [C.c_size_t, P(vp)]
+    L.plhip_alloc_pinned.restype = i32
+    L.plhip_free_pinned.argtypes = [vp]
+    L.plhip_free_pinned.restype = i32
     L.plhip_release_workspace.argtypes = []
     L.plhip_release_workspace.restype = i32
     L.plhip_pooled_buffers.argtypes = [i32]
@@ -289,5 +293,5 @@ EXPORTED_SYMBOLS = [
     "plhip_comm_unique_id", "plhip_comm_init_rccl", "plhip_comm_init_host", "plhip_comm_free", "plhip_group_by_agg_sharded",
     "plhip_sharded_last_stats", "plhip_group_by_agg_chunked",
     "plhip_utf8_encode", "plhip_dictionary_len", "plhip_dictionary_strings", "plhip_dictionary_free",
-    "plhip_set_timing_interval", "plhip_hash_join", "plhip_join_num_rows", "plhip_join_buffers", "plhip_join_free",
+    "plhip_set_timing_interval", "plhip_alloc_pinned", "plhip_free_pinned", "plhip_hash_join", "plhip_join_num_rows", "plhip_join_buffers", "plhip_join_free",
 ]

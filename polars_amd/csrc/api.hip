@@ -2206,6 +2206,23 @@ int32_t plhip_group_by_agg_chunked(const plhip_chunked_column_t *keys, int32_t n
   return rc;
 }
 
+// page-locked host buffers for the host layer's Arrow allocator (host -> HBM copies then run as one DMA)
+int32_t plhip_alloc_pinned(size_t bytes, void **ptr) {
+  if (!ptr) return fail(PLHIP_ERR_INVALID, "NULL pointer");
+  *ptr = nullptr;
+  const int rc = ensure_ctx();
+  if (rc) return rc;
+  const hipError_t e = hipHostMalloc(ptr, bytes ? bytes : 8, hipHostMallocDefault);
+  if (e != hipSuccess) { *ptr = nullptr; return fail_hip(e, "hipHostMalloc"); }
+  return PLHIP_OK;
+}
+
+int32_t plhip_free_pinned(void *ptr) {
+  if (!ptr) return PLHIP_OK;
+  const hipError_t e = hipHostFree(ptr);
+  return e == hipSuccess ? PLHIP_OK : fail_hip(e, "hipHostFree");
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // string keys: LargeUtf8 -> dense codes + dictionary (utf8.hpp)
 // ---------------------------------------------------------------------------------------------------------
