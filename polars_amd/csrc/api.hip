@@ -181,6 +181,14 @@ struct Staging { // owns device copies of host columns for the duration of one c
   ~Staging() { for (void *p : owned) hipFree(p); }
 };
 
+// Declared AFTER the owners of pooled buffers in a function: it is destroyed first, so the stream has retired every kernel that
+// still touches those buffers before an early return hands them back to the pool (where the next query would reuse them).
+struct StreamDrain {
+  hipStream_t s;
+  explicit StreamDrain(hipStream_t st) : s(st) {}
+  ~StreamDrain() { if (s && hipStreamSynchronize(s) != hipSuccess) (void)hipGetLastError(); }
+};
+
 int stage_column(const plhip_column_t &c, DevCol &d, Staging &st, hipStream_t s) {
   const int w = dtype_width(c.dtype);
   if (!w) return fail(PLHIP_ERR_UNSUPPORTED_DTYPE, "unsupported dtype code " + std::to_string(c.dtype));
@@ -2084,6 +2092,7 @@ int bool_group_by(const plhip_column_t *keys, int32_t n_keys, const plhip_column
   plhip_result_t *R = nullptr;
   if ((rc = group_by_agg_impl(lk.data(), n_keys, lv.data(), n_values, aggs, n_aggs, flags | PLHIP_FLAG_OUTPUT_DEVICE, opts, &R))) return rc;
   std::unique_ptr<plhip_result> Rg(R);
+  StreamDrain drain(c.stream);
   const int64_t G = R->n_rows;
   if (R->cols.size() != bool_out.size()) return fail(PLHIP_ERR_COMPUTE, "the result frame does not match the query");
   for (size_t i = 0; i < R->cols.size(); i++) {
@@ -2261,6 +2270,8 @@ int32_t plhip_utf8_encode(const plhip_utf8_column_t *col, plhip_dictionary_t **d
   std::unique_ptr<plhip_dictionary> D(new (std::nothrow) plhip_dictionary());
   if (!D) return fail(PLHIP_ERR_OOM, "host allocation failed");
   D->device = c.device; D->n = n;
+  struct Groups { plhip_result_t *p = nullptr; ~Groups() { delete p; } } groups; // (device-resident frame: back to the pool on every path out)
+  StreamDrain drain(c.stream);
   // ---- the column in HBM -------------------------------------------------------------------------------------------
   Utf8View V{};
   V.n = n;
@@ -2289,7 +2300,6 @@ int32_t plhip_utf8_encode(const plhip_utf8_column_t *col, plhip_dictionary_t **d
   HIP_TRY(c.str_a.reserve(h_bytes + i_bytes + 256));
   void *h = c.str_a.p, *iota = (uint8_t *)c.str_a.p + h_bytes, *bad_d = (uint8_t *)c.str_a.p + h_bytes + i_bytes;
   HIP_TRY(g_pool.get(c.device, n ? (size_t)n * 4 : 8, (void **)&D->codes, &D->cap[0]));
-  struct Groups { plhip_result_t *p = nullptr; ~Groups() { delete p; } } groups; // (device-resident frame: back to the pool on every path out)
   uint64_t G = 0;
   static const uint64_t seeds[3] = {0x243F6A8885A308D3ull, 0x13198A2E03707344ull, 0xA4093822299F31D0ull};
   for (int attempt = 0;; attempt++) {
@@ -2464,6 +2474,7 @@ int32_t plhip_hash_join(const plhip_column_t *left, const plhip_column_t *right,
   std::unique_ptr<plhip_join> J(new (std::nothrow) plhip_join());
   if (!J) return fail(PLHIP_ERR_OOM, "host allocation failed");
   J->device = c.device; J->n = (int64_t)total;
+  StreamDrain drain(c.stream);
   uint32_t *out_probe = nullptr, *out_build = nullptr;
   size_t cp = 0, cb = 0;
   HIP_TRY(g_pool.get(c.device, std::max<size_t>((size_t)total * 4, 8), (void **)&out_probe, &cp));
