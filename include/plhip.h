@@ -470,7 +470,14 @@ void plhip_dictionary_free(plhip_dictionary_t *dict);
  * (row, PLHIP_JOIN_NONE).  Keys are Option<T>: nulls join nulls (crates/polars/tests/it/core/joins.rs:574-586).  Both keys
  * must have the same integer dtype.  The host layer gathers the payload columns with the two index arrays
  * (DataFrame::_finish_join), which is outside this path. */
-typedef enum plhip_join_how { PLHIP_JOIN_INNER = 0, PLHIP_JOIN_LEFT = 1 } plhip_join_how_t;
+typedef enum plhip_join_how {
+  PLHIP_JOIN_INNER = 0,
+  PLHIP_JOIN_LEFT = 1,
+  /* semi_anti_impl (single_keys_semi_anti.rs:33-): the left rows whose key occurs (SEMI) / does not occur (ANTI) among the right
+   * keys, in left order, each once; right_idx comes back NULL */
+  PLHIP_JOIN_SEMI = 2,
+  PLHIP_JOIN_ANTI = 3
+} plhip_join_how_t;
 #define PLHIP_JOIN_NONE 0xFFFFFFFFu
 typedef struct plhip_join plhip_join_t;
 int32_t plhip_hash_join(const plhip_column_t *left, const plhip_column_t *right, int32_t how, int32_t out_location, plhip_join_t **out);

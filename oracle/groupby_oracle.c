@@ -922,6 +922,10 @@ int64_t orc_hash_join(const plhip_column_t *left, const plhip_column_t *right, i
         if (jkey(build, head[s], &hv) == k) { row = head[s]; break; }
       }
     }
+    if (how >= 2) { /* semi_anti_impl (single_keys_semi_anti.rs:33-): membership in the right keys; left rows in order, each once */
+      if ((row >= 0) == (how == 2)) { if (out_left) out_left[m] = (uint32_t)i; m++; }
+      continue;
+    }
     if (row < 0) {
       if (how == 1) { if (out_left) { out_left[m] = (uint32_t)i; out_right[m] = 0xFFFFFFFFu; } m++; }
       continue;

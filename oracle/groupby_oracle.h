@@ -80,7 +80,7 @@ int64_t orc_utf8_group_codes(const int64_t *offsets, const uint8_t *data, const 
  * (single_keys_left.rs:109-) for one integer key column pair of the same dtype: build_tables over the shorter relation
  * (inner; det_hash_prone_order!, hash_join/mod.rs:42-58) or over the right one (left join), key -> rows in ascending
  * order; the other relation probes in row order.  Keys are Option<T>: null == null.  how: 0 inner, 1 left (no match:
- * right index 0xFFFFFFFF).  Pass out_left = NULL to get the pair count only.  Returns the number of pairs, -1 on error. */
+ * right index 0xFFFFFFFF), 2 semi / 3 anti (single_keys_semi_anti.rs: left rows whose key is / is not among the right keys; out_right unused).  Pass out_left = NULL to get the pair count only.  Returns the number of pairs, -1 on error. */
 int64_t orc_hash_join(const plhip_column_t *left, const plhip_column_t *right, int how, uint32_t *out_left, uint32_t *out_right);
 
 int orc_take_keys(const plhip_column_t *key, const orc_groups_t *g, void *out_values, uint8_t *out_valid);

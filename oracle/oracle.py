@@ -339,7 +339,7 @@ def utf8_group_codes(offsets: np.ndarray, data: np.ndarray, valid: np.ndarray | 
 
 def hash_join(left: Column, right: Column, how: str = "inner"):
     """orc_hash_join: (left_idx, right_idx) u32 arrays in the reference's pair order; right_idx 0xFFFFFFFF = no match (left join)."""
-    h = {"inner": 0, "left": 1}[how]
+    h = {"inner": 0, "left": 1, "semi": 2, "anti": 3}[how]
     ls, rs = left.struct(), right.struct()
     m = lib().orc_hash_join(C.byref(ls), C.byref(rs), h, None, None)
     if m < 0:

@@ -2419,7 +2419,8 @@ struct plhip_join {
 int32_t plhip_hash_join(const plhip_column_t *left, const plhip_column_t *right, int32_t how, int32_t out_location, plhip_join_t **out) {
   if (!left || !right || !out) return fail(PLHIP_ERR_INVALID, "NULL pointer");
   *out = nullptr;
-  if (how != PLHIP_JOIN_INNER && how != PLHIP_JOIN_LEFT) return fail(PLHIP_ERR_INVALID, "bad join kind");
+  if (how < PLHIP_JOIN_INNER || how > PLHIP_JOIN_ANTI) return fail(PLHIP_ERR_INVALID, "bad join kind");
+  const bool membership = how == PLHIP_JOIN_SEMI || how == PLHIP_JOIN_ANTI;
   if (out_location != PLHIP_HOST && out_location != PLHIP_DEVICE) return fail(PLHIP_ERR_INVALID, "bad output location");
   if (left->dtype != right->dtype) return fail(PLHIP_ERR_COMPUTE, "datatypes of join keys don't match");
   if (dt_is_float(left->dtype) || !dtype_width(left->dtype)) return fail(PLHIP_ERR_UNSUPPORTED_DTYPE, "the join key must be an integer column");
@@ -2463,7 +2464,7 @@ int32_t plhip_hash_join(const plhip_column_t *left, const plhip_column_t *right,
   uint32_t *gid = (uint32_t *)c.str_a.p;
   uint64_t *cnt = (uint64_t *)((uint8_t *)c.str_a.p + g_bytes), *pos = (uint64_t *)((uint8_t *)c.str_a.p + g_bytes + c_bytes);
   void *tmp = (uint8_t *)c.str_a.p + g_bytes + 2 * c_bytes;
-  launch_join_count(KP, T, offsets, how == PLHIP_JOIN_LEFT, gid, cnt, c.stream);
+  launch_join_count(KP, T, offsets, how, gid, cnt, c.stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(join_scan(tmp, tb, cnt, pos, n, c.stream));
   HIP_TRY(hipMemcpyAsync(c.host_flags, pos + n, 8, hipMemcpyDeviceToHost, c.stream));
@@ -2479,17 +2480,19 @@ int32_t plhip_hash_join(const plhip_column_t *left, const plhip_column_t *right,
   size_t cp = 0, cb = 0;
   HIP_TRY(g_pool.get(c.device, std::max<size_t>((size_t)total * 4, 8), (void **)&out_probe, &cp));
   (swapped ? J->right : J->left) = out_probe; (swapped ? J->capr : J->capl) = cp;
-  HIP_TRY(g_pool.get(c.device, std::max<size_t>((size_t)total * 4, 8), (void **)&out_build, &cb));
-  (swapped ? J->left : J->right) = out_build; (swapped ? J->capl : J->capr) = cb;
+  if (!membership) {
+    HIP_TRY(g_pool.get(c.device, std::max<size_t>((size_t)total * 4, 8), (void **)&out_build, &cb));
+    (swapped ? J->left : J->right) = out_build; (swapped ? J->capl : J->capr) = cb;
+  }
   launch_join_fill(n, gid, pos, offsets, indices, out_probe, out_build, c.stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(c.stream));
   c.strategy = "hash_join";
   if (out_location == PLHIP_HOST) {
-    uint32_t *hl = (uint32_t *)malloc(std::max<size_t>((size_t)total * 4, 8)), *hr = (uint32_t *)malloc(std::max<size_t>((size_t)total * 4, 8));
-    hipError_t e = (hl && hr) ? hipSuccess : hipErrorOutOfMemory;
+    uint32_t *hl = (uint32_t *)malloc(std::max<size_t>((size_t)total * 4, 8)), *hr = membership ? nullptr : (uint32_t *)malloc(std::max<size_t>((size_t)total * 4, 8));
+    hipError_t e = (hl && (hr || membership)) ? hipSuccess : hipErrorOutOfMemory;
     if (e == hipSuccess && total) e = hipMemcpy(hl, J->left, (size_t)total * 4, hipMemcpyDeviceToHost);
-    if (e == hipSuccess && total) e = hipMemcpy(hr, J->right, (size_t)total * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && total && !membership) e = hipMemcpy(hr, J->right, (size_t)total * 4, hipMemcpyDeviceToHost);
     if (e != hipSuccess) { free(hl); free(hr); return fail_hip(e, "join result copy"); }
     g_pool.put(c.device, J->left, J->capl); g_pool.put(c.device, J->right, J->capr);
     J->left = hl; J->right = hr; J->capl = J->capr = 0; J->on_device = false;

@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(JOIN_BLOCK) k_join_build(JoinKey b, const uint
     if (atomicCAS(&t.slots[s].used, 0u, 1u) == 0u) { t.slots[s].key = key; t.slots[s].val = g; return; } // the groups' keys are distinct: nothing to compare
 }
 
-__global__ void __launch_bounds__(JOIN_BLOCK) k_join_count(JoinKey p, JoinTable t, const uint32_t *offsets, int left_join, uint32_t *gid, uint64_t *cnt) {
+__global__ void __launch_bounds__(JOIN_BLOCK) k_join_count(JoinKey p, JoinTable t, const uint32_t *offsets, int mode, uint32_t *gid, uint64_t *cnt) {
   const int64_t i = (int64_t)blockIdx.x * JOIN_BLOCK + threadIdx.x;
   if (i > p.n) return;
   if (i == p.n) { cnt[i] = 0; return; }
@@ -53,8 +53,14 @@ __global__ void __launch_bounds__(JOIN_BLOCK) k_join_count(JoinKey p, JoinTable 
       if ((((uint64_t)e.y << 32) | e.x) == key) { g = e.z; break; }
     }
   }
+  if (mode >= 2) { // semi / anti: membership only
+    const bool keep = (g != JOIN_NONE) == (mode == 2);
+    gid[i] = JOIN_NONE;
+    cnt[i] = keep ? 1ull : 0ull;
+    return;
+  }
   gid[i] = g;
-  cnt[i] = g != JOIN_NONE ? (uint64_t)(offsets[g + 1] - offsets[g]) : (left_join ? 1ull : 0ull);
+  cnt[i] = g != JOIN_NONE ? (uint64_t)(offsets[g + 1] - offsets[g]) : (mode == 1 ? 1ull : 0ull);
 }
 
 __global__ void __launch_bounds__(JOIN_BLOCK) k_join_fill(int64_t n, const uint32_t *gid, const uint64_t *pos, const uint32_t *offsets,
@@ -64,7 +70,7 @@ __global__ void __launch_bounds__(JOIN_BLOCK) k_join_fill(int64_t n, const uint3
   const uint32_t g = gid[i];
   const uint64_t p0 = pos[i];
   if (g == JOIN_NONE) {
-    if (pos[i + 1] > p0) { out_probe[p0] = (uint32_t)i; out_build[p0] = JOIN_NONE; } // left join: (row, None)
+    if (pos[i + 1] > p0) { out_probe[p0] = (uint32_t)i; if (out_build) out_build[p0] = JOIN_NONE; } // left join: (row, None); semi / anti: the row
     return;
   }
   const uint32_t o0 = offsets[g], o1 = offsets[g + 1];
@@ -78,8 +84,8 @@ void launch_join_build(const JoinKey &build, const uint32_t *first, uint32_t G, 
   hipLaunchKernelGGL(k_join_build, dim3((G + JOIN_BLOCK - 1) / JOIN_BLOCK), dim3(JOIN_BLOCK), 0, s, build, first, G, t);
 }
 
-void launch_join_count(const JoinKey &probe, const JoinTable &t, const uint32_t *offsets, int left_join, uint32_t *gid, uint64_t *cnt, hipStream_t s) {
-  hipLaunchKernelGGL(k_join_count, dim3((unsigned)((probe.n + 1 + JOIN_BLOCK - 1) / JOIN_BLOCK)), dim3(JOIN_BLOCK), 0, s, probe, t, offsets, left_join, gid, cnt);
+void launch_join_count(const JoinKey &probe, const JoinTable &t, const uint32_t *offsets, int mode, uint32_t *gid, uint64_t *cnt, hipStream_t s) {
+  hipLaunchKernelGGL(k_join_count, dim3((unsigned)((probe.n + 1 + JOIN_BLOCK - 1) / JOIN_BLOCK)), dim3(JOIN_BLOCK), 0, s, probe, t, offsets, mode, gid, cnt);
 }
 
 size_t join_scan_temp_bytes(int64_t n) {

@@ -159,7 +159,7 @@ class DataFrame:
 
     def join(self, other: "DataFrame", on: str | None = None, how: str = "inner", *, left_on: str | None = None,
              right_on: str | None = None, suffix: str = "_right") -> "DataFrame":
-        """DataFrame.join on one integer key, `how` = 'inner' | 'left' (py-polars/polars/dataframe/frame.py:5856): the index
+        """DataFrame.join on one integer key, `how` = 'inner' | 'left' | 'semi' | 'anti' (py-polars/polars/dataframe/frame.py:5856): the index
         pairs come from plhip_hash_join in the reference's order; the payload gather (`_finish_join`: left columns, then the
         right ones without the key, clashing names suffixed) runs on the host."""
         from .join import join_indices, take
@@ -170,6 +170,8 @@ class DataFrame:
             raise ValueError("you should pass the column to join on as an argument")
         li, ri = join_indices(self.get_column(left_on), other.get_column(right_on), how)
         out = [take(c, li, n) for n, c in self._cols.items()]
+        if how in ("semi", "anti"):  # only the left frame's rows
+            return DataFrame(out)
         taken = set(self._cols)
         for n, c in other._cols.items():
             if n == right_on:

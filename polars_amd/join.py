@@ -16,11 +16,12 @@ NONE = 0xFFFFFFFF
 
 
 def join_indices(left: Column, right: Column, how: str = "inner") -> tuple[np.ndarray, np.ndarray]:
-    """(left_idx, right_idx) as host u32 arrays; right_idx == NONE where a left-join row has no match."""
+    """(left_idx, right_idx) as host u32 arrays; right_idx == NONE where a left-join row has no match; semi / anti: the kept left
+    rows and an empty right array."""
     L = _ffi.lib()
-    h = {"inner": 0, "left": 1}.get(how)
+    h = {"inner": 0, "left": 1, "semi": 2, "anti": 3}.get(how)
     if h is None:
-        raise _ffi.PlHipError(6, f"join kind {how!r} is not on the accelerated path (inner, left)")
+        raise _ffi.PlHipError(6, f"join kind {how!r} is not on the accelerated path (inner, left, semi, anti)")
     for c in (left, right):
         if c.location == _ffi.DEVICE and type(c.values).__module__.startswith("torch"):
             import torch
@@ -37,7 +38,7 @@ def join_indices(left: Column, right: Column, how: str = "inner") -> tuple[np.nd
         if m == 0:
             return np.zeros(0, np.uint32), np.zeros(0, np.uint32)
         li = np.ctypeslib.as_array(C.cast(lp, C.POINTER(C.c_uint32)), shape=(m,)).copy()
-        ri = np.ctypeslib.as_array(C.cast(rp, C.POINTER(C.c_uint32)), shape=(m,)).copy()
+        ri = np.ctypeslib.as_array(C.cast(rp, C.POINTER(C.c_uint32)), shape=(m,)).copy() if rp.value else np.zeros(0, np.uint32)
         return li, ri
     finally:
         L.plhip_join_free(handle)

@@ -19,7 +19,7 @@ def test_reference_known_answers_on_the_gpu():
             check_case(case, dt, join_indices)
 
 
-@pytest.mark.parametrize("how", ["inner", "left"])
+@pytest.mark.parametrize("how", ["inner", "left", "semi", "anti"])
 @pytest.mark.parametrize("dtype", [np.int8, np.uint8, np.int16, np.uint16, np.int32, np.uint32, np.int64, np.uint64])
 def test_join_matches_the_oracle_pair_for_pair(oracle, how, dtype):
     rng = np.random.default_rng(np.dtype(dtype).itemsize * 7 + (how == "left"))
@@ -38,7 +38,7 @@ def test_join_matches_the_oracle_pair_for_pair(oracle, how, dtype):
         gl, gr = join_indices(left, right, how)
         wl, wr = oracle.hash_join(left, right, how)
         assert len(gl) == len(wl), (how, dtype, nl, nr)
-        assert np.array_equal(gl, wl) and np.array_equal(gr, wr), (how, dtype, nl, nr)
+        assert np.array_equal(gl, wl) and (how in ("semi", "anti") or np.array_equal(gr, wr)), (how, dtype, nl, nr)
 
 
 def test_join_large_and_device_resident(oracle):
@@ -50,10 +50,10 @@ def test_join_large_and_device_resident(oracle):
     rk = rng.permutation(2_000_000)[:nr].astype(np.int64)  # unique build keys: at most one match per probe row
     dev = torch.device("cuda:0")
     left, right = Column("k", torch.from_numpy(lk).to(dev)), Column("k", torch.from_numpy(rk).to(dev))
-    for how in ("inner", "left"):
+    for how in ("inner", "left", "semi", "anti"):
         gl, gr = join_indices(left, right, how)
         wl, wr = oracle.hash_join(Column("k", lk), Column("k", rk), how)
-        assert np.array_equal(gl, wl) and np.array_equal(gr, wr), how
+        assert np.array_equal(gl, wl) and (how in ("semi", "anti") or np.array_equal(gr, wr)), how
     assert _ffi.lib().plhip_last_strategy() == b"hash_join"
 
 
@@ -72,3 +72,5 @@ def test_frame_join():
     assert out.to_dict() == {"foo": [1, 2], "bar": [6.0, 7.0], "ham": [10, 20], "apple": ["x", "y"]}
     out = df.join(other, on="ham", how="left")
     assert out.to_dict() == {"foo": [1, 2, 3], "bar": [6.0, 7.0, 8.0], "ham": [10, 20, 30], "apple": ["x", "y", None]}
+    assert df.join(other, on="ham", how="semi").to_dict() == {"foo": [1, 2], "bar": [6.0, 7.0], "ham": [10, 20]}
+    assert df.join(other, on="ham", how="anti").to_dict() == {"foo": [3], "bar": [8.0], "ham": [30]}
