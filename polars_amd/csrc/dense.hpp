@@ -32,6 +32,9 @@ enum DenseKind : uint32_t {
   DENSE_KIND_SUMF64 = 2,    // f64 column: [ADD_F64]                                          (q3's v3 part)
   DENSE_KIND_SUM32 = 3,     // 4-byte integer column: [ADD_U64 kept in 32 bits]
   DENSE_KIND_CNTV_SUMF64 = 4, // nullable f64 column: [CNT_VALID, ADD_F64]                     (mean of a nullable column)
+  DENSE_KIND_CNTV = 5,      // a nullable column's valid count alone: reads the key and the column's validity bits, never its values.
+                            // The host splits [CNT_VALID, ADD_F64] into this and SUMF64 when 12 bytes of state per group would cost
+                            // more ranges than 8 (db-benchmark's NA variant: 8 ranges -> 5, and the counting part reads 4 bytes a row)
 };
 
 struct DensePart {

@@ -205,25 +205,25 @@ struct DenseBases { // wave-uniform: the slice's first element of every stream, 
   const uint8_t *k, *v, *kbm, *vbm;
   uint32_t ksh0, vsh0; // 0 or 4
 };
-template <int VQ, bool KV, bool VV>
+template <int VQ, bool KV, bool VV, int VL = VQ> // VL: value loads per quad (0: the part never reads the values, DENSE_KIND_CNTV)
 DEVINL void dense_issue(DenseBuf<VQ> &X, const DenseBases &S, uint32_t row_in_slice) {
 #pragma unroll
   for (int g = 0; g < 2; g++) {
     const uint32_t q = row_in_slice + ((uint32_t)g * DENSE_BLOCK + threadIdx.x) * 4u; // first row of the lane's quad g
     X.k[g] = gload16(S.k, q * 4u);
 #pragma unroll
-    for (int h = 0; h < VQ; h++) X.v[g * VQ + h] = gload16(S.v, q * (4u * VQ) + 16u * h);
+    for (int h = 0; h < VL; h++) X.v[g * VQ + h] = gload16(S.v, q * (4u * VQ) + 16u * h);
     if (KV) X.kb[g] = gload1(S.kbm, (S.ksh0 + q) >> 3);
     if (VV) X.vb[g] = gload1(S.vbm, (S.vsh0 + q) >> 3);
   }
 }
 template <int N> DEVINL void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-template <int VQ, bool KV, bool VV>
+template <int VQ, bool KV, bool VV, int VL = VQ>
 DEVINL void dense_pin(DenseBuf<VQ> &X) {
 #pragma unroll
   for (int g = 0; g < 2; g++) { u32x4 t = X.k[g]; asm volatile("" : "+v"(t)::"memory"); X.k[g] = t; }
 #pragma unroll
-  for (int g = 0; g < 2 * VQ; g++) { u32x4 t = X.v[g]; asm volatile("" : "+v"(t)::"memory"); X.v[g] = t; }
+  for (int g = 0; g < 2 * VL; g++) { u32x4 t = X.v[g]; asm volatile("" : "+v"(t)::"memory"); X.v[g] = t; }
 #pragma unroll
   for (int g = 0; g < 2; g++) {
     if (KV) { uint32_t t = X.kb[g]; asm volatile("" : "+v"(t)::"memory"); X.kb[g] = t; }
@@ -253,7 +253,11 @@ DEVINL void dense_fold_buf(const DenseArgs &A, const DensePart &D, uint8_t *tab,
       } else if (isnull) code = 0xFFFFFFFFu;
       rel[b] = code - c0;
     }
-    if (KIND == DENSE_KIND_SUMF64 || KIND == DENSE_KIND_CNTV_SUMF64) {
+    if (KIND == DENSE_KIND_CNTV) {
+#pragma unroll
+      for (int b = 0; b < 4; b++)
+        if (rel[b] < cnt_r && !((vnull >> b) & 1u)) atomicAdd((unsigned int *)(t0 + rel[b] * 4u), 1u);
+    } else if (KIND == DENSE_KIND_SUMF64 || KIND == DENSE_KIND_CNTV_SUMF64) {
       const u32x4 a = X.v[2 * g], b2 = X.v[2 * g + 1];
       const double d[4] = {__hiloint2double((int)a.y, (int)a.x), __hiloint2double((int)a.w, (int)a.z), __hiloint2double((int)b2.y, (int)b2.x),
                            __hiloint2double((int)b2.w, (int)b2.z)};
@@ -278,21 +282,22 @@ template <int KIND, bool KV, bool VV>
 DEVINL uint32_t dense_fold_rows_fast(const Plan &P, const DenseArgs &A, const DensePart &D, uint8_t *tab, uint32_t c0, uint32_t cnt, bool is_last,
                                      int64_t row0, uint32_t nb, uint32_t &bad) {
   constexpr int VQ = (KIND == DENSE_KIND_SUMF64 || KIND == DENSE_KIND_CNTV_SUMF64) ? 2 : 1;
-  constexpr int NL = 2 + 2 * VQ + (KV ? 2 : 0) + (VV ? 2 : 0); // loads per batch
+  constexpr int VL = KIND == DENSE_KIND_CNTV ? 0 : VQ;          // value loads per quad
+  constexpr int NL = 2 + 2 * VL + (KV ? 2 : 0) + (VV ? 2 : 0); // loads per batch
   DenseBases S;
   S.k = P.keys[0].values + row0 * 4; S.v = P.vals[D.src].values + row0 * (4 * VQ);
   S.kbm = nullptr; S.vbm = nullptr; S.ksh0 = 0; S.vsh0 = 0;
   if (KV) { const int64_t bit = P.keys[0].boff + row0; S.kbm = P.keys[0].validity + (bit >> 3); S.ksh0 = (uint32_t)bit & 7u; }
   if (VV) { const int64_t bit = P.vals[D.src].boff + row0; S.vbm = P.vals[D.src].validity + (bit >> 3); S.vsh0 = (uint32_t)bit & 7u; }
   DenseBuf<VQ> b0, b1, b2;
-  if (nb > 0) dense_issue<VQ, KV, VV>(b0, S, 0u);
-  if (nb > 1) dense_issue<VQ, KV, VV>(b1, S, (uint32_t)DENSE_BATCH);
+  if (nb > 0) dense_issue<VQ, KV, VV, VL>(b0, S, 0u);
+  if (nb > 1) dense_issue<VQ, KV, VV, VL>(b1, S, (uint32_t)DENSE_BATCH);
 #define DENSE_STEP(CUR, NEXT)                                                                     \
   {                                                                                               \
-    if (t + 2 < nb) dense_issue<VQ, KV, VV>(NEXT, S, (t + 2) * (uint32_t)DENSE_BATCH);            \
+    if (t + 2 < nb) dense_issue<VQ, KV, VV, VL>(NEXT, S, (t + 2) * (uint32_t)DENSE_BATCH);        \
     const uint32_t ahead = nb - 1 - t; /* batches issued behind this one */                       \
     if (ahead >= 2) wait_vm<2 * NL>(); else if (ahead == 1) wait_vm<NL>(); else wait_vm<0>();     \
-    dense_pin<VQ, KV, VV>(CUR);                                                                   \
+    dense_pin<VQ, KV, VV, VL>(CUR);                                                               \
     dense_fold_buf<KIND, VQ, KV, VV>(A, D, tab, c0, cnt, is_last, CUR, S, t * (uint32_t)DENSE_BATCH, bad); \
     ++t;                                                                                          \
   }
@@ -377,6 +382,7 @@ __global__ void __launch_bounds__(DENSE_BLOCK) k_dense_fold(Plan P, DenseArgs A)
       case DENSE_KIND_SUMF64: dense_fold_rows<DENSE_KIND_SUMF64, KV>(P, A, D, dsm, c0, cnt, is_last, row0, row1, bad); break;
       case DENSE_KIND_SUM32: dense_fold_rows<DENSE_KIND_SUM32, KV>(P, A, D, dsm, c0, cnt, is_last, row0, row1, bad); break;
       case DENSE_KIND_CNTV_SUMF64: dense_fold_rows<DENSE_KIND_CNTV_SUMF64, KV>(P, A, D, dsm, c0, cnt, is_last, row0, row1, bad); break;
+      case DENSE_KIND_CNTV: dense_fold_rows<DENSE_KIND_CNTV, KV>(P, A, D, dsm, c0, cnt, is_last, row0, row1, bad); break;
       default:
         if constexpr (RT) dense_fold_rows<DENSE_KIND_RT, KV>(P, A, D, dsm, c0, cnt, is_last, row0, row1, bad);
         break;
