@@ -481,6 +481,12 @@ typedef enum plhip_join_how {
 #define PLHIP_JOIN_NONE 0xFFFFFFFFu
 typedef struct plhip_join plhip_join_t;
 int32_t plhip_hash_join(const plhip_column_t *left, const plhip_column_t *right, int32_t how, int32_t out_location, plhip_join_t **out);
+/* The same on several key columns (_inner_join_multiple_keys / _left_join_multiple_keys, hash_join/multiple_keys.rs:173-,251-: rows
+ * hashed, equal when every column is equal -- compare_df_rows2 -- floats by bit pattern, nulls equal to nulls; build side and pair
+ * order as above).  left_keys[i] and right_keys[i] have the same dtype (any dtype of plhip_dtype_t but PLHIP_BOOL).  The key
+ * tuples of both relations are reduced to dense ids over their concatenation (plhip_group_tuples), then joined on the ids. */
+int32_t plhip_hash_join_multi(const plhip_column_t *left_keys, const plhip_column_t *right_keys, int32_t n_keys, int32_t how,
+                              int32_t out_location, plhip_join_t **out);
 int64_t plhip_join_num_rows(const plhip_join_t *j);
 /* u32 = IdxSize pairs, owned by the handle, in `*location` memory */
 int32_t plhip_join_buffers(const plhip_join_t *j, const uint32_t **left_idx, const uint32_t **right_idx, int32_t *location);

@@ -938,3 +938,69 @@ int64_t orc_hash_join(const plhip_column_t *left, const plhip_column_t *right, i
   free(head); free(tail); free(next);
   return m;
 }
+
+/* ---- hash join on several key columns (hash_join/multiple_keys.rs) ------------------------------------------ */
+static uint64_t jbits(const plhip_column_t *c, int64_t i, int *valid) { /* the row's key bits, zero-extended (floats by bit pattern) */
+  const int64_t r = c->offset + i;
+  *valid = !c->validity || ((c->validity[r >> 3] >> (r & 7)) & 1);
+  switch (c->dtype) {
+    case PLHIP_I8: case PLHIP_U8: return ((const uint8_t *)c->values)[r];
+    case PLHIP_I16: case PLHIP_U16: return ((const uint16_t *)c->values)[r];
+    case PLHIP_I32: case PLHIP_U32: case PLHIP_F32: return ((const uint32_t *)c->values)[r];
+    default: return ((const uint64_t *)c->values)[r];
+  }
+}
+static uint64_t jrow_hash(const plhip_column_t *cols, int n_keys, int64_t i) { /* _df_rows_to_hashes: one hash per row, nulls a constant */
+  uint64_t h = 0x243F6A8885A308D3ull;
+  for (int k = 0; k < n_keys; k++) {
+    int v;
+    const uint64_t b = jbits(&cols[k], i, &v);
+    h = orc_folded_multiply(h ^ (v ? b : 0x5851F42D4C957F2Dull), 0x9E3779B97F4A7C15ull) + (uint64_t)v;
+  }
+  return h;
+}
+static int jrow_eq(const plhip_column_t *a, int64_t i, const plhip_column_t *b, int64_t j, int n_keys) { /* compare_df_rows2 */
+  for (int k = 0; k < n_keys; k++) {
+    int va, vb;
+    const uint64_t x = jbits(&a[k], i, &va), y = jbits(&b[k], j, &vb);
+    if (va != vb || (va && x != y)) return 0;
+  }
+  return 1;
+}
+
+int64_t orc_hash_join_multi(const plhip_column_t *left, const plhip_column_t *right, int n_keys, int how, uint32_t *out_left,
+                            uint32_t *out_right) {
+  for (int k = 0; k < n_keys; k++) if (left[k].dtype != right[k].dtype) return -1;
+  const int swapped = how == 0 && !(left[0].length > right[0].length);
+  const plhip_column_t *probe = swapped ? right : left, *build = swapped ? left : right;
+  const int64_t nb = build[0].length, np = probe[0].length;
+  uint64_t cap = 16;
+  while (cap < (uint64_t)nb * 2 + 2) cap <<= 1;
+  int64_t *head = (int64_t *)malloc(cap * sizeof(int64_t)), *tail = (int64_t *)malloc(cap * sizeof(int64_t));
+  int64_t *next = (int64_t *)malloc((nb > 0 ? nb : 1) * sizeof(int64_t));
+  if (!head || !tail || !next) { free(head); free(tail); free(next); return -1; }
+  for (uint64_t i = 0; i < cap; i++) head[i] = -1;
+  for (int64_t i = 0; i < nb; i++) { /* create_probe_table: row -> Vec<idx>, ascending */
+    next[i] = -1;
+    uint64_t s = jrow_hash(build, n_keys, i) & (cap - 1);
+    for (;;) {
+      if (head[s] < 0) { head[s] = tail[s] = i; break; }
+      if (jrow_eq(build, head[s], build, i, n_keys)) { next[tail[s]] = i; tail[s] = i; break; }
+      s = (s + 1) & (cap - 1);
+    }
+  }
+  int64_t m = 0;
+  for (int64_t i = 0; i < np; i++) {
+    int64_t row = -1;
+    for (uint64_t s = jrow_hash(probe, n_keys, i) & (cap - 1); head[s] >= 0; s = (s + 1) & (cap - 1))
+      if (jrow_eq(build, head[s], probe, i, n_keys)) { row = head[s]; break; }
+    if (how >= 2) { if ((row >= 0) == (how == 2)) { if (out_left) out_left[m] = (uint32_t)i; m++; } continue; }
+    if (row < 0) { if (how == 1) { if (out_left) { out_left[m] = (uint32_t)i; out_right[m] = 0xFFFFFFFFu; } m++; } continue; }
+    for (; row >= 0; row = next[row]) {
+      if (out_left) { (swapped ? out_right : out_left)[m] = (uint32_t)i; (swapped ? out_left : out_right)[m] = (uint32_t)row; }
+      m++;
+    }
+  }
+  free(head); free(tail); free(next);
+  return m;
+}

@@ -83,6 +83,12 @@ int64_t orc_utf8_group_codes(const int64_t *offsets, const uint8_t *data, const 
  * right index 0xFFFFFFFF), 2 semi / 3 anti (single_keys_semi_anti.rs: left rows whose key is / is not among the right keys; out_right unused).  Pass out_left = NULL to get the pair count only.  Returns the number of pairs, -1 on error. */
 int64_t orc_hash_join(const plhip_column_t *left, const plhip_column_t *right, int how, uint32_t *out_left, uint32_t *out_right);
 
+/* _inner_join_multiple_keys / _left_join_multiple_keys (polars-ops/src/frame/join/hash_join/multiple_keys.rs:173-,251-): rows
+ * hashed over all key columns, equal when every column is equal (compare_df_rows2: floats by bit pattern after
+ * _to_physical_and_bit_repr, null == null); build side, probe order and `how` as orc_hash_join. */
+int64_t orc_hash_join_multi(const plhip_column_t *left, const plhip_column_t *right, int n_keys, int how, uint32_t *out_left,
+                            uint32_t *out_right);
+
 int orc_take_keys(const plhip_column_t *key, const orc_groups_t *g, void *out_values, uint8_t *out_valid);
 
 #ifdef __cplusplus

@@ -53,6 +53,8 @@ def lib():
         L.orc_utf8_group_codes.restype = C.c_int64
         L.orc_hash_join.argtypes = [P(_ffi.ColumnStruct), P(_ffi.ColumnStruct), C.c_int, C.c_void_p, C.c_void_p]
         L.orc_hash_join.restype = C.c_int64
+        L.orc_hash_join_multi.argtypes = [P(_ffi.ColumnStruct), P(_ffi.ColumnStruct), C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_hash_join_multi.restype = C.c_int64
         L.orc_take_keys.argtypes = [P(_ffi.ColumnStruct), P(_Groups), C.c_void_p, C.c_void_p]
         L.orc_sink_group_by.argtypes = [P(_ffi.ColumnStruct), P(_ffi.ColumnStruct), C.c_int, P(C.c_int), P(C.c_int), C.c_int, C.c_int,
                                         C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, P(C.c_int64)]
@@ -346,4 +348,16 @@ def hash_join(left: Column, right: Column, how: str = "inner"):
         raise ValueError("orc_hash_join: unsupported key columns")
     li, ri = np.zeros(max(m, 1), np.uint32), np.zeros(max(m, 1), np.uint32)
     lib().orc_hash_join(C.byref(ls), C.byref(rs), h, li.ctypes.data, ri.ctypes.data)
+    return li[:m], ri[:m]
+
+
+def hash_join_multi(left: list[Column], right: list[Column], how: str = "inner"):
+    """orc_hash_join_multi: the pairs of a join on several key columns (multiple_keys.rs), same conventions as hash_join."""
+    h = {"inner": 0, "left": 1, "semi": 2, "anti": 3}[how]
+    la, ra = _structs(left), _structs(right)
+    m = lib().orc_hash_join_multi(la, ra, len(left), h, None, None)
+    if m < 0:
+        raise ValueError("orc_hash_join_multi: unsupported key columns")
+    li, ri = np.zeros(max(m, 1), np.uint32), np.zeros(max(m, 1), np.uint32)
+    lib().orc_hash_join_multi(la, ra, len(left), h, li.ctypes.data, ri.ctypes.data)
     return li[:m], ri[:m]

@@ -217,6 +217,8 @@ def lib():
     L.plhip_dictionary_free.restype = None
     L.plhip_hash_join.argtypes = [P(ColumnStruct), P(ColumnStruct), i32, i32, P(vp)]
     L.plhip_hash_join.restype = i32
+    L.plhip_hash_join_multi.argtypes = [P(ColumnStruct), P(ColumnStruct), i32, i32, i32, P(vp)]
+    L.plhip_hash_join_multi.restype = i32
     L.plhip_join_num_rows.argtypes = [vp]
     L.plhip_join_num_rows.restype = C.c_int64
     L.plhip_join_buffers.argtypes = [vp, P(vp), P(vp), P(i32)]
@@ -293,5 +295,5 @@ EXPORTED_SYMBOLS = [
     "plhip_comm_unique_id", "plhip_comm_init_rccl", "plhip_comm_init_host", "plhip_comm_free", "plhip_group_by_agg_sharded",
     "plhip_sharded_last_stats", "plhip_group_by_agg_chunked",
     "plhip_utf8_encode", "plhip_dictionary_len", "plhip_dictionary_strings", "plhip_dictionary_free",
-    "plhip_set_timing_interval", "plhip_alloc_pinned", "plhip_free_pinned", "plhip_hash_join", "plhip_join_num_rows", "plhip_join_buffers", "plhip_join_free",
+    "plhip_set_timing_interval", "plhip_alloc_pinned", "plhip_free_pinned", "plhip_hash_join", "plhip_hash_join_multi", "plhip_join_num_rows", "plhip_join_buffers", "plhip_join_free",
 ]

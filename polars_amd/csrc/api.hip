@@ -2542,6 +2542,49 @@ int32_t plhip_hash_join(const plhip_column_t *left, const plhip_column_t *right,
   return PLHIP_OK;
 }
 
+int32_t plhip_hash_join_multi(const plhip_column_t *left_keys, const plhip_column_t *right_keys, int32_t n_keys, int32_t how,
+                              int32_t out_location, plhip_join_t **out) {
+  if (!left_keys || !right_keys || !out) return fail(PLHIP_ERR_INVALID, "NULL pointer");
+  *out = nullptr;
+  if (n_keys < 1 || n_keys > PLHIP_MAX_KEYS) return fail(PLHIP_ERR_INVALID, "bad number of key columns");
+  const int64_t nl = left_keys[0].length, nr = right_keys[0].length;
+  for (int i = 0; i < n_keys; i++) {
+    if (left_keys[i].dtype != right_keys[i].dtype) return fail(PLHIP_ERR_COMPUTE, "datatypes of join keys don't match");
+    if (!dtype_width(left_keys[i].dtype)) return fail(PLHIP_ERR_UNSUPPORTED_DTYPE, "unsupported join key dtype");
+    if (left_keys[i].length != nl || right_keys[i].length != nr) return fail(PLHIP_ERR_SHAPE_MISMATCH, "join key columns of one frame differ in length");
+  }
+  if (n_keys == 1 && !dt_is_float(left_keys[0].dtype)) return plhip_hash_join(left_keys, right_keys, how, out_location, out);
+  if (nl < 0 || nr < 0 || nl + nr > 0xFFFFFFFEll) return fail(PLHIP_ERR_COMPUTE, "more than u32::MAX rows (IdxSize is u32)");
+  int rc = ensure_ctx();
+  if (rc) return rc;
+  Ctx &c = g_ctx;
+  Staging st;
+  void *gid = nullptr;
+  HIP_TRY(hipMalloc(&gid, (size_t)std::max<int64_t>(nl + nr, 1) * 4));
+  st.owned.push_back(gid);
+  if (nl + nr > 0) {
+    // both relations' key tuples end to end, one dense id per distinct tuple: equal tuples of either side share an id
+    std::vector<plhip_column_t> cat(n_keys);
+    for (int i = 0; i < n_keys; i++) {
+      const plhip_column_t two[2] = {left_keys[i], right_keys[i]};
+      const plhip_chunked_column_t cc{two, 2, 0};
+      if ((rc = rechunk_column(cc, cat[i], st, c.stream))) return rc;
+    }
+    struct GroupsGuard { plhip_groups_t *p = nullptr; ~GroupsGuard() { delete p; } } gr;
+    if ((rc = plhip_group_tuples(cat.data(), n_keys, 0, PLHIP_DEVICE, &gr.p))) return rc;
+    const uint32_t *first = nullptr, *offsets = nullptr, *indices = nullptr;
+    int32_t loc = 0;
+    if ((rc = plhip_groups_buffers(gr.p, &first, &offsets, &indices, &loc))) return rc;
+    launch_csr_to_gid(offsets, indices, (uint32_t)gr.p->n_groups, nl + nr, (uint32_t *)gid, c.stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c.stream)); // (the CSR goes back with `gr`)
+  }
+  plhip_column_t lc{}, rcol{};
+  lc.values = gid; lc.length = nl; lc.dtype = PLHIP_U32; lc.location = PLHIP_DEVICE;
+  rcol.values = gid; rcol.offset = nl; rcol.length = nr; rcol.dtype = PLHIP_U32; rcol.location = PLHIP_DEVICE;
+  return plhip_hash_join(&lc, &rcol, how, out_location, out);
+}
+
 int64_t plhip_join_num_rows(const plhip_join_t *j) { return j ? j->n : -1; }
 
 int32_t plhip_join_buffers(const plhip_join_t *j, const uint32_t **left_idx, const uint32_t **right_idx, int32_t *location) {

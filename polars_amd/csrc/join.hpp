@@ -49,3 +49,5 @@ hipError_t join_scan(void *temp, size_t temp_bytes, const uint64_t *cnt, uint64_
 // out_build == nullptr (semi / anti): the probe rows with a non-zero count, each once
 void launch_join_fill(int64_t n, const uint32_t *gid, const uint64_t *pos, const uint32_t *offsets, const uint32_t *indices, uint32_t *out_probe,
                       uint32_t *out_build, hipStream_t s);
+// CSR groups (first / offsets / indices of plhip_group_tuples) -> the group of every row: gid[indices[j]] = g for offsets[g] <= j < offsets[g + 1]
+void launch_csr_to_gid(const uint32_t *offsets, const uint32_t *indices, uint32_t G, int64_t n, uint32_t *gid, hipStream_t s);

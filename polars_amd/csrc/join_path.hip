@@ -77,7 +77,20 @@ __global__ void __launch_bounds__(JOIN_BLOCK) k_join_fill(int64_t n, const uint3
   for (uint32_t j = o0; j < o1; j++) { out_probe[p0 + (j - o0)] = (uint32_t)i; out_build[p0 + (j - o0)] = indices[j]; }
 }
 
+__global__ void __launch_bounds__(JOIN_BLOCK) k_csr_to_gid(const uint32_t *offsets, const uint32_t *indices, uint32_t G, int64_t n, uint32_t *gid) {
+  const int64_t j = (int64_t)blockIdx.x * JOIN_BLOCK + threadIdx.x;
+  if (j >= n) return;
+  uint32_t lo = 0, hi = G; // the last g with offsets[g] <= j
+  while (hi - lo > 1) { const uint32_t mid = lo + ((hi - lo) >> 1); if ((int64_t)offsets[mid] <= j) lo = mid; else hi = mid; }
+  gid[indices[j]] = lo;
+}
+
 } // namespace
+
+void launch_csr_to_gid(const uint32_t *offsets, const uint32_t *indices, uint32_t G, int64_t n, uint32_t *gid, hipStream_t s) {
+  if (n <= 0 || !G) return;
+  hipLaunchKernelGGL(k_csr_to_gid, dim3((unsigned)((n + JOIN_BLOCK - 1) / JOIN_BLOCK)), dim3(JOIN_BLOCK), 0, s, offsets, indices, G, n, gid);
+}
 
 void launch_join_build(const JoinKey &build, const uint32_t *first, uint32_t G, const JoinTable &t, hipStream_t s) {
   if (!G) return;

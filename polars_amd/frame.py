@@ -168,13 +168,16 @@ class DataFrame:
             left_on = right_on = on
         if left_on is None or right_on is None:
             raise ValueError("you should pass the column to join on as an argument")
-        li, ri = join_indices(self.get_column(left_on), other.get_column(right_on), how)
+        lo = [left_on] if isinstance(left_on, str) else list(left_on)
+        ro = [right_on] if isinstance(right_on, str) else list(right_on)
+        li, ri = join_indices([self.get_column(n) for n in lo], [other.get_column(n) for n in ro], how)
+        right_on = ro
         out = [take(c, li, n) for n, c in self._cols.items()]
         if how in ("semi", "anti"):  # only the left frame's rows
             return DataFrame(out)
         taken = set(self._cols)
         for n, c in other._cols.items():
-            if n == right_on:
+            if n in right_on:
                 continue
             out.append(take(c, ri, n + suffix if n in taken else n))
         return DataFrame(out)

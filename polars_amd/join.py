@@ -15,22 +15,31 @@ from .column import Column
 NONE = 0xFFFFFFFF
 
 
-def join_indices(left: Column, right: Column, how: str = "inner") -> tuple[np.ndarray, np.ndarray]:
+def join_indices(left, right, how: str = "inner") -> tuple[np.ndarray, np.ndarray]:
     """(left_idx, right_idx) as host u32 arrays; right_idx == NONE where a left-join row has no match; semi / anti: the kept left
     rows and an empty right array."""
     L = _ffi.lib()
     h = {"inner": 0, "left": 1, "semi": 2, "anti": 3}.get(how)
     if h is None:
         raise _ffi.PlHipError(6, f"join kind {how!r} is not on the accelerated path (inner, left, semi, anti)")
-    for c in (left, right):
+    lefts = list(left) if isinstance(left, (list, tuple)) else [left]
+    rights = list(right) if isinstance(right, (list, tuple)) else [right]
+    if len(lefts) != len(rights) or not lefts:
+        raise _ffi.PlHipError(6, "the two sides of a join need the same number of key columns")
+    for c in lefts + rights:
         if c.location == _ffi.DEVICE and type(c.values).__module__.startswith("torch"):
             import torch
 
             torch.cuda.current_stream(c.values.device).synchronize()
             break
     handle = C.c_void_p()
-    ls, rs = left.struct(), right.struct()
-    _ffi.check(L.plhip_hash_join(C.byref(ls), C.byref(rs), h, _ffi.HOST, C.byref(handle)))
+    if len(lefts) == 1:
+        ls, rs = lefts[0].struct(), rights[0].struct()
+        _ffi.check(L.plhip_hash_join(C.byref(ls), C.byref(rs), h, _ffi.HOST, C.byref(handle)))
+    else:  # several key columns: hash_join/multiple_keys.rs
+        la = (_ffi.ColumnStruct * len(lefts))(*[c.struct() for c in lefts])
+        ra = (_ffi.ColumnStruct * len(rights))(*[c.struct() for c in rights])
+        _ffi.check(L.plhip_hash_join_multi(la, ra, len(lefts), h, _ffi.HOST, C.byref(handle)))
     try:
         m = L.plhip_join_num_rows(handle)
         lp, rp, loc = C.c_void_p(), C.c_void_p(), C.c_int32()

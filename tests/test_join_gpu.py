@@ -74,3 +74,33 @@ def test_frame_join():
     assert out.to_dict() == {"foo": [1, 2, 3], "bar": [6.0, 7.0, 8.0], "ham": [10, 20, 30], "apple": ["x", "y", None]}
     assert df.join(other, on="ham", how="semi").to_dict() == {"foo": [1, 2], "bar": [6.0, 7.0], "ham": [10, 20]}
     assert df.join(other, on="ham", how="anti").to_dict() == {"foo": [3], "bar": [8.0], "ham": [30]}
+
+
+@pytest.mark.parametrize("how", ["inner", "left", "semi", "anti"])
+def test_multi_key_join_matches_the_oracle(oracle, how):
+    """hash_join/multiple_keys.rs: (i64, f64 by bit pattern, nullable i32) key tuples, pair for pair against the oracle."""
+    rng = np.random.default_rng(21 + len(how))
+    for nl, nr in ((0, 7), (7, 0), (500, 500), (40_000, 15_000), (15_000, 40_000)):
+        def side(n):
+            a = rng.integers(0, 30, n).astype(np.int64)
+            b = rng.integers(0, 4, n).astype(np.float64) * 0.5
+            if n > 4:
+                b[:2] = [-0.0, 0.0]  # different bit patterns: different keys
+            c = rng.integers(0, 3, n).astype(np.int32)
+            cm = rng.random(n) >= 0.1
+            return [Column("a", a), Column("b", b), Column("c", c, cm)]
+        left, right = side(nl), side(nr)
+        gl, gr = join_indices(left, right, how)
+        wl, wr = oracle.hash_join_multi(left, right, how)
+        assert len(gl) == len(wl), (how, nl, nr)
+        assert np.array_equal(gl, wl) and (how in ("semi", "anti") or np.array_equal(gr, wr)), (how, nl, nr)
+
+
+def test_multi_key_frame_join_reference_shape():
+    """crates/polars/tests/it/core/joins.rs:167-185 (get_dfs) joined on two keys, a = foo and b = bar: rows (1, "a") x 1 and
+    (1, "c") x 2 x 2 -> 5 rows; strings go in as integer ids here."""
+    ids = {"a": 0, "b": 1, "c": 2}
+    df_a = pa.DataFrame({"a": np.array([1, 2, 1, 1], np.int32), "b": np.array([ids[x] for x in ["a", "b", "c", "c"]], np.int32), "c": np.array([0, 1, 2, 3], np.int64)})
+    df_b = pa.DataFrame({"foo": np.array([1, 1, 1], np.int32), "bar": np.array([ids[x] for x in ["a", "c", "c"]], np.int32), "ham": np.array([10, 11, 12], np.int64)})
+    out = df_a.join(df_b, left_on=["a", "b"], right_on=["foo", "bar"])
+    assert out.height == 5 and sorted(out["ham"].to_list()) == [10, 11, 11, 12, 12]

@@ -65,3 +65,29 @@ def test_against_brute_force(oracle):
                 assert li.tolist() == brute(lk, lm, rk, rm, how), (how, nl, nr)
             else:
                 assert list(zip(li.tolist(), ri.tolist())) == brute(lk, lm, rk, rm, how), (how, nl, nr)
+
+
+def test_multi_key_against_brute_force(oracle):
+    rng = np.random.default_rng(4)
+    for how in ("inner", "left", "semi", "anti"):
+        for nl, nr in ((0, 4), (30, 30), (90, 50), (50, 90)):
+            def side(n):
+                return rng.integers(0, 4, n).astype(np.int16), rng.integers(0, 3, n).astype(np.float32), rng.random(n) >= 0.2
+            la, lb, lm = side(nl)
+            ra, rb, rm = side(nr)
+            lt = [(int(a), float(b) if m else None) for a, b, m in zip(la, lb, lm)]
+            rt = [(int(a), float(b) if m else None) for a, b, m in zip(ra, rb, rm)]
+            if how in ("semi", "anti"):
+                want = [i for i in range(nl) if (lt[i] in rt) == (how == "semi")]
+            else:
+                swapped = how == "inner" and not (nl > nr)
+                pt, bt = (rt, lt) if swapped else (lt, rt)
+                want = []
+                for i, t in enumerate(pt):
+                    hits = [j for j, u in enumerate(bt) if u == t]
+                    if not hits and how == "left":
+                        want.append((i, 0xFFFFFFFF))
+                    want += [((j, i) if swapped else (i, j)) for j in hits]
+            li, ri = oracle.hash_join_multi([Column("a", la), Column("b", lb, lm)], [Column("a", ra), Column("b", rb, rm)], how)
+            got = li.tolist() if how in ("semi", "anti") else list(zip(li.tolist(), ri.tolist()))
+            assert got == want, (how, nl, nr)
