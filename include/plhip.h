@@ -476,7 +476,11 @@ typedef enum plhip_join_how {
   /* semi_anti_impl (single_keys_semi_anti.rs:33-): the left rows whose key occurs (SEMI) / does not occur (ANTI) among the right
    * keys, in left order, each once; right_idx comes back NULL */
   PLHIP_JOIN_SEMI = 2,
-  PLHIP_JOIN_ANTI = 3
+  PLHIP_JOIN_ANTI = 3,
+  /* hash_join_tuples_outer (single_keys_outer.rs:62-): build / probe sides as INNER; a probe row without a match yields (row, NONE);
+   * afterwards the build rows whose key no probe row had follow as (NONE, row) -- in the reference in its hash map's iteration
+   * order, here in the build side's group order: that tail's order is unspecified on both sides.  Either index may be NONE. */
+  PLHIP_JOIN_OUTER = 4
 } plhip_join_how_t;
 #define PLHIP_JOIN_NONE 0xFFFFFFFFu
 typedef struct plhip_join plhip_join_t;

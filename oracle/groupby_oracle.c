@@ -883,7 +883,7 @@ static uint64_t jkey(const plhip_column_t *c, int64_t i, int *valid) {
 int64_t orc_hash_join(const plhip_column_t *left, const plhip_column_t *right, int how, uint32_t *out_left, uint32_t *out_right) {
   if (left->dtype != right->dtype || left->dtype == PLHIP_F32 || left->dtype == PLHIP_F64) return -1;
   /* the shorter relation builds (mod.rs:42-58: `left_first = self.len() > other.len()`); left join: the right one */
-  const int swapped = how == 0 && !(left->length > right->length);
+  const int swapped = (how == 0 || how == 4) && !(left->length > right->length);
   const plhip_column_t *probe = swapped ? right : left, *build = swapped ? left : right;
   const int64_t nb = build->length, np = probe->length;
   /* build_tables (single_keys.rs:3-57): key -> Vec<idx>, rows pushed in ascending order.  Chained: head[slot] -> first row,
@@ -909,6 +909,9 @@ int64_t orc_hash_join(const plhip_column_t *left, const plhip_column_t *right, i
     }
   }
   /* probe_inner (single_keys_inner.rs:8-36) / the left join's probe: rows in order, matches in the table's order */
+  const int outer = how == 4;
+  const int swapped_o = outer && !(left->length > right->length);
+  uint8_t *hit = outer ? (uint8_t *)calloc((size_t)(nb > 0 ? nb : 1), 1) : NULL; /* probe_outer's tracker, per build row */
   int64_t m = 0;
   for (int64_t i = 0; i < np; i++) {
     int v;
@@ -922,19 +925,26 @@ int64_t orc_hash_join(const plhip_column_t *left, const plhip_column_t *right, i
         if (jkey(build, head[s], &hv) == k) { row = head[s]; break; }
       }
     }
-    if (how >= 2) { /* semi_anti_impl (single_keys_semi_anti.rs:33-): membership in the right keys; left rows in order, each once */
+    if (how == 2 || how == 3) { /* semi_anti_impl (single_keys_semi_anti.rs:33-): membership in the right keys; left rows in order, each once */
       if ((row >= 0) == (how == 2)) { if (out_left) out_left[m] = (uint32_t)i; m++; }
       continue;
     }
     if (row < 0) {
-      if (how == 1) { if (out_left) { out_left[m] = (uint32_t)i; out_right[m] = 0xFFFFFFFFu; } m++; }
+      if (how == 1 || outer) { if (out_left) { (swapped ? out_right : out_left)[m] = (uint32_t)i; (swapped ? out_left : out_right)[m] = 0xFFFFFFFFu; } m++; }
       continue;
     }
     for (; row >= 0; row = next[row]) {
+      if (hit) hit[row] = 1;
       if (out_left) { (swapped ? out_right : out_left)[m] = (uint32_t)i; (swapped ? out_left : out_right)[m] = (uint32_t)row; }
       m++;
     }
   }
+  if (outer) { /* the table's unmatched entries (single_keys_outer.rs:50-58; iteration order unspecified there: build-row order here) */
+    for (int64_t j = 0; j < nb; j++)
+      if (!hit[j]) { if (out_left) { (swapped ? out_left : out_right)[m] = (uint32_t)j; (swapped ? out_right : out_left)[m] = 0xFFFFFFFFu; } m++; }
+    free(hit);
+  }
+  (void)swapped_o;
   free(head); free(tail); free(next);
   return m;
 }
@@ -971,9 +981,11 @@ static int jrow_eq(const plhip_column_t *a, int64_t i, const plhip_column_t *b, 
 int64_t orc_hash_join_multi(const plhip_column_t *left, const plhip_column_t *right, int n_keys, int how, uint32_t *out_left,
                             uint32_t *out_right) {
   for (int k = 0; k < n_keys; k++) if (left[k].dtype != right[k].dtype) return -1;
-  const int swapped = how == 0 && !(left[0].length > right[0].length);
+  const int outer = how == 4;
+  const int swapped = (how == 0 || outer) && !(left[0].length > right[0].length);
   const plhip_column_t *probe = swapped ? right : left, *build = swapped ? left : right;
   const int64_t nb = build[0].length, np = probe[0].length;
+  uint8_t *hit = outer ? (uint8_t *)calloc((size_t)(nb > 0 ? nb : 1), 1) : NULL;
   uint64_t cap = 16;
   while (cap < (uint64_t)nb * 2 + 2) cap <<= 1;
   int64_t *head = (int64_t *)malloc(cap * sizeof(int64_t)), *tail = (int64_t *)malloc(cap * sizeof(int64_t));
@@ -994,12 +1006,21 @@ int64_t orc_hash_join_multi(const plhip_column_t *left, const plhip_column_t *ri
     int64_t row = -1;
     for (uint64_t s = jrow_hash(probe, n_keys, i) & (cap - 1); head[s] >= 0; s = (s + 1) & (cap - 1))
       if (jrow_eq(build, head[s], probe, i, n_keys)) { row = head[s]; break; }
-    if (how >= 2) { if ((row >= 0) == (how == 2)) { if (out_left) out_left[m] = (uint32_t)i; m++; } continue; }
-    if (row < 0) { if (how == 1) { if (out_left) { out_left[m] = (uint32_t)i; out_right[m] = 0xFFFFFFFFu; } m++; } continue; }
+    if (how == 2 || how == 3) { if ((row >= 0) == (how == 2)) { if (out_left) out_left[m] = (uint32_t)i; m++; } continue; }
+    if (row < 0) {
+      if (how == 1 || outer) { if (out_left) { (swapped ? out_right : out_left)[m] = (uint32_t)i; (swapped ? out_left : out_right)[m] = 0xFFFFFFFFu; } m++; }
+      continue;
+    }
     for (; row >= 0; row = next[row]) {
+      if (hit) hit[row] = 1;
       if (out_left) { (swapped ? out_right : out_left)[m] = (uint32_t)i; (swapped ? out_left : out_right)[m] = (uint32_t)row; }
       m++;
     }
+  }
+  if (outer) {
+    for (int64_t j = 0; j < nb; j++)
+      if (!hit[j]) { if (out_left) { (swapped ? out_left : out_right)[m] = (uint32_t)j; (swapped ? out_right : out_left)[m] = 0xFFFFFFFFu; } m++; }
+    free(hit);
   }
   free(head); free(tail); free(next);
   return m;

@@ -80,7 +80,9 @@ int64_t orc_utf8_group_codes(const int64_t *offsets, const uint8_t *data, const 
  * (single_keys_left.rs:109-) for one integer key column pair of the same dtype: build_tables over the shorter relation
  * (inner; det_hash_prone_order!, hash_join/mod.rs:42-58) or over the right one (left join), key -> rows in ascending
  * order; the other relation probes in row order.  Keys are Option<T>: null == null.  how: 0 inner, 1 left (no match:
- * right index 0xFFFFFFFF), 2 semi / 3 anti (single_keys_semi_anti.rs: left rows whose key is / is not among the right keys; out_right unused).  Pass out_left = NULL to get the pair count only.  Returns the number of pairs, -1 on error. */
+ * right index 0xFFFFFFFF), 2 semi / 3 anti (single_keys_semi_anti.rs: left rows whose key is / is not among the right keys; out_right unused),
+ * 4 outer (single_keys_outer.rs: as inner plus (row, None) for unmatched probe rows, then (None, row) for the build rows nobody
+ * matched -- in build-row order here, hash-map order in the reference).  Pass out_left = NULL to get the pair count only.  Returns the number of pairs, -1 on error. */
 int64_t orc_hash_join(const plhip_column_t *left, const plhip_column_t *right, int how, uint32_t *out_left, uint32_t *out_right);
 
 /* _inner_join_multiple_keys / _left_join_multiple_keys (polars-ops/src/frame/join/hash_join/multiple_keys.rs:173-,251-): rows

@@ -341,7 +341,7 @@ def utf8_group_codes(offsets: np.ndarray, data: np.ndarray, valid: np.ndarray | 
 
 def hash_join(left: Column, right: Column, how: str = "inner"):
     """orc_hash_join: (left_idx, right_idx) u32 arrays in the reference's pair order; right_idx 0xFFFFFFFF = no match (left join)."""
-    h = {"inner": 0, "left": 1, "semi": 2, "anti": 3}[how]
+    h = {"inner": 0, "left": 1, "semi": 2, "anti": 3, "outer": 4}[how]
     ls, rs = left.struct(), right.struct()
     m = lib().orc_hash_join(C.byref(ls), C.byref(rs), h, None, None)
     if m < 0:
@@ -353,7 +353,7 @@ def hash_join(left: Column, right: Column, how: str = "inner"):
 
 def hash_join_multi(left: list[Column], right: list[Column], how: str = "inner"):
     """orc_hash_join_multi: the pairs of a join on several key columns (multiple_keys.rs), same conventions as hash_join."""
-    h = {"inner": 0, "left": 1, "semi": 2, "anti": 3}[how]
+    h = {"inner": 0, "left": 1, "semi": 2, "anti": 3, "outer": 4}[how]
     la, ra = _structs(left), _structs(right)
     m = lib().orc_hash_join_multi(la, ra, len(left), h, None, None)
     if m < 0:

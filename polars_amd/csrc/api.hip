@@ -2460,7 +2460,8 @@ struct plhip_join {
 int32_t plhip_hash_join(const plhip_column_t *left, const plhip_column_t *right, int32_t how, int32_t out_location, plhip_join_t **out) {
   if (!left || !right || !out) return fail(PLHIP_ERR_INVALID, "NULL pointer");
   *out = nullptr;
-  if (how < PLHIP_JOIN_INNER || how > PLHIP_JOIN_ANTI) return fail(PLHIP_ERR_INVALID, "bad join kind");
+  if (how < PLHIP_JOIN_INNER || how > PLHIP_JOIN_OUTER) return fail(PLHIP_ERR_INVALID, "bad join kind");
+  const bool outer = how == PLHIP_JOIN_OUTER;
   const bool membership = how == PLHIP_JOIN_SEMI || how == PLHIP_JOIN_ANTI;
   if (out_location != PLHIP_HOST && out_location != PLHIP_DEVICE) return fail(PLHIP_ERR_INVALID, "bad output location");
   if (left->dtype != right->dtype) return fail(PLHIP_ERR_COMPUTE, "datatypes of join keys don't match");
@@ -2473,7 +2474,7 @@ int32_t plhip_hash_join(const plhip_column_t *left, const plhip_column_t *right,
   DevCol dl, dr;
   if ((rc = stage_column(*left, dl, st, c.stream)) || (rc = stage_column(*right, dr, st, c.stream))) return rc;
   // the shorter relation builds (hash_join/mod.rs:42-58); a left join always probes with the left one
-  const bool swapped = how == PLHIP_JOIN_INNER && !(left->length > right->length);
+  const bool swapped = (how == PLHIP_JOIN_INNER || outer) && !(left->length > right->length);
   const DevCol &dp = swapped ? dr : dl, &db = swapped ? dl : dr;
   const uint32_t w = (uint32_t)dtype_width(left->dtype);
   const int64_t n = dp.length, nb = db.length;
@@ -2500,18 +2501,32 @@ int32_t plhip_hash_join(const plhip_column_t *left, const plhip_column_t *right,
   launch_join_build(KB, first, (uint32_t)G, T, c.stream);
   HIP_TRY(hipGetLastError());
   // ---- probe: count, scan, fill -----------------------------------------------------------------------------------------
-  const size_t g_bytes = ((size_t)n * 4 + 255) & ~(size_t)255, c_bytes = ((size_t)(n + 1) * 8 + 255) & ~(size_t)255, tb = join_scan_temp_bytes(n);
-  HIP_TRY(c.str_a.reserve(g_bytes + 2 * c_bytes + tb + 256));
+  const size_t g_bytes = ((size_t)n * 4 + 255) & ~(size_t)255, c_bytes = ((size_t)(n + 1) * 8 + 255) & ~(size_t)255;
+  const size_t tb = std::max(join_scan_temp_bytes(n), join_scan_temp_bytes((int64_t)G));
+  // outer join: matched flags per build group, and the count / position arrays of the tail (the unmatched groups' rows)
+  const size_t m_bytes = outer ? (((size_t)G * 4 + 255) & ~(size_t)255) + 256 : 0, t_bytes = outer ? (((size_t)(G + 1) * 8 + 255) & ~(size_t)255) : 0;
+  HIP_TRY(c.str_a.reserve(g_bytes + 2 * c_bytes + tb + m_bytes + 2 * t_bytes + 256));
   uint32_t *gid = (uint32_t *)c.str_a.p;
   uint64_t *cnt = (uint64_t *)((uint8_t *)c.str_a.p + g_bytes), *pos = (uint64_t *)((uint8_t *)c.str_a.p + g_bytes + c_bytes);
   void *tmp = (uint8_t *)c.str_a.p + g_bytes + 2 * c_bytes;
-  launch_join_count(KP, T, offsets, how, gid, cnt, c.stream);
+  uint32_t *matched = (uint32_t *)((uint8_t *)tmp + tb);
+  uint64_t *tcnt = (uint64_t *)((uint8_t *)matched + m_bytes), *tpos = (uint64_t *)((uint8_t *)matched + m_bytes + t_bytes);
+  if (outer) HIP_TRY(hipMemsetAsync(matched, 0, m_bytes, c.stream));
+  launch_join_count(KP, T, offsets, how, gid, cnt, outer ? matched : nullptr, c.stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(join_scan(tmp, tb, cnt, pos, n, c.stream));
   HIP_TRY(hipMemcpyAsync(c.host_flags, pos + n, 8, hipMemcpyDeviceToHost, c.stream));
+  if (outer) {
+    launch_join_tail_count((uint32_t)G, matched, offsets, tcnt, c.stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(join_scan(tmp, tb, tcnt, tpos, (int64_t)G, c.stream));
+    HIP_TRY(hipMemcpyAsync(c.host_flags + 2, tpos + G, 8, hipMemcpyDeviceToHost, c.stream));
+  }
   HIP_TRY(hipStreamSynchronize(c.stream));
-  uint64_t total = 0;
-  memcpy(&total, c.host_flags, 8);
+  uint64_t total = 0, head = 0;
+  memcpy(&head, c.host_flags, 8);
+  total = head;
+  if (outer) { uint64_t tail = 0; memcpy(&tail, c.host_flags + 2, 8); total += tail; }
   if (total > 0xFFFFFFFEull) return fail(PLHIP_ERR_COMPUTE, "the join yields more than u32::MAX rows (IdxSize is u32)");
   std::unique_ptr<plhip_join> J(new (std::nothrow) plhip_join());
   if (!J) return fail(PLHIP_ERR_OOM, "host allocation failed");
@@ -2527,6 +2542,10 @@ int32_t plhip_hash_join(const plhip_column_t *left, const plhip_column_t *right,
   }
   launch_join_fill(n, gid, pos, offsets, indices, out_probe, out_build, c.stream);
   HIP_TRY(hipGetLastError());
+  if (outer) { // the build rows nobody matched, behind the probe rows' pairs
+    launch_join_tail_fill((uint32_t)G, matched, tpos, offsets, indices, out_probe + head, out_build + head, c.stream);
+    HIP_TRY(hipGetLastError());
+  }
   HIP_TRY(hipStreamSynchronize(c.stream));
   c.strategy = "hash_join";
   if (out_location == PLHIP_HOST) {

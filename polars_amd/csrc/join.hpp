@@ -43,7 +43,14 @@ struct JoinTable {
 void launch_join_build(const JoinKey &build, const uint32_t *first, uint32_t G, const JoinTable &t, hipStream_t s);
 // gid[i] = the probe row's group or JOIN_NONE; cnt[i] = rows it yields; cnt[n] = 0.  mode 0: one per match (inner); 1: at least one
 // (left); 2: one if matched (semi); 3: one if not matched (anti; gid is then reported as JOIN_NONE so that the fill writes the row alone)
-void launch_join_count(const JoinKey &probe, const JoinTable &t, const uint32_t *offsets, int mode, uint32_t *gid, uint64_t *cnt, hipStream_t s);
+// mode 4 (outer): as 1, and matched[g] = 1 for every group a probe row found (`matched`: G words, zeroed)
+void launch_join_count(const JoinKey &probe, const JoinTable &t, const uint32_t *offsets, int mode, uint32_t *gid, uint64_t *cnt, uint32_t *matched,
+                       hipStream_t s);
+// outer join's tail: the rows of the build groups no probe row matched.  cnt[g] = rows of group g if unmatched, cnt[G] = 0;
+// after the scan the fill writes (JOIN_NONE, row) pairs behind the probe rows' pairs
+void launch_join_tail_count(uint32_t G, const uint32_t *matched, const uint32_t *offsets, uint64_t *cnt, hipStream_t s);
+void launch_join_tail_fill(uint32_t G, const uint32_t *matched, const uint64_t *pos, const uint32_t *offsets, const uint32_t *indices,
+                           uint32_t *out_probe, uint32_t *out_build, hipStream_t s);
 size_t join_scan_temp_bytes(int64_t n);
 hipError_t join_scan(void *temp, size_t temp_bytes, const uint64_t *cnt, uint64_t *pos, int64_t n, hipStream_t s); // exclusive, n + 1 entries
 // out_build == nullptr (semi / anti): the probe rows with a non-zero count, each once

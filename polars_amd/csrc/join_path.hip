@@ -39,7 +39,8 @@ __global__ void __launch_bounds__(JOIN_BLOCK) k_join_build(JoinKey b, const uint
     if (atomicCAS(&t.slots[s].used, 0u, 1u) == 0u) { t.slots[s].key = key; t.slots[s].val = g; return; } // the groups' keys are distinct: nothing to compare
 }
 
-__global__ void __launch_bounds__(JOIN_BLOCK) k_join_count(JoinKey p, JoinTable t, const uint32_t *offsets, int mode, uint32_t *gid, uint64_t *cnt) {
+__global__ void __launch_bounds__(JOIN_BLOCK) k_join_count(JoinKey p, JoinTable t, const uint32_t *offsets, int mode, uint32_t *gid, uint64_t *cnt,
+                                                           uint32_t *matched) {
   const int64_t i = (int64_t)blockIdx.x * JOIN_BLOCK + threadIdx.x;
   if (i > p.n) return;
   if (i == p.n) { cnt[i] = 0; return; }
@@ -53,14 +54,15 @@ __global__ void __launch_bounds__(JOIN_BLOCK) k_join_count(JoinKey p, JoinTable 
       if ((((uint64_t)e.y << 32) | e.x) == key) { g = e.z; break; }
     }
   }
-  if (mode >= 2) { // semi / anti: membership only
+  if (mode == 2 || mode == 3) { // semi / anti: membership only
     const bool keep = (g != JOIN_NONE) == (mode == 2);
     gid[i] = JOIN_NONE;
     cnt[i] = keep ? 1ull : 0ull;
     return;
   }
   gid[i] = g;
-  cnt[i] = g != JOIN_NONE ? (uint64_t)(offsets[g + 1] - offsets[g]) : (mode == 1 ? 1ull : 0ull);
+  if (mode == 4 && g != JOIN_NONE) matched[g] = 1u; // (every writer stores the same value)
+  cnt[i] = g != JOIN_NONE ? (uint64_t)(offsets[g + 1] - offsets[g]) : (mode == 1 || mode == 4 ? 1ull : 0ull);
 }
 
 __global__ void __launch_bounds__(JOIN_BLOCK) k_join_fill(int64_t n, const uint32_t *gid, const uint64_t *pos, const uint32_t *offsets,
@@ -75,6 +77,21 @@ __global__ void __launch_bounds__(JOIN_BLOCK) k_join_fill(int64_t n, const uint3
   }
   const uint32_t o0 = offsets[g], o1 = offsets[g + 1];
   for (uint32_t j = o0; j < o1; j++) { out_probe[p0 + (j - o0)] = (uint32_t)i; out_build[p0 + (j - o0)] = indices[j]; }
+}
+
+__global__ void __launch_bounds__(JOIN_BLOCK) k_join_tail_count(uint32_t G, const uint32_t *matched, const uint32_t *offsets, uint64_t *cnt) {
+  const uint32_t g = blockIdx.x * JOIN_BLOCK + threadIdx.x;
+  if (g > G) return;
+  cnt[g] = (g < G && !matched[g]) ? (uint64_t)(offsets[g + 1] - offsets[g]) : 0ull;
+}
+
+__global__ void __launch_bounds__(JOIN_BLOCK) k_join_tail_fill(uint32_t G, const uint32_t *matched, const uint64_t *pos, const uint32_t *offsets,
+                                                               const uint32_t *indices, uint32_t *out_probe, uint32_t *out_build) {
+  const uint32_t g = blockIdx.x * JOIN_BLOCK + threadIdx.x;
+  if (g >= G || matched[g]) return;
+  const uint64_t p0 = pos[g];
+  const uint32_t o0 = offsets[g], o1 = offsets[g + 1];
+  for (uint32_t j = o0; j < o1; j++) { out_probe[p0 + (j - o0)] = JOIN_NONE; out_build[p0 + (j - o0)] = indices[j]; }
 }
 
 __global__ void __launch_bounds__(JOIN_BLOCK) k_csr_to_gid(const uint32_t *offsets, const uint32_t *indices, uint32_t G, int64_t n, uint32_t *gid) {
@@ -97,8 +114,20 @@ void launch_join_build(const JoinKey &build, const uint32_t *first, uint32_t G, 
   hipLaunchKernelGGL(k_join_build, dim3((G + JOIN_BLOCK - 1) / JOIN_BLOCK), dim3(JOIN_BLOCK), 0, s, build, first, G, t);
 }
 
-void launch_join_count(const JoinKey &probe, const JoinTable &t, const uint32_t *offsets, int mode, uint32_t *gid, uint64_t *cnt, hipStream_t s) {
-  hipLaunchKernelGGL(k_join_count, dim3((unsigned)((probe.n + 1 + JOIN_BLOCK - 1) / JOIN_BLOCK)), dim3(JOIN_BLOCK), 0, s, probe, t, offsets, mode, gid, cnt);
+void launch_join_count(const JoinKey &probe, const JoinTable &t, const uint32_t *offsets, int mode, uint32_t *gid, uint64_t *cnt, uint32_t *matched,
+                       hipStream_t s) {
+  hipLaunchKernelGGL(k_join_count, dim3((unsigned)((probe.n + 1 + JOIN_BLOCK - 1) / JOIN_BLOCK)), dim3(JOIN_BLOCK), 0, s, probe, t, offsets, mode, gid, cnt,
+                     matched);
+}
+
+void launch_join_tail_count(uint32_t G, const uint32_t *matched, const uint32_t *offsets, uint64_t *cnt, hipStream_t s) {
+  hipLaunchKernelGGL(k_join_tail_count, dim3((G + 1 + JOIN_BLOCK - 1) / JOIN_BLOCK), dim3(JOIN_BLOCK), 0, s, G, matched, offsets, cnt);
+}
+
+void launch_join_tail_fill(uint32_t G, const uint32_t *matched, const uint64_t *pos, const uint32_t *offsets, const uint32_t *indices,
+                           uint32_t *out_probe, uint32_t *out_build, hipStream_t s) {
+  if (!G) return;
+  hipLaunchKernelGGL(k_join_tail_fill, dim3((G + JOIN_BLOCK - 1) / JOIN_BLOCK), dim3(JOIN_BLOCK), 0, s, G, matched, pos, offsets, indices, out_probe, out_build);
 }
 
 size_t join_scan_temp_bytes(int64_t n) {

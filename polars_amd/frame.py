@@ -159,7 +159,7 @@ class DataFrame:
 
     def join(self, other: "DataFrame", on: str | None = None, how: str = "inner", *, left_on: str | None = None,
              right_on: str | None = None, suffix: str = "_right") -> "DataFrame":
-        """DataFrame.join on one integer key, `how` = 'inner' | 'left' | 'semi' | 'anti' (py-polars/polars/dataframe/frame.py:5856): the index
+        """DataFrame.join on one integer key, `how` = 'inner' | 'left' | 'semi' | 'anti' | 'outer' (py-polars/polars/dataframe/frame.py:5856): the index
         pairs come from plhip_hash_join in the reference's order; the payload gather (`_finish_join`: left columns, then the
         right ones without the key, clashing names suffixed) runs on the host."""
         from .join import join_indices, take
@@ -175,6 +175,17 @@ class DataFrame:
         out = [take(c, li, n) for n, c in self._cols.items()]
         if how in ("semi", "anti"):  # only the left frame's rows
             return DataFrame(out)
+        if how == "outer":  # the key columns are coalesced: the right frame's key where the left side has no row
+            from .join import NONE
+
+            for ln, rn in zip(lo, ro):
+                i = list(self._cols).index(ln)
+                lcol, rcol = out[i], take(other.get_column(rn), ri, ln)
+                lv, rv = lcol.to_list(), rcol.to_list()
+                merged = [r if a == NONE else l for l, r, a in zip(lv, rv, li.tolist())]
+                dt = _ffi.code_np_dtype(self.get_column(ln).dtype)
+                mask = np.array([x is not None for x in merged], dtype=bool)
+                out[i] = Column(ln, np.array([0 if x is None else x for x in merged], dtype=dt), None if mask.all() else mask)
         taken = set(self._cols)
         for n, c in other._cols.items():
             if n in right_on:

@@ -19,9 +19,9 @@ def join_indices(left, right, how: str = "inner") -> tuple[np.ndarray, np.ndarra
     """(left_idx, right_idx) as host u32 arrays; right_idx == NONE where a left-join row has no match; semi / anti: the kept left
     rows and an empty right array."""
     L = _ffi.lib()
-    h = {"inner": 0, "left": 1, "semi": 2, "anti": 3}.get(how)
+    h = {"inner": 0, "left": 1, "semi": 2, "anti": 3, "outer": 4}.get(how)
     if h is None:
-        raise _ffi.PlHipError(6, f"join kind {how!r} is not on the accelerated path (inner, left, semi, anti)")
+        raise _ffi.PlHipError(6, f"join kind {how!r} is not on the accelerated path (inner, left, semi, anti, outer)")
     lefts = list(left) if isinstance(left, (list, tuple)) else [left]
     rights = list(right) if isinstance(right, (list, tuple)) else [right]
     if len(lefts) != len(rights) or not lefts:

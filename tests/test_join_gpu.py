@@ -104,3 +104,36 @@ def test_multi_key_frame_join_reference_shape():
     df_b = pa.DataFrame({"foo": np.array([1, 1, 1], np.int32), "bar": np.array([ids[x] for x in ["a", "c", "c"]], np.int32), "ham": np.array([10, 11, 12], np.int64)})
     out = df_a.join(df_b, left_on=["a", "b"], right_on=["foo", "bar"])
     assert out.height == 5 and sorted(out["ham"].to_list()) == [10, 11, 11, 12, 12]
+
+
+@pytest.mark.parametrize("multi", [False, True], ids=["one_key", "key_tuples"])
+def test_outer_join(oracle, multi):
+    """hash_join_tuples_outer (single_keys_outer.rs:62-): the probe rows' pairs in the reference's order, then the unmatched build
+    rows -- whose order the reference leaves to its hash map, so that tail is compared as a set."""
+    NONE = 0xFFFFFFFF
+    rng = np.random.default_rng(31 + multi)
+    for nl, nr in ((0, 6), (6, 0), (300, 300), (30_000, 12_000), (12_000, 30_000)):
+        def side(n, lo, hi):
+            a = rng.integers(lo, hi, n).astype(np.int32)
+            am = rng.random(n) >= 0.05
+            cols = [Column("a", a, am)]
+            if multi:
+                cols.append(Column("b", rng.integers(0, 3, n).astype(np.int64)))
+            return cols
+        left, right = side(nl, 0, 4000), side(nr, 2000, 6000)
+        gl, gr = join_indices(left if multi else left[0], right if multi else right[0], "outer")
+        wl, wr = (oracle.hash_join_multi(left, right, "outer") if multi else oracle.hash_join(left[0], right[0], "outer"))
+        assert len(gl) == len(wl), (nl, nr)
+        probe = 1 if not (nl > nr) else 0  # the longer relation probes (the right one on a tie)
+        gp, wp = list(zip(gl.tolist(), gr.tolist())), list(zip(wl.tolist(), wr.tolist()))
+        assert [p for p in gp if p[probe] != NONE] == [p for p in wp if p[probe] != NONE], (nl, nr)
+        gt, wt = [p for p in gp if p[probe] == NONE], [p for p in wp if p[probe] == NONE]
+        assert gp[len(gp) - len(gt):] == gt and sorted(gt) == sorted(wt), (nl, nr)  # the tail sits behind the probe rows' pairs
+
+
+def test_outer_join_reference_answer_and_frame():
+    """test_join_sorted_fast_paths_null's outer answer (py-polars/tests/unit/operations/test_join.py:593-596) through the frame API."""
+    df1 = pa.DataFrame({"x": np.array([0, 0, 1], np.int64)})
+    df2 = pa.DataFrame({"x": (np.array([0, 0], np.int64), np.array([True, False])), "y": np.array([0, 1], np.int64)})
+    out = df1.join(df2, on="x", how="outer")
+    assert out.to_dict() == {"x": [0, 0, 1, None], "y": [0, 0, None, 1]}

@@ -25,7 +25,9 @@ def check_case(case, dt, join_fn):
         return
     got = {}
     for name, vals in case["left"].items():
-        got[name] = [vals[i] for i in li]
+        got[name] = [None if i == 0xFFFFFFFF else vals[i] for i in li]
+        if name == on and case["how"] == "outer":  # coalesced key
+            got[name] = [case["right"][on][j] if i == 0xFFFFFFFF else vals[i] for i, j in zip(li, ri)]
     for name, vals in case["right"].items():
         if name != on and case["how"] not in ("semi", "anti"):
             got[name] = [None if i == 0xFFFFFFFF else vals[i] for i in ri]
