@@ -170,7 +170,13 @@ class DataFrame:
             raise ValueError("you should pass the column to join on as an argument")
         lo = [left_on] if isinstance(left_on, str) else list(left_on)
         ro = [right_on] if isinstance(right_on, str) else list(right_on)
-        li, ri = join_indices([self.get_column(n) for n in lo], [other.get_column(n) for n in ro], how)
+        lk, rk = [self.get_column(n) for n in lo], [other.get_column(n) for n in ro]
+        for i in range(len(lk)):  # string keys: both sides' codes under one dictionary, built on the device
+            if type(lk[i]).__name__ == "Utf8Column" and type(rk[i]).__name__ == "Utf8Column":
+                from .strings import encode_together
+
+                lk[i], rk[i] = encode_together(lk[i], rk[i])
+        li, ri = join_indices(lk, rk, how)
         right_on = ro
         out = [take(c, li, n) for n, c in self._cols.items()]
         if how in ("semi", "anti"):  # only the left frame's rows
@@ -183,6 +189,11 @@ class DataFrame:
                 lcol, rcol = out[i], take(other.get_column(rn), ri, ln)
                 lv, rv = lcol.to_list(), rcol.to_list()
                 merged = [r if a == NONE else l for l, r, a in zip(lv, rv, li.tolist())]
+                if type(self.get_column(ln)).__name__ == "Utf8Column":
+                    from .strings import DecodedColumn
+
+                    out[i] = DecodedColumn(ln, merged)
+                    continue
                 dt = _ffi.code_np_dtype(self.get_column(ln).dtype)
                 mask = np.array([x is not None for x in merged], dtype=bool)
                 out[i] = Column(ln, np.array([0 if x is None else x for x in merged], dtype=dt), None if mask.all() else mask)

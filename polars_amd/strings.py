@@ -150,3 +150,30 @@ class DecodedColumn:
 
     def __repr__(self) -> str:
         return f"DecodedColumn({self.name!r}, utf8, len={len(self._values)})"
+
+
+def concat(cols: list) -> Utf8Column:
+    """The columns' logical slices end to end as one host LargeUtf8 column (the join's key columns share one dictionary)."""
+    offs, datas, masks, base, any_null = [np.zeros(1, np.int64)], [], [], 0, False
+    for c in cols:
+        o = c.offsets[c.offset:c.offset + c.length + 1]
+        datas.append(c.data[o[0]:o[-1]])
+        offs.append(o[1:] - o[0] + base)
+        base += int(o[-1] - o[0])
+        m = c.valid_mask()
+        any_null |= m is not None
+        masks.append(np.ones(c.length, bool) if m is None else m)
+    return Utf8Column(cols[0].name, np.concatenate(offs), np.concatenate(datas) if datas else np.zeros(0, np.uint8),
+                      np.concatenate(masks) if any_null else None)
+
+
+def encode_together(left: Utf8Column, right: Utf8Column):
+    """Codes of two string columns under ONE dictionary (equal strings of either column get equal codes): views of the encoded
+    concatenation.  What a join on string keys needs (the reference hashes both sides' bytes with one RandomState)."""
+    both = encode(concat([left, right]))
+    import copy
+
+    lc, rc = copy.copy(both), copy.copy(both)
+    lc.offset, lc.length = 0, left.length
+    rc.offset, rc.length = left.length, right.length
+    return lc, rc

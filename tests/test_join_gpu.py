@@ -137,3 +137,23 @@ def test_outer_join_reference_answer_and_frame():
     df2 = pa.DataFrame({"x": (np.array([0, 0], np.int64), np.array([True, False])), "y": np.array([0, 1], np.int64)})
     out = df1.join(df2, on="x", how="outer")
     assert out.to_dict() == {"x": [0, 0, 1, None], "y": [0, 0, None, 1]}
+
+
+def test_string_key_join_reference_docstring():
+    """DataFrame.join's own examples (py-polars/polars/dataframe/frame.py:5913-5979): a string key on both sides, every join kind.
+    Both key columns are encoded under one dictionary on the device, the pairs come from plhip_hash_join on the codes.  (The outer
+    example's two unmatched rows are compared as a set of rows: the reference prints them in its hash map's order.)"""
+    import json
+    import os
+
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_join_known_answers.json")))["docstring_frames"]
+    mk = lambda d: pa.DataFrame({k: (np.array(v, np.int64) if isinstance(v[0], int) else np.array(v) if isinstance(v[0], float) else v) for k, v in d.items()})
+    df, other = mk(gold["df"]), mk(gold["other"])
+    for how, want in gold["results"].items():
+        out = df.join(other, on="ham", how=how).to_dict()
+        rows = lambda d: sorted(zip(*[[repr(x) for x in d[c]] for c in want]))
+        assert list(out) == list(want), how
+        if how == "outer":
+            assert rows(out) == rows(want), how
+        else:
+            assert out == want, how
