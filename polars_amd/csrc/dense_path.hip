@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "dense.hpp"
 #include "device.hpp"
@@ -609,6 +610,8 @@ static void dense_merge_shape(const Plan &p, uint32_t groups, uint32_t &gb, uint
   // gb groups per workgroup (about 512 workgroups when there are that many groups), W >= 4 ways of gb / 4 threads each
   gb = 16;
   while (gb < 1024 && (groups + gb - 1) / gb > 512) gb <<= 1;
+  static const int gb_env = getenv("PLHIP_MERGE_GB") ? atoi(getenv("PLHIP_MERGE_GB")) : 0; // (experiments)
+  if (gb_env >= 16 && gb_env <= 1024 && (gb_env & (gb_env - 1)) == 0) gb = (uint32_t)gb_env;
   W = DENSE_BLOCK / (gb / 4);
   if (W > 64) W = 64;
   while (W > 4 && (size_t)p.n_accs * W * gb * 8 + gb * 4 > 64 * 1024) W >>= 1; // the ways' partial results of every accumulator live in LDS
