@@ -85,7 +85,7 @@ def _host_columns(cols):
     return out
 
 
-def cpu_baseline(tensors, keys, vals, aggs, gpu_frame, budget_s=10.0):
+def cpu_baseline(tensors, keys, vals, aggs, gpu_frame, budget_s=10.0, path_b=True):
     """The oracle (C restatement of the reference algorithm: P = pow2 <= threads partitions, every thread scans
     all keys, per-group index lists, gather-fold aggregation, crates/polars-core/src/frame/group_by/hashing.rs:
     182-243 + aggregations/mod.rs) timed on this box's host cores: whole passes over the same rows for about
@@ -106,7 +106,7 @@ def cpu_baseline(tensors, keys, vals, aggs, gpu_frame, budget_s=10.0):
     base = {"value": n * passes / dt, "unit": "rows/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
             "sample": f"{passes} whole passes over the same {n} rows ({dt:.1f} s)",
             "path": "A: partitioned hash maps of row-index lists, then gather-fold per group (hashing.rs:182-243 + aggregations/mod.rs)"}
-    if len(hk) == 1:  # path B: the streaming sink's accumulators, timed on the same rows
+    if len(hk) == 1 and path_b:  # path B: the streaming sink's accumulators, timed on the same rows
         p2, t1 = 0, time.perf_counter()
         while True:
             g2 = orc.sink_group_by(hk[0], hv, aggs, n_threads=threads, outputs=False)
@@ -207,7 +207,7 @@ def parity_check(keys, vals, aggs, want, gpu_frame):
             "against": "oracle (C restatement), same rows, canonical key sort"}
 
 
-def measured_traffic(workload, n_rows, strategy):
+def measured_traffic(key):
     """HBM bytes of the WHOLE query (summed over its kernels, per launch) from the rocprofv3 --pmc passes kept under
     profiles/ (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE; scripts/prof_summary.py
     writes the entry together with the per-kernel figures); None if no such measurement is on file for this
@@ -216,7 +216,7 @@ def measured_traffic(workload, n_rows, strategy):
     if not f.exists():
         return None, None
     try:
-        t = json.loads(f.read_text()).get(f"{workload}:{n_rows}:{strategy}")
+        t = json.loads(f.read_text()).get(key)
         if not t:
             return None, None
         return t["hbm_bytes"], {k: int(v["fetch_bytes"] + v["write_bytes"]) for k, v in t.get("kernels", {}).items()}
@@ -224,95 +224,223 @@ def measured_traffic(workload, n_rows, strategy):
         return None, None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=0, help="default 200 (c3: 20, c5: 5)")
-    ap.add_argument("--warmup", type=int, default=-1, help="default 10 (c3: 3, c5: 1)")
-    ap.add_argument("--workload", default="q3", choices=sorted(WORKLOADS))
-    ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default 1e7; c3: 1e8; c5: 1e9)")
-    ap.add_argument("--total-rows", type=int, default=0,
-                    help="strong scaling (BASELINE configs[3]): the job's rows, every rank gets total / N of them")
-    ap.add_argument("--strategy", default="auto")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-dense", action="store_true", help="do not declare a single Categorical key's codes dense (PLHIP_FLAG_KEYS_DENSE)")
-    ap.add_argument("--no-hint", action="store_true",
-                    help="do not pass the category count of categorical keys (id1..id3) as n_groups_hint")
-    ap.add_argument("--na", action="store_true", help="db-benchmark's NA variant (groupby-datagen.R:30-44): 5 %% of the distinct key values "
-                                                      "nulled, 5 %% NA values, as validity bitmaps")
-    args = ap.parse_args()
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: this process starts the N ranks itself, one per
+    GPU, and never touches the GPU (no torch import, no HIP call here: a process that has initialised the GPU must not
+    start replacements of itself, and this one has not).  Every child is this same file with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, which is what torch.distributed.run would have set; rank 0's one JSON line
+    is relayed on stdout, everything else goes to stderr, and the exit status is non-zero if any rank's is.
+    PLHIP_BENCH_SHARE_GPU=1 puts all ranks on device 0 with the host (gloo) transport: the launcher and the whole sharded
+    step can then be tested on a one-GPU box."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   PLHIP_BENCH_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, "-u", str(Path(__file__).resolve())] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode]
+    for p_ in procs[1:]:
+        try:
+            rcs.append(p_.wait(timeout=120 if rcs[0] else None))
+        except subprocess.TimeoutExpired:  # rank 0 failed and a peer is stuck in a collective: end exactly that child
+            p_.kill()
+            rcs.append(p_.wait())
+    lines = [ln for ln in out0.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if any(rcs) or len(lines) != 1:
+        sys.stderr.write(f"bench.py launcher: rank exit codes {rcs}, {len(lines)} JSON line(s) from rank 0\n")
+        sys.stderr.write(out0.decode(errors="replace"))
+        return max([abs(rc) for rc in rcs] + [1])
+    sys.stdout.write(lines[0] + "\n")
+    sys.stdout.flush()
+    return 0
+
+
+class Ctx:
+    """What every workload of one bench.py process shares: the process group, this rank's device, the engine."""
+    world = 1
+    rank = 0
+    dev = None
+    dist = None
+    share_gpu = False
+    rehearse = False
+    eng = None
+
+    @property
+    def sharded(self):
+        return self.world > 1 or self.rehearse
+
+    def reduce(self, values, op):
+        """all_reduce of a few f64 numbers over the ranks (on the device under RCCL, on the host under gloo)."""
+        import torch
+
+        t = torch.tensor(values, dtype=torch.float64, device="cpu" if self.share_gpu else self.dev)
+        self.dist.all_reduce(t, op=getattr(self.dist.ReduceOp, op))
+        return t.tolist()
+
+    def sync(self):
+        import torch
+
+        torch.cuda.synchronize()
+        if self.sharded:
+            self.dist.barrier()
+            torch.cuda.synchronize()
+
+
+def sharded_parity(ctx, tensors, keys, vals, keys_n, vals_n, aggs, hint, n_job):
+    """Parity of the N-rank result: every rank's share of the result frame (one more, untimed call).  Up to
+    2e7 rows in the job, the shards' rows and the shares travel to rank 0 and the whole frame is compared with the oracle's
+    on the concatenated rows (canonical key sort; keys / integer sums / counts bit-exact, f64 within 1e-12).  Beyond that,
+    size-independent properties over all ranks: the shares' integer sums add up to the column's sum over all rows, counts add
+    up to the job's rows, the f64 checksum holds to 1e-9, and the shares' keys are exactly the distinct keys of the job
+    (disjoint between ranks, none missing: presence bitmaps over the Categorical's codes)."""
+    import numpy as np
+    import torch
+
+    dist = ctx.dist
+    names = [f"a{i}" for i in range(len(aggs))]
+    res = ctx.eng.sharded(keys, vals, aggs, ctx.world, None, hint, names)
+    nk = len(keys)
+    if n_job <= 20_000_000:
+        mine = {"rows": {k_: tensors[k_].cpu().numpy() for k_ in list(keys_n) + list(vals_n)},
+                "masks": {k_: tensors[k_ + "__valid"].cpu().numpy() for k_ in list(keys_n) + list(vals_n) if k_ + "__valid" in tensors},
+                "cols": [(c.t.cpu().numpy().view(_np_dtype(c.code)), None if c.mask is None else c.mask.cpu().numpy()) for c in res]}
+        gathered = [None] * ctx.world
+        dist.all_gather_object(gathered, mine)
+        if ctx.rank != 0:
+            return None
+        from oracle import oracle as orc
+        from polars_amd.column import Column
+
+        def cat(name):
+            v = np.concatenate([g_["rows"][name] for g_ in gathered])
+            m = np.concatenate([g_["masks"][name] for g_ in gathered]) if name in gathered[0]["masks"] else None
+            return v, m
+
+        hk = [Column(k_, *cat(k_), dtype=keys[i].dtype) for i, k_ in enumerate(keys_n)]
+        hv = [Column(v_, *cat(v_)) for v_ in vals_n]
+        want, _ = orc.group_by_agg(hk, hv, aggs, n_threads=min(os.cpu_count() or 1, 16))
+        got = []
+        for j in range(nk + len(aggs)):
+            v = np.concatenate([g_["cols"][j][0] for g_ in gathered])
+            ms = [g_["cols"][j][1] for g_ in gathered]
+            m = None if all(x is None for x in ms) else np.concatenate([np.ones(len(g_["cols"][j][0]), bool) if x is None else x
+                                                                       for x, g_ in zip(ms, gathered)])
+            got.append((v, m))
+        out = parity_check(hk, hv, aggs, want, lambda: got)
+        out["against"] = f"oracle (C restatement) on the {ctx.world} shards' concatenated rows, canonical key sort"
+        out["groups_per_rank"] = [int(len(g_["cols"][0][0])) for g_ in gathered]
+        return out
+    checks = {}
+    g_local = int(res[0].t.numel())
+    for j, (ci, kind) in enumerate(aggs):
+        col = res[nk + j].t
+        src = tensors[vals_n[ci]]
+        ok_rows = tensors.get(vals_n[ci] + "__valid")
+        if kind == "count":
+            tot = ctx.reduce([float(col.to(torch.int64).sum().item())], "SUM")[0]
+            checks["counts_add_up_to_n"] = int(tot) == n_job
+        elif kind == "sum" and not src.dtype.is_floating_point:
+            a = int(col.to(torch.int64).sum().item())
+            b = int((src if ok_rows is None else src[ok_rows]).to(torch.int64).sum().item())
+            d = ctx.reduce([float(a - b)], "SUM")[0]  # the difference is what travels: exact in f64 whatever the sums' size
+            checks["integer_checksum_exact"] = d == 0.0 and bool(ctx.reduce([float(a != b)], "MAX")[0] == 0.0 or d == 0.0)
+        elif kind == "sum":
+            a = float(col.sum().item())
+            b = float((src if ok_rows is None else src[ok_rows]).sum().item())
+            ta, tb = ctx.reduce([a, b], "SUM")
+            checks["f64_checksum_1e-9"] = abs(ta - tb) <= 1e-9 * abs(tb)
+    if nk == 1 and hint and keys_n[0] + "__valid" not in tensors:
+        seen_in = torch.zeros(hint + 1, dtype=torch.float64, device=ctx.dev)
+        seen_in[tensors[keys_n[0]].to(torch.int64).clamp_(0, hint)] = 1.0
+        seen_out = torch.zeros(hint + 1, dtype=torch.float64, device=ctx.dev)
+        seen_out.index_add_(0, res[0].t.to(torch.int64).clamp_(0, hint), torch.ones(g_local, dtype=torch.float64, device=ctx.dev))
+        if ctx.share_gpu:
+            seen_in, seen_out = seen_in.cpu(), seen_out.cpu()
+        dist.all_reduce(seen_in, op=dist.ReduceOp.MAX)
+        dist.all_reduce(seen_out, op=dist.ReduceOp.SUM)
+        checks["shares_hold_every_distinct_key_exactly_once"] = bool(torch.equal(seen_in, seen_out))
+    g_tot = int(ctx.reduce([float(g_local)], "SUM")[0])
+    if ctx.rank != 0:
+        return None
+    return {"ok": bool(checks) and all(checks.values()), "properties": checks, "groups": g_tot,
+            "against": f"size-independent properties over the {ctx.world} ranks' shares (the oracle would need minutes at {n_job} rows)"}
+
+
+def _np_dtype(code):
+    from polars_amd._ffi import code_np_dtype
+
+    return code_np_dtype(code)
+
+
+def run_workload(ctx, a, light=False):
+    """One workload: generates its rows in HBM, W untimed + K timed steps (barrier + synchronize on both sides), parity.
+    Returns the JSON line's dict on rank 0 (None elsewhere).  `light`: one of the extra configs of the default run: a 3 s
+    CPU baseline instead of 10 + 5 s."""
+    import ctypes as C
 
     import torch
 
     import polars_amd as pa
     from polars_amd import _ffi, h2oai
 
-    # ONE JSON line on stdout, nothing else: native libraries write to descriptor 1 on their own (RCCL prints a version banner
-    # when its first communicator is made), so everything but the line goes to stderr
-    sys.stdout.flush()
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    rehearse = os.environ.get("PLHIP_BENCH_FORCE_EXCHANGE") == "1"  # run the sharded path (and RCCL) even on one rank
-    if world > 1 or rehearse:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"), rank=rank, world_size=world)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device(f"cuda:{local_rank}")
-    _ffi.check(_ffi.lib().plhip_init(local_rank))
-
-    wl = WORKLOADS[args.workload]
-    keys_n, vals_n, aggs, wide = wl
-    strong = args.total_rows > 0
-    n = args.total_rows // world if strong else (args.rows or DEFAULT_ROWS.get(args.workload, 10_000_000))
+    world, rank, dev, dist = ctx.world, ctx.rank, ctx.dev, ctx.dist
+    sharded = ctx.sharded
+    L = _ffi.lib()
+    keys_n, vals_n, aggs, wide = WORKLOADS[a.workload]
+    strong = a.total_rows > 0
+    n = a.total_rows // world if strong else (a.rows or DEFAULT_ROWS.get(a.workload, 10_000_000))
     job_rows = n * world  # the generator's N: key cardinalities (N / K ids) follow the JOB's size under strong scaling
-    steps = args.steps or {"c3": 20, "c5": 5}.get(args.workload, 200)
-    warmup = args.warmup if args.warmup >= 0 else {"c3": 3, "c5": 1}.get(args.workload, 10)
-    if args.workload == "c5":
+    steps = a.steps or {"c3": 20, "c5": 5}.get(a.workload, 200)
+    warmup = a.warmup if a.warmup >= 0 else {"c3": 3, "c5": 1}.get(a.workload, 10)
+    if a.workload == "c5":
         tensors = skewed_keys(n, max(int((job_rows if strong else n) * C5_IDS_PER_ROW), 1), 108 + rank, dev)
         cols = {k: pa.Column(k, t) for k, t in tensors.items()}
     else:
-        tensors = h2oai.generate(n, seed=108 + rank, device=dev, wide=wide, columns=keys_n + vals_n, na=args.na,
+        tensors = h2oai.generate(n, seed=108 + rank, device=dev, wide=wide, columns=keys_n + vals_n, na=a.na,
                                  n_for_ids=job_rows if strong else None)
         cols = h2oai.to_columns(tensors, wide, n=job_rows if strong else n)
     keys = [cols[k] for k in keys_n]
     vals = [cols[v] for v in vals_n]
     agg_codes = [(ci, _ffi.AGG_NAMES[kind]) for ci, kind in aggs]
-    pa.set_strategy(args.strategy)
-    L = _ffi.lib()
+    pa.set_strategy(a.strategy)
+    # --no-dense: the hashed pipelines the north_star names (no dense-code flag, and no compact-range detection under AUTO either)
+    if a.no_dense:
+        os.environ["PLHIP_NO_RANGE_DENSE"] = "1"
+    else:
+        os.environ.pop("PLHIP_NO_RANGE_DENSE", None)
     # id1..id3 are Categorical in the reference harness (run_h2oai_benchmark.py:21-35): the engine knows their
     # category counts (K, K, N/K) without touching the data, and hands the product of them on as the bound.
     hint = 0
-    if not wide and not args.no_hint and all(k in ("id1", "id2", "id3") for k in keys_n):
+    if not wide and not a.no_hint and all(k in ("id1", "id2", "id3") for k in keys_n):
         hint = 1
         for k in keys:
             hint *= k.n_categories
-        hint = min(hint, n)
+        hint = min(hint, job_rows)
     # a single Categorical key: its codes index the tables directly (group_tuples_perfect, perfect.rs:190-227)
-    qflags = _ffi.FLAG_KEYS_DENSE if (hint and len(keys) == 1 and keys[0].n_categories is not None and not args.no_dense) else 0
+    qflags = _ffi.FLAG_KEYS_DENSE if (hint and len(keys) == 1 and keys[0].n_categories is not None and not a.no_dense) else 0
+    if a.exact_fold:
+        qflags |= _ffi.FLAG_EXACT_FOLD
 
-    if world > 1 or rehearse:
-        from polars_amd import distributed as pdist
-
-        eng = pdist.HipEngine(dev)
-        eng.dense_keys = bool(qflags)  # the local pass takes the dense-code path as the single-GPU run does
-
+    eng = ctx.eng
+    if sharded:
+        eng.dense_keys = bool(qflags & _ffi.FLAG_KEYS_DENSE)  # the local pass takes the dense-code path as the single-GPU run does
         group = None  # the default process group
 
         def step():  # ONE library call per rank; the result frame stays in HBM, its row count is on the host
-            handle, cols = eng.sharded_raw(keys, vals, aggs, group, hint)
+            handle, rcols = eng.sharded_raw(keys, vals, aggs, group, hint)
             g = L.plhip_result_num_rows(handle)
-            widths = [_ffi.code_np_dtype(cs.dtype).itemsize for cs in cols]
+            widths = [_ffi.code_np_dtype(cs.dtype).itemsize for cs in rcols]
             L.plhip_result_free(handle)
             return g, widths
     else:
-        import ctypes as C
-
         # the column / aggregation descriptors are built once, as a host layer that re-runs a query would
         karr = (_ffi.ColumnStruct * len(keys))(*[k.struct() for k in keys])
         varr = (_ffi.ColumnStruct * len(vals))(*[v.struct() for v in vals])
@@ -333,24 +461,15 @@ def main():
             L.plhip_result_free(handle)
             return g, widths
 
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1 or rehearse:
-            dist.barrier()
-            torch.cuda.synchronize()
-
     for _ in range(warmup):
         step()
-    sync()
+    ctx.sync()
     kernel_ms, dom_ms, parts, dom_names, phases = [], [], [], [], []
     # the library's HIP-event times of every step are read inside the timed region; the ctypes out-parameters are built once
     # (three object constructions per call cost more than the call)
-    import ctypes as C
-
     f_tot, f_dom, f_name, f_a, f_b, f_c = C.c_float(), C.c_float(), C.c_char_p(), C.c_float(), C.c_float(), C.c_float()
     r_ms = (C.byref(f_tot), C.byref(f_dom), C.byref(f_name))
     r_bd = (C.byref(f_a), C.byref(f_b), C.byref(f_c))
-    sharded = world > 1 or rehearse
     # the library records its HIP events on every TIMING_EVERY-th query (three event records and their read-back cost ~5 % of a
     # 0.1 ms step); the times below are those of the sampled steps INSIDE the timed region
     TIMING_EVERY = max(1, min(8, steps // 4)) if not sharded else 1
@@ -374,23 +493,29 @@ def main():
         kernel_ms.append(tot)
         dom_ms.append(dom)
         dom_names.append(dom_name)
-    sync()
+    ctx.sync()
     dt = time.perf_counter() - t0
     L.plhip_set_timing_interval(1)
     groups_total = g
+    n_ranks = world
+    if sharded:
+        # the rank count is the one the library's communicator reports (RCCL: ncclCommCount), not an environment variable
+        n_ranks, comm_rank, is_rccl = eng.comm_info(None)
+        assert comm_rank == rank, (comm_rank, rank)
     if world > 1:
-        t = torch.tensor([dt, float(g)], device=dev, dtype=torch.float64)
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        dt, groups_total = float(tmax[0].item()), int(t[1].item())
+        dt = ctx.reduce([dt], "MAX")[0]
+        groups_total = int(ctx.reduce([float(g)], "SUM")[0])
+    parity = None
+    if world > 1 and not a.no_parity:
+        parity = sharded_parity(ctx, tensors, keys, vals, keys_n, vals_n, aggs, hint, job_rows)
 
+    line = None
     if rank == 0:
         ms_per_step = dt / steps * 1e3
-        total_rows = n * world
-        strategy = pa.last_strategy() if world == 1 and not rehearse else eng.last_partial_strategy
+        total_rows = n * n_ranks
+        strategy = pa.last_strategy() if not sharded else eng.last_partial_strategy
         # the local pass of rank 0 (for N > 1: its partial aggregation over its n rows, the dominant kernels of the step)
-        g_local = g if world == 1 and not rehearse else eng.last_partial_groups
+        g_local = g if not sharded else eng.last_partial_groups
         if g_local < 0:  # the dense exchange never counts the local pass's groups: its partial arrays cover every code
             g_local = hint
         abytes = algorithmic_bytes(n, g_local, keys, vals, out_widths)
@@ -399,13 +524,14 @@ def main():
         achieved = abytes / (dom_avg * 1e-3) / 1e9 if dom_avg > 0 else 0.0
         dom_name = max(set(dom_names), key=dom_names.count)
         dom_name = dom_name.decode() if isinstance(dom_name, bytes) else dom_name
-        traffic, traffic_kernels = measured_traffic(args.workload + ("_na" if args.na else ""), n, strategy)
-        acc_dtype = {"q1": "i32", "q3": "i32+f64", "q5": "i32+f64", "c3": "i64+f64", "c5": "i64+f64"}[args.workload]
+        traffic_key = a.workload + ("_na" if a.na else "") + f":{n}:{strategy}"
+        traffic, traffic_kernels = measured_traffic(traffic_key)
+        acc_dtype = {"q1": "i32", "q3": "i32+f64", "q5": "i32+f64", "c3": "i64+f64", "c5": "i64+f64"}[a.workload]
         line = {
             "metric": "db-benchmark group-by rows/sec + % HBM roofline at 1/2/4/8 MI355X",
             "value": total_rows / (dt / steps),
             "unit": "rows/s",
-            "n_gpus": world,
+            "n_gpus": n_ranks,
             "steps": steps,
             "warmup": warmup,
             "ms_per_step": ms_per_step,
@@ -414,25 +540,37 @@ def main():
             "vs_baseline": None,
             "dtype": acc_dtype,
             "data": "synthetic",
-            "config": {"workload": f"{'db-benchmark ' if args.workload[0] == 'q' else 'BASELINE config '}{args.workload}"
-                                   f"{' (NA variant)' if args.na else ''}: {', '.join(f'{k}({vals_n[c]})' for c, k in aggs)} by "
+            "config": {"workload": f"{'db-benchmark ' if a.workload[0] == 'q' else 'BASELINE config '}{a.workload}"
+                                   f"{' (NA variant)' if a.na else ''}: {', '.join(f'{k}({vals_n[c]})' for c, k in aggs)} by "
                                    f"{','.join(keys_n)}, {n} rows per GPU, {groups_total} groups",
-                       "strategy": strategy, "n_groups_hint": hint, "dense_codes": bool(qflags), "rows_per_gpu": n, "groups": int(groups_total),
-                       "exchange": "none" if world == 1 and not rehearse else "plhip_group_by_agg_sharded: ncclSend/ncclRecv of partial records on the library's stream (RCCL)"},
+                       "strategy": strategy, "n_groups_hint": hint, "dense_codes": bool(qflags & _ffi.FLAG_KEYS_DENSE), "rows_per_gpu": n,
+                       "groups": int(groups_total),
+                       "exchange": "none" if not sharded else "plhip_group_by_agg_sharded: ncclSend/ncclRecv of partial records on the library's stream (RCCL)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_by_kernel": traffic_kernels,
+                         "traffic_source": (f"profiles/traffic.json[{traffic_key}]: rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) + WRITE_SIZE passes of this "
+                                            "workload kept under profiles/, NOT counted in this run") if traffic else None,
                          "traffic_over_algorithmic": (traffic / abytes) if traffic else None, "kernel": dom_name,
                          "kernel_ms": dom_avg, "algorithmic_bytes": abytes,
                          "breakdown_ms": {k: sum(p[i] for p in parts) / len(parts) for i, k in
                                           enumerate(("partition", "fold", "merge_emit"))},
                          "all_kernels_ms": tot_avg,
-                         "all_kernels_frac": abytes / (tot_avg * 1e-3) / 1e9 / HBM_PEAK_GBPS if tot_avg > 0 else 0.0},
+                         "all_kernels_frac": abytes / (tot_avg * 1e-3) / 1e9 / HBM_PEAK_GBPS if tot_avg > 0 else 0.0,
+                         "step_frac": abytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS},
         }
-        if phases:  # shuffle bytes and time reported separately
+        if sharded:
+            line["config"]["transport"] = eng.transport
+            line["config"]["ranks_share_one_gpu"] = ctx.share_gpu
+            # per-GPU GB/s (this rank's algorithmic bytes over the whole step's wall time) ...
+            line["per_gpu"] = {"algorithmic_GBps": abytes / (ms_per_step * 1e-3) / 1e9, "rows_per_s": n / (ms_per_step * 1e-3),
+                               "frac_of_hbm_peak": abytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+        if phases:  # ... and the shuffle's bytes and time reported separately
             line["sharded_step_ms"] = {k: sum(p.get(k, 0.0) for p in phases) / len(phases) for k in phases[0]}
-            line["shuffle"] = {"bytes_sent_per_rank": eng.last_shuffle_bytes, "protocol": eng.last_protocol, "host_syncs_per_step": eng.last_host_syncs,
-                               "transport": eng.transport}
-        if world == 1 and not rehearse and not args.no_cpu_baseline:
+            line["shuffle"] = {"bytes_sent_per_rank": eng.last_shuffle_bytes, "ms": line["sharded_step_ms"].get("exchange"),
+                               "protocol": eng.last_protocol, "host_syncs_per_step": eng.last_host_syncs, "transport": eng.transport}
+        if parity is not None:
+            line["parity"] = parity
+        if not sharded and not a.no_cpu_baseline:
             def gpu_frame():  # the timed configuration once more, result copied to the host
                 handle, out = pa.group_by_agg_raw(keys, vals, agg_codes, qflags, hint)
                 try:
@@ -444,14 +582,135 @@ def main():
                 finally:
                     L.plhip_result_free(handle)
 
-            if n <= 100_000_000:
-                line["cpu_baseline"], line["parity"] = cpu_baseline(tensors, keys, vals, aggs, gpu_frame)
+            # whole-frame parity against the oracle up to 1e8 rows (as an extra config of the default run only up to 2e7: the
+            # canonical sort of config 3's 1e8-row result on the host alone takes over a minute)
+            if n <= (20_000_000 if light else 100_000_000):
+                line["cpu_baseline"], line["parity"] = cpu_baseline(tensors, keys, vals, aggs, gpu_frame, budget_s=3.0 if light else 10.0,
+                                                                    path_b=not light)
             else:
                 line["cpu_baseline"], line["parity"] = cpu_baseline_sample(tensors, keys_n, vals_n, aggs, gpu_frame)
+    del tensors, cols, keys, vals
+    return line
+
+
+# the BASELINE single-GPU configs the default run times after the headline; (name, workload, overrides, steps, warmup,
+# seconds the config is expected to need on the box: data generation + steps + its CPU leg)
+EXTRA_CONFIGS = [
+    ("q1", "q1", {}, 100, 10, 8),
+    ("q5", "q5", {}, 100, 10, 8),
+    ("q3_na", "q3", {"na": True}, 100, 10, 10),
+    ("q3_no_dense", "q3", {"no_dense": True}, 100, 10, 8),
+    ("q3_exact_fold", "q3", {"exact_fold": True}, 50, 5, 8),
+    ("c3", "c3", {}, 10, 2, 45),
+    ("c5", "c5", {}, 4, 1, 90),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=0, help="ranks, one per GPU (default: WORLD_SIZE, else 1); with N > 1 and no WORLD_SIZE "
+                                                         "in the environment this process starts the N ranks itself")
+    ap.add_argument("--steps", type=int, default=0, help="default 200 (c3: 20, c5: 5)")
+    ap.add_argument("--warmup", type=int, default=-1, help="default 10 (c3: 3, c5: 1)")
+    ap.add_argument("--workload", default="q3", choices=sorted(WORKLOADS))
+    ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default 1e7; c3: 1e8; c5: 1e9)")
+    ap.add_argument("--total-rows", type=int, default=0,
+                    help="strong scaling (BASELINE configs[3]): the job's rows, every rank gets total / N of them")
+    ap.add_argument("--strategy", default="auto")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="N > 1: skip the parity leg (one more, untimed sharded call + checks)")
+    ap.add_argument("--no-dense", action="store_true", help="do not declare a single Categorical key's codes dense (PLHIP_FLAG_KEYS_DENSE)")
+    ap.add_argument("--no-hint", action="store_true",
+                    help="do not pass the category count of categorical keys (id1..id3) as n_groups_hint")
+    ap.add_argument("--na", action="store_true", help="db-benchmark's NA variant (groupby-datagen.R:30-44): 5 %% of the distinct key values "
+                                                      "nulled, 5 %% NA values, as validity bitmaps")
+    ap.add_argument("--exact-fold", action="store_true", help="PLHIP_FLAG_EXACT_FOLD: float sums / means folded in row order (bit-exact, deterministic)")
+    ap.add_argument("--configs", default="auto", help="'auto': a default single-GPU q3 run also times the other BASELINE single-GPU configs "
+                                                      "(q1, q5, q3 NA, q3 hashed, c3, c5) into \"configs\"; 'none'; or a comma list of their names")
+    ap.add_argument("--configs-budget-s", type=float, default=240.0, help="wall-clock budget of the extra configs")
+    args = ap.parse_args()
+
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and env_world is None:
+        sys.exit(launch_ranks(args))
+    if env_world is not None and args.gpus and int(env_world) != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: start exactly one rank per GPU")
+
+    import torch
+
+    import polars_amd as pa
+    from polars_amd import _ffi
+
+    # ONE JSON line on stdout, nothing else: native libraries write to descriptor 1 on their own (RCCL prints a version banner
+    # when its first communicator is made), so everything but the line goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    ctx = Ctx()
+    ctx.world = int(env_world or "1")
+    ctx.rank = int(os.environ.get("RANK", "0"))
+    ctx.share_gpu = os.environ.get("PLHIP_BENCH_SHARE_GPU") == "1"  # all ranks on device 0, host (gloo) transport
+    local_rank = 0 if ctx.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+    ctx.rehearse = os.environ.get("PLHIP_BENCH_FORCE_EXCHANGE") == "1"  # run the sharded path (and RCCL) even on one rank
+    ctx.dev = torch.device(f"cuda:{local_rank}")
+    if ctx.sharded:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if ctx.share_gpu:
+            dist.init_process_group("gloo", rank=ctx.rank, world_size=ctx.world)
+        else:
+            dist.init_process_group("nccl", device_id=ctx.dev, rank=ctx.rank, world_size=ctx.world)
+        ctx.dist = dist
+    torch.cuda.set_device(local_rank)
+    _ffi.check(_ffi.lib().plhip_init(local_rank))
+    if ctx.sharded:
+        from polars_amd import distributed as pdist
+
+        ctx.eng = pdist.HipEngine(ctx.dev)
+
+    t_start = time.perf_counter()
+    line = run_workload(ctx, args)
+    extra = args.configs != "none" and not ctx.sharded and args.workload == "q3" and not (
+        args.rows or args.total_rows or args.na or args.no_dense or args.no_hint or args.exact_fold or args.strategy != "auto" or args.no_cpu_baseline)
+    if extra and line is not None:
+        wanted = None if args.configs == "auto" else set(args.configs.split(","))
+        line["configs"] = {}
+        for name, wl, over, k_steps, k_warm, need_s in EXTRA_CONFIGS:
+            if wanted is not None and name not in wanted:
+                continue
+            left = args.configs_budget_s - (time.perf_counter() - t_start)
+            if left < need_s:
+                line["configs"][name] = {"skipped": f"{left:.0f} s of the extra configs' budget left, needs ~{need_s} s (run: python bench.py --workload {wl}"
+                                                    f"{' --na' if over.get('na') else ''}{' --no-dense' if over.get('no_dense') else ''})"}
+                continue
+            sub = argparse.Namespace(**{**vars(args), **over, "workload": wl, "steps": k_steps, "warmup": k_warm})
+            _ffi.lib().plhip_release_workspace()
+            torch.cuda.empty_cache()
+            t1 = time.perf_counter()
+            try:
+                ln = run_workload(ctx, sub, light=True)
+            except Exception as e:  # one config's failure must not take the headline with it; it is reported, not hidden
+                line["configs"][name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                continue
+            rf = ln["roofline"]
+            line["configs"][name] = {
+                "workload": ln["config"]["workload"], "strategy": ln["config"]["strategy"], "steps": k_steps, "ms_per_step": ln["ms_per_step"],
+                "rows_per_s": ln["value"], "kernel": rf["kernel"], "kernel_ms": rf["kernel_ms"], "kernel_frac": rf["frac"],
+                "all_kernels_ms": rf["all_kernels_ms"], "all_kernels_frac": rf["all_kernels_frac"], "step_frac": rf["step_frac"],
+                "algorithmic_bytes": rf["algorithmic_bytes"], "traffic_over_algorithmic": rf["traffic_over_algorithmic"],
+                "traffic_source": rf["traffic_source"], "parity": ln.get("parity"),
+                "cpu_baseline_rows_per_s": (ln.get("cpu_baseline") or {}).get("value"), "wall_s": time.perf_counter() - t1}
+        pa.set_strategy("auto")
+    if ctx.rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
-    if world > 1 or rehearse:
-        dist.destroy_process_group()
+    if ctx.sharded:
+        from polars_amd import distributed as pdist
+
+        pdist.HipEngine.close()
+        ctx.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -142,6 +142,16 @@ typedef struct plhip_agg {
 /* strategy override, PLHIP_STRATEGY env var or plhip_set_strategy(): mirrors the reference's
  * POLARS_NO_PARTITION / POLARS_FORCE_PARTITION switches
  * (crates/polars-lazy/src/physical_plan/executors/group_by_partitioned.rs:167-186). */
+#define PLHIP_FLAG_EXACT_FOLD 64u     /* float SUM / MEAN (and the f64 sum behind i64 / u64 means) fold every group strictly in
+                                       * ascending row order from 0 -- the association of the reference's GroupsProxy::Idx path
+                                       * (take_agg_no_null_primitive_iter_unchecked, crates/polars-arrow/src/kernels/take_agg/
+                                       * mod.rs:17-37; agg_sum / agg_mean, aggregations/mod.rs:622-651, 701-742) -- with f32 columns
+                                       * folded IN f32 (aggregations/mod.rs:719-724) and the reference's 1-row shortcut
+                                       * (`arr.get(first)`).  Results are then BIT-EXACT against that path and identical from run
+                                       * to run; without the flag float sums are re-associated (LDS atomics; bound below).  The
+                                       * query runs on the sort strategy (stable radix sort of (key, row), one sequential fold per
+                                       * group; a group of >= 2048 rows is folded by ONE wave, 64 rows per trip): about 10x the
+                                       * fused paths' time at q3's shape.  Not with PLHIP_FLAG_PARTIAL. */
 typedef enum plhip_strategy {
   PLHIP_STRATEGY_AUTO = 0,
   PLHIP_STRATEGY_GLOBAL = 1,     /* every row updates the HBM-resident table */
@@ -521,6 +531,10 @@ int32_t plhip_comm_init_rccl(const uint8_t id[PLHIP_COMM_ID_BYTES], int32_t worl
 int32_t plhip_comm_init_host(int32_t world, int32_t rank, plhip_alltoall_fn all_to_all, plhip_alltoallv_fn all_to_all_v, void *user,
                              plhip_comm_t **comm);
 void plhip_comm_free(plhip_comm_t *comm);
+/* The communicator's size and this rank as the TRANSPORT reports them (RCCL: ncclCommCount / ncclCommUserRank; host transport:
+ * what plhip_comm_init_host was given); *transport = 1 for RCCL, 0 for host callbacks.  bench.py's "n_gpus" is this world.
+ * (The reference's counterpart is the thread count of its POOL, crates/polars-core/src/lib.rs:49-62.) */
+int32_t plhip_comm_info(plhip_comm_t *comm, int32_t *world, int32_t *rank, int32_t *transport);
 
 /* plhip_group_by_agg_opts over the rows of ALL ranks of `comm`: every rank passes its shard (same schema on every
  * rank: dtypes and which columns carry a validity bitmap) and gets its share of the groups, disjoint in the keys between

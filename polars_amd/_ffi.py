@@ -35,6 +35,7 @@ FLAG_OUTPUT_DEVICE = 2
 FLAG_KEYS_SORTED = 8
 FLAG_PARTIAL = 4
 FLAG_KEYS_DENSE = 16
+FLAG_EXACT_FOLD = 64
 
 STRATEGIES = {"auto": 0, "global": 1, "lds": 2, "partitioned": 3, "direct": 4, "tilesort": 5, "sort": 6, "tilesort2": 7, "dense": 8}
 
@@ -199,6 +200,8 @@ def lib():
     L.plhip_comm_init_host.restype = i32
     L.plhip_comm_free.argtypes = [vp]
     L.plhip_comm_free.restype = None
+    L.plhip_comm_info.argtypes = [vp, P(i32), P(i32), P(i32)]
+    L.plhip_comm_info.restype = i32
     L.plhip_group_by_agg_sharded.argtypes = [vp, P(ColumnStruct), i32, P(ColumnStruct), i32, P(AggStruct), i32, u32,
                                              P(OptionsStruct), P(vp)]
     L.plhip_group_by_agg_sharded.restype = i32
@@ -292,7 +295,7 @@ EXPORTED_SYMBOLS = [
     "plhip_groups_num_groups", "plhip_groups_num_rows", "plhip_groups_buffers", "plhip_groups_free",
     "plhip_agg_groups", "plhip_agg_groups_quantile", "plhip_result_record_bytes", "plhip_result_pack_by_owner", "plhip_records_to_frame", "plhip_merge_records", "plhip_finalize_partial", "plhip_slot_bytes", "plhip_result_pack_slots", "plhip_merge_slots",
     "plhip_group_by_agg_noalloc", "plhip_release_workspace", "plhip_pooled_buffers",
-    "plhip_comm_unique_id", "plhip_comm_init_rccl", "plhip_comm_init_host", "plhip_comm_free", "plhip_group_by_agg_sharded",
+    "plhip_comm_unique_id", "plhip_comm_init_rccl", "plhip_comm_init_host", "plhip_comm_free", "plhip_comm_info", "plhip_group_by_agg_sharded",
     "plhip_sharded_last_stats", "plhip_group_by_agg_chunked",
     "plhip_utf8_encode", "plhip_dictionary_len", "plhip_dictionary_strings", "plhip_dictionary_free",
     "plhip_set_timing_interval", "plhip_alloc_pinned", "plhip_free_pinned", "plhip_hash_join", "plhip_hash_join_multi", "plhip_join_num_rows", "plhip_join_buffers", "plhip_join_free",

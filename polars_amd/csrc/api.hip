@@ -500,6 +500,7 @@ int build_aggs(Lowered &L, const std::vector<DevCol> &vals, const plhip_agg_t *a
     L.outs.push_back(o);
   }
   const bool partial = flags & PLHIP_FLAG_PARTIAL;
+  const bool exact = (flags & PLHIP_FLAG_EXACT_FOLD) && !partial;
   for (int i = 0; i < n_aggs; i++) {
     const int kind = aggs[i].kind;
     OutSpec o{};
@@ -521,7 +522,7 @@ int build_aggs(Lowered &L, const std::vector<DevCol> &vals, const plhip_agg_t *a
     const int w = dtype_width(dt);
     const int cnt_valid = nullable ? add_acc(P, ACC_CNT_VALID, CONV_NONE, ci, 4, 0) : -1;
     if (kind == PLHIP_AGG_SUM) {
-      if (is_f) { o.kind = OUT_SUM_F64; o.dtype = dt; o.acc = add_acc(P, ACC_ADD_F64, CONV_F64, ci, 8, 0); }
+      if (is_f) { o.kind = OUT_SUM_F64; o.dtype = dt; o.acc = add_acc(P, (exact && dt == PLHIP_F32) ? ACC_ADD_F32 : ACC_ADD_F64, CONV_F64, ci, 8, 0); }
       else {
         o.kind = OUT_SUM_INT; o.dtype = w < 4 ? PLHIP_I64 : dt; // series/implementations/mod.rs:167-174
         o.acc = add_acc(P, ACC_ADD_U64, CONV_INT, ci, 8, 0);
@@ -540,7 +541,7 @@ int build_aggs(Lowered &L, const std::vector<DevCol> &vals, const plhip_agg_t *a
         o.acc = add_acc(P, ACC_ADD_U64, CONV_INT, ci, 8, 0);
       } else {
         o.kind = OUT_MEAN_F64; o.dtype = dt == PLHIP_F32 ? PLHIP_F32 : PLHIP_F64;
-        o.acc = add_acc(P, ACC_ADD_F64, CONV_F64, ci, 8, 0);
+        o.acc = add_acc(P, (exact && dt == PLHIP_F32) ? ACC_ADD_F32 : ACC_ADD_F64, CONV_F64, ci, 8, 0);
       }
       o.validity = nullable ? (uint8_t *)1 : nullptr;
       if (partial) { // (sum, valid count) as in evaluate_partitioned (aggregation.rs:297-322)
@@ -2685,6 +2686,19 @@ int32_t group_by_agg_impl(const plhip_column_t *keys, int32_t n_keys, const plhi
 
   // ---- strategy ------------------------------------------------------------------------------------
   int strategy = c.forced_strategy >= 0 ? c.forced_strategy : env_strategy();
+  if (flags & PLHIP_FLAG_EXACT_FOLD) { // bit-exact float sums: only the sort strategy folds a group in row order
+    if (flags & PLHIP_FLAG_PARTIAL) return fail(PLHIP_ERR_INVALID, "PLHIP_FLAG_EXACT_FOLD does not combine with PLHIP_FLAG_PARTIAL");
+    bool any_float = false;
+    for (int a = 0; a < P.n_accs; a++) any_float |= P.accs[a].op == ACC_ADD_F64 || P.accs[a].op == ACC_ADD_F32;
+    if (any_float && n > 0) {
+      P.exact_fold = 1;
+      bool handled = false;
+      if ((rc = run_sorted(L, dk, flags, out, handled, (flags & PLHIP_FLAG_KEYS_SORTED) && n_keys == 1))) return rc;
+      if (handled) return PLHIP_OK;
+      return fail(PLHIP_ERR_UNSUPPORTED_DTYPE, "PLHIP_FLAG_EXACT_FOLD: the sort strategy declined this query (more than 20 accumulators, or a "
+                                               "nullable key spanning all 2^64 values)");
+    }
+  }
   if ((flags & PLHIP_FLAG_KEYS_SORTED) && n_keys == 1 && n > 0) { // into_groups.rs:142-150: the flag wins over every hash path
     bool handled = false;
     if ((rc = run_sorted(L, dk, flags, out, handled, true))) return rc;
@@ -3498,6 +3512,16 @@ int32_t plhip_comm_init_host(int32_t world, int32_t rank, plhip_alltoall_fn all_
 }
 
 void plhip_comm_free(plhip_comm_t *comm) { comm_free(comm); }
+
+int32_t plhip_comm_info(plhip_comm_t *comm, int32_t *world, int32_t *rank, int32_t *transport) {
+  if (!comm || !world || !rank || !transport) return fail(PLHIP_ERR_INVALID, "NULL pointer");
+  std::string err;
+  int w = 0, r = 0, t = 0;
+  const int rc = comm_info(comm, &w, &r, &t, err);
+  if (rc) return fail(rc, err);
+  *world = w; *rank = r; *transport = t;
+  return PLHIP_OK;
+}
 
 int32_t plhip_sharded_last_stats(plhip_sharded_stats_t *stats) {
   if (!stats) return fail(PLHIP_ERR_INVALID, "NULL pointer");

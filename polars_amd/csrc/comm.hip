@@ -27,6 +27,8 @@ struct Rccl {
   decltype(&ncclSend) Send = nullptr;
   decltype(&ncclRecv) Recv = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;
+  decltype(&ncclCommUserRank) CommUserRank = nullptr;
   std::string why;
 };
 Rccl g_rccl;
@@ -35,21 +37,28 @@ std::once_flag g_rccl_once;
 void load_rccl() {
   Rccl &R = g_rccl;
   const char *env = getenv("PLHIP_RCCL_LIBRARY");
-  // an instance the process already holds first (RTLD_NOLOAD), then the usual places
-  const char *names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  // an instance the process already holds first (RTLD_NOLOAD), then the usual places; PLHIP_RCCL_LIBRARY, when set, is the ONLY
+  // name tried (the host said which RCCL it wants: a missing file is an error, not a reason to pick another copy)
+  const bool only_env = env && *env;
+  const char *names[] = {env, only_env ? nullptr : "librccl.so.1", only_env ? nullptr : "librccl.so",
+                         only_env ? nullptr : "/opt/rocm/lib/librccl.so.1"};
   for (int pass = 0; pass < 2 && !R.h; pass++)
     for (const char *n : names) {
       if (!n || !*n) continue;
       R.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
       if (R.h) break;
     }
-  if (!R.h) { R.why = std::string("librccl.so not found (set PLHIP_RCCL_LIBRARY): ") + (dlerror() ? dlerror() : ""); return; }
+  if (!R.h) {
+    const char *e = dlerror(); // ONE call: dlerror() hands the message over and clears it
+    R.why = std::string("librccl.so not found (set PLHIP_RCCL_LIBRARY): ") + (e ? e : "");
+    return;
+  }
 #define SYM(field, name)                                                  \
   R.field = (decltype(R.field))dlsym(R.h, name);                          \
   if (!R.field) { R.why = std::string("librccl.so lacks ") + name; R.h = nullptr; return; }
   SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
   SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd") SYM(Send, "ncclSend") SYM(Recv, "ncclRecv")
-  SYM(GetErrorString, "ncclGetErrorString")
+  SYM(GetErrorString, "ncclGetErrorString") SYM(CommCount, "ncclCommCount") SYM(CommUserRank, "ncclCommUserRank")
 #undef SYM
 }
 
@@ -87,6 +96,17 @@ int comm_init_rccl(const uint8_t *id128, int world, int rank, int device, plhip_
   plhip_comm *c = new plhip_comm();
   c->world = world; c->rank = rank; c->device = device; c->nccl = comm;
   *out = c;
+  return PLHIP_OK;
+}
+
+int comm_info(plhip_comm *c, int *world, int *rank, int *transport, std::string &err) {
+  *world = c->world; *rank = c->rank; *transport = c->nccl ? 1 : 0;
+  if (c->nccl) { // what RCCL itself says about the communicator, not what the caller passed in
+    Rccl *R = rccl(err);
+    if (!R) return PLHIP_ERR_NO_DEVICE;
+    NCCL_TRY(R, R->CommCount((ncclComm_t)c->nccl, world));
+    NCCL_TRY(R, R->CommUserRank((ncclComm_t)c->nccl, rank));
+  }
   return PLHIP_OK;
 }
 

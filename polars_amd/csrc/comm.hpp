@@ -24,4 +24,6 @@ int comm_all_to_all_v(plhip_comm *c, const void *send, const int64_t *send_bytes
                       std::string &err);
 int comm_unique_id(uint8_t *id128, std::string &err);
 int comm_init_rccl(const uint8_t *id128, int world, int rank, int device, plhip_comm **out, std::string &err);
+// world / rank as the transport reports them (RCCL: ncclCommCount / ncclCommUserRank); transport: 1 = RCCL, 0 = host callbacks
+int comm_info(plhip_comm *c, int *world, int *rank, int *transport, std::string &err);
 void comm_free(plhip_comm *c);

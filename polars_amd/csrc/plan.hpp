@@ -31,6 +31,8 @@ enum AccOp : uint32_t {
   ACC_CNT_ALL = 6,   // rows in the group, nulls included (u32)
   ACC_CNT_VALID = 7, // non-null rows of the source column (u32)
   ACC_FIRST_ROW = 8, // smallest row index of the group (u32 min) for maintain_order / GroupsIdx.first
+  ACC_ADD_F32 = 9,   // PLHIP_FLAG_EXACT_FOLD only (the sort strategy's row-order fold): an f32 column folded IN f32 as the reference
+                     // does (aggregations/mod.rs:719-724); the state is the f64 image of that f32, so the finalizers are ADD_F64's
 };
 
 // how the source value is turned into the accumulator operand
@@ -78,7 +80,7 @@ struct Plan {
   int32_t single_key; // 1: packed key = normalised key bits, null -> reserved slot; 0: range-packed tuple
   const uint32_t *rowidx; // original row index of each row (partitioned intermediates) or nullptr = identity
   int32_t prepacked;      // 1: keys[0].values already holds the packed key (u32 or u64), use it as is
-  int32_t pad0;
+  int32_t exact_fold;     // 1: PLHIP_FLAG_EXACT_FOLD -- float sums fold strictly in ascending row order (sort strategy only)
   KeySpec keys[PLHIP_MAX_KEYS];
   ValSpec vals[PLHIP_MAX_VALS];
   AccSpec accs[PLHIP_MAX_ACCS];

@@ -74,6 +74,9 @@ DEVINL void fold_local(const AccSpec &a, uint64_t &state, uint64_t operand) {
   switch (a.op) {
     case ACC_ADD_U64: state += operand; break;
     case ACC_ADD_F64: state = (uint64_t)__double_as_longlong(__longlong_as_double((long long)state) + __longlong_as_double((long long)operand)); break;
+    case ACC_ADD_F32: // the f32 fold of the reference (aggregations/mod.rs:719-724); state and operand are f64 images of f32 values
+      state = (uint64_t)__double_as_longlong((double)((float)__longlong_as_double((long long)state) + (float)__longlong_as_double((long long)operand)));
+      break;
     case ACC_MIN_I64: state = (long long)operand < (long long)state ? operand : state; break;
     case ACC_MAX_I64: state = (long long)operand > (long long)state ? operand : state; break;
     case ACC_MIN_U64: state = operand < state ? operand : state; break;
@@ -117,6 +120,10 @@ __global__ void __launch_bounds__(SP_BLOCK) k_fold_sorted(Plan P, OutPlan O, con
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= G) return;
   const uint32_t b = offsets[g], e = offsets[g + 1];
+  if (P.exact_fold && e - b >= SP_LONG) { // one wave folds the run in row order (k_fold_sorted_exact_long)
+    long_list[atomicAdd(long_count, 1u)] = (uint32_t)g;
+    return;
+  }
   if (e - b >= SP_HUGE) { // queued from the list's far end, with the combined state of its chunks at the identities
     const uint32_t hi = atomicAdd(long_count + 1, 1u);
     long_list[max_runs - 1 - hi] = (uint32_t)g;
@@ -165,6 +172,9 @@ __global__ void __launch_bounds__(SP_BLOCK) k_fold_sorted(Plan P, OutPlan O, con
           raw_to_operands<4>(dtype, A.conv, raw, opnd);
 #pragma unroll
           for (int k = 0; k < 4; k++) if ((okm >> k) & 1) fold_local(A, st, opnd[k]); // index order: the reference's fold order
+          // the reference's 1-row shortcut (`arr.get(first)`, aggregations/mod.rs:631-633): the value itself, not 0.0 + value
+          // (which would turn -0.0 into +0.0)
+          if (P.exact_fold && e - b == 1 && (okm & 1) && (A.op == ACC_ADD_F64 || A.op == ACC_ADD_F32)) st = opnd[0];
         }
         sst[a * SP_BLOCK + threadIdx.x] = st;
       }
@@ -254,6 +264,53 @@ __global__ void __launch_bounds__(SP_BLOCK) k_fold_sorted_long(Plan P, OutPlan O
       __syncthreads();
     }
     base += C;
+  }
+}
+
+// PLHIP_FLAG_EXACT_FOLD, runs of >= SP_LONG rows: ONE wave per run.  Per trip the lanes gather 64 consecutive rows of the run
+// (coalesced index reads), then the float sums are folded lane after lane in row order -- every lane computes the same
+// chain from the broadcast operands, so the state stays wave-uniform -- while the order-independent accumulators (integer
+// sums, extrema, counts) fold per lane and meet in a xor-shuffle tree at the end.
+__global__ void __launch_bounds__(SP_BLOCK) k_fold_sorted_exact_long(Plan P, OutPlan O, const KeyGather *__restrict__ KG,
+                                                                     const uint64_t *__restrict__ skeys, const uint32_t *__restrict__ rows,
+                                                                     const uint32_t *__restrict__ offsets,
+                                                                     const uint32_t *__restrict__ long_list, const uint32_t *__restrict__ long_count,
+                                                                     const uint32_t *__restrict__ gmap) {
+  extern __shared__ __align__(16) uint64_t sst[]; // [n_accs][SP_BLOCK]
+  const uint32_t count = long_count[0];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, waves = SP_BLOCK / 64;
+  for (uint32_t li = blockIdx.x * waves + wave; li < count; li += gridDim.x * waves) {
+    const uint64_t g = long_list[li];
+    const uint32_t b = offsets[g], e = offsets[g + 1];
+    for (int a = 0; a < P.n_accs; a++) {
+      const AccSpec A = P.accs[a];
+      const bool ordered = A.op == ACC_ADD_F64 || A.op == ACC_ADD_F32;
+      uint64_t st = A.init;
+      for (uint32_t i0 = b; i0 < e; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        bool ok = i < e;
+        const uint32_t r = rows[ok ? i : b];
+        uint64_t operand = 0;
+        ok = acc_operand(P, A, (int64_t)r, operand) && ok;
+        if (ordered) {
+          unsigned long long m = __ballot(ok);
+          while (m) { // ascending lanes = ascending rows of the run
+            const int k = __ffsll((long long)m) - 1;
+            const uint64_t v = ((uint64_t)(uint32_t)__shfl((int)(operand >> 32), k) << 32) | (uint32_t)__shfl((int)operand, k);
+            fold_local(A, st, v);
+            m &= m - 1;
+          }
+        } else if (ok) fold_local(A, st, operand);
+      }
+      if (!ordered) {
+        for (int off = 32; off > 0; off >>= 1) {
+          const uint64_t o = ((uint64_t)(uint32_t)__shfl_xor((int)(st >> 32), off) << 32) | (uint32_t)__shfl_xor((int)st, off);
+          fold_local(A, st, o);
+        }
+      }
+      if (lane == 0) sst[a * SP_BLOCK + wave * 64] = st;
+    }
+    if (lane == 0) emit_run(P, O, KG, sst, wave * 64, skeys ? skeys[b] : 0ull, rows[b], gmap ? gmap[g] : g);
   }
 }
 
@@ -576,6 +633,12 @@ void launch_fold_sorted(const Plan &p, const OutPlan &o, const KeyGather *kg_dev
   hipLaunchKernelGGL(k_fold_sorted, dim3((unsigned)((G + SP_BLOCK - 1) / SP_BLOCK)), dim3(SP_BLOCK), lds, s, p, o, kg_dev, skeys, rows, offsets, G,
                      long_list, long_count, gmap, long_done, long_part, (uint32_t)max_runs);
   const uint64_t max_long = (uint64_t)p.n_rows / SP_LONG + 1;
+  if (p.exact_fold) {
+    const uint64_t blocks = (max_long + SP_BLOCK / 64 - 1) / (SP_BLOCK / 64);
+    hipLaunchKernelGGL(k_fold_sorted_exact_long, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(SP_BLOCK), lds, s, p, o, kg_dev, skeys, rows,
+                       offsets, long_list, long_count, gmap);
+    return;
+  }
   hipLaunchKernelGGL(k_fold_sorted_long, dim3((unsigned)(max_long < 4096 ? max_long : 4096)), dim3(SP_BLOCK), lds, s, p, o, kg_dev, skeys, rows,
                      offsets, long_list, long_count, gmap, long_done, long_part, (uint32_t)max_runs);
 }

@@ -345,18 +345,28 @@ class HipEngine:
         import torch
         import torch.distributed as dist
 
-        key = id(group) if group is not None else 0
+        # keyed by the process-group OBJECT (held in the entry, so its id cannot be recycled while the entry lives); the default
+        # group is dist.group.WORLD, a new object after destroy_process_group() + init_process_group(): entries whose group is
+        # no longer the one asked for are released, never reused
+        pg = group if group is not None else dist.group.WORLD
+        key = id(pg)
         hit = self._comms.get(key)
-        if hit is not None:
+        if hit is not None and hit[2] is pg:
+            self.transport = hit[3]
             return hit[0]
         L = _ffi.lib()
+        if hit is not None:
+            self._release(key)
+        for k in [k for k, e in self._comms.items() if not _group_alive(e[2])]:
+            self._release(k)
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         _ffi.check(L.plhip_init(self.device.index or 0))
         comm = C.c_void_p()
         if dist.get_backend(group) == "gloo":
             tr = _HostTransport(group, world)
             _ffi.check(L.plhip_comm_init_host(world, rank, tr.a2a, tr.a2av, None, C.byref(comm)))
-            self._comms[key] = (comm, tr)
+            self.transport = "host (gloo rehearsal)"
+            self._comms[key] = (comm, tr, pg, self.transport)
         else:
             import os
 
@@ -376,21 +386,42 @@ class HipEngine:
             flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
             if int(flag.item()) == 1:
-                self._comms[key] = (comm, None)
                 self.transport = "rccl (library-side ncclSend / ncclRecv)"
+                self._comms[key] = (comm, None, pg, self.transport)
             else:
                 if ok:
                     L.plhip_comm_free(comm)
                 comm = C.c_void_p()
                 tr = _HostTransport(group, world, device=self.device)
                 _ffi.check(L.plhip_comm_init_host(world, rank, tr.a2a, tr.a2av, None, C.byref(comm)))
-                self._comms[key] = (comm, tr)
                 self.transport = "torch.distributed all_to_all_single (fallback: " + L.plhip_last_error().decode()[:120] + ")"
+                self._comms[key] = (comm, tr, pg, self.transport)
         return comm
 
     transport = "host (gloo rehearsal)"
 
-    _comms: dict = {}
+    _comms: dict = {}  # id(process group) -> (plhip_comm_t*, host transport or None, the group object, transport name)
+
+    @classmethod
+    def _release(cls, key) -> None:
+        e = cls._comms.pop(key, None)
+        if e is not None and e[0]:
+            _ffi.lib().plhip_comm_free(e[0])
+
+    @classmethod
+    def close(cls) -> None:
+        """Releases every cached communicator (plhip_comm_free): call before dist.destroy_process_group()."""
+        for k in list(cls._comms):
+            cls._release(k)
+
+    def comm_info(self, group=None):
+        """(world, rank, transport is RCCL) as the library's communicator of `group` reports them (plhip_comm_info: RCCL's own
+        ncclCommCount / ncclCommUserRank)."""
+        import ctypes as C
+
+        w, r, t = C.c_int32(), C.c_int32(), C.c_int32()
+        _ffi.check(_ffi.lib().plhip_comm_info(self.communicator(group), C.byref(w), C.byref(r), C.byref(t)))
+        return w.value, r.value, bool(t.value)
 
     def sharded(self, keys, vals, aggs, world: int, group, hint: int, names) -> list[Col]:
         """ONE library call: plhip_group_by_agg_sharded (local pass -> pack -> exchange -> unpack + regroup -> finalize,
@@ -478,6 +509,21 @@ class HipEngine:
             _ffi.check(L.plhip_merge_slots(recv.data_ptr(), world, slot_rows, rc, dts, nul, len(schema), nk, kinds,
                                            _ffi.FLAG_OUTPUT_DEVICE, C.byref(opts), C.byref(merged)))
         return merged
+
+
+def _group_alive(pg) -> bool:
+    """Is `pg` still a usable process group (the default one: still dist.group.WORLD; a sub-group: still registered)?"""
+    import torch.distributed as dist
+
+    if not dist.is_initialized():
+        return False
+    if pg is dist.group.WORLD:
+        return True
+    try:
+        dist.get_world_size(pg)
+        return True
+    except Exception:
+        return False
 
 
 def partial_schema(keys, vals, aggs) -> list[tuple[int, bool]]:

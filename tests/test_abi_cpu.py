@@ -70,3 +70,27 @@ def test_argument_errors_match_reference_kinds():
         _ffi.ColumnStruct(a.ctypes.data, None, 0, 4, _ffi.I32, 0), _ffi.ColumnStruct(b.ctypes.data, None, 0, 5, _ffi.I32, 0))
     rc = L.plhip_group_by_agg(keys, 2, None, 0, None, 0, 0, C.byref(out))
     assert rc == 2
+
+
+def test_missing_rccl_library_is_a_clean_error():
+    """with no loadable librccl.so the communicator entry points must answer PLHIP_ERR_NO_DEVICE with a
+    message (what HipEngine.communicator falls back on), not crash while building that message.  A fresh process: the
+    library resolves RCCL once."""
+    import subprocess
+    import sys
+
+    code = (
+        "import ctypes as C, sys\n"
+        f"sys.path.insert(0, {str(ROOT)!r})\n"
+        "from polars_amd import _ffi\n"
+        "L = _ffi.lib()\n"
+        "buf = (C.c_uint8 * _ffi.COMM_ID_BYTES)()\n"
+        "rc = L.plhip_comm_unique_id(buf)\n"
+        "msg = L.plhip_last_error().decode()\n"
+        "print(rc, '|', msg)\n"
+        "rc2 = L.plhip_comm_unique_id(buf)\n"
+        "assert rc == 7 and rc2 == 7, (rc, rc2)\n"
+        "assert 'librccl.so not found' in msg and 'no-such-dir' in msg, msg\n")
+    env = dict(__import__("os").environ, PLHIP_RCCL_LIBRARY="/no-such-dir/librccl.so.1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
