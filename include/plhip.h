@@ -302,9 +302,12 @@ int32_t plhip_group_by_agg_chunked(const plhip_chunked_column_t *keys, int32_t n
                                    int32_t n_values, const plhip_agg_t *aggs, int32_t n_aggs, uint32_t flags,
                                    const plhip_options_t *opts, plhip_result_t **out);
 
-/* plhip_group_by_agg_opts for callers that cannot allocate: code under HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc.  NO counterpart in the reference (there every aggregation allocates its output
- * Series); it exists for those callers only.  It calls no hipMalloc / hipFree / allocating routine: inputs and
+/* plhip_group_by_agg_opts for callers that cannot allocate: tight serving loops, harnesses that forbid hipMalloc,
+ * processes with a stream of their own under HIP graph capture (which forbids allocation process-wide in the default
+ * capture mode).  NO counterpart in the reference (there every aggregation allocates its output
+ * Series); it exists for those callers only.  The call is BLOCKING and not itself capturable: it launches on the library's
+ * private stream, waits for the group count through a pinned signal word and hipStreamSynchronize, and returns the count.
+ * It calls no hipMalloc / hipFree / allocating routine: inputs and
  * outputs are the caller's device buffers, and everything the kernels need beyond them (flag block, dump headers,
  * the compact table dumps k_fold_rows hands to k_merge_emit) lives in one static device array of
  * PLHIP_NOALLOC_SCRATCH_BYTES per GPU, resolved with hipGetSymbolAddress when plhip_init binds the thread's device.
@@ -554,7 +557,10 @@ int32_t plhip_comm_info(plhip_comm_t *comm, int32_t *world, int32_t *rank, int32
  * (RCCL transport).  A rank that cannot keep the promise (a code >= hint, misaligned buffers) flags its slot headers; every
  * rank sees the flag and all fall back to the hashed protocols above together.  The sums of a group are added in a fixed
  * order (slices of a rank, then ranks 0 .. world - 1): results do not change from run to run.
- * Collective: every rank of the communicator must call it with the same query. */
+ * Collective: every rank of the communicator must call it with the same query.  A non-zero return on any rank is FATAL for
+ * the communicator: the library has no collective error path, the peers of a rank that bailed out between the local pass and
+ * the exchange stay blocked in their receive; tear the job down (plhip_comm_free, a new communicator) as after a failed
+ * RCCL call. */
 #define PLHIP_FLAG_EXACT_EXCHANGE 32u
 int32_t plhip_group_by_agg_sharded(plhip_comm_t *comm, const plhip_column_t *keys, int32_t n_keys, const plhip_column_t *values,
                                    int32_t n_values, const plhip_agg_t *aggs, int32_t n_aggs, uint32_t flags,

@@ -1536,6 +1536,9 @@ int run_dense(const Lowered &L0, const std::vector<DevCol> &dk, uint32_t flags, 
   std::unique_ptr<plhip_result> R_(new (std::nothrow) plhip_result());
   if (!R_) return fail(PLHIP_ERR_OOM, "host allocation failed");
   R_->on_device = true; R_->device = c.device;
+  // every early return below (a failed launch, a failed exchange, a failed wait) drains the stream before R_ hands its pooled
+  // buffers back: kernels already queued may still write them (disarmed once wait_signal has synchronised the stream)
+  StreamDrain drain(c.stream);
   OutPlan OP{};
   OP.n_outs = (int)L.outs.size();
   (void)hipGetLastError();
@@ -1583,6 +1586,7 @@ int run_dense(const Lowered &L0, const std::vector<DevCol> &dk, uint32_t flags, 
   TableRef t{nullptr, 0, dflags};
   const int rc = wait_signal(t, seq, fl);
   if (rc) return rc;
+  drain.s = nullptr; // (the stream is idle: wait_signal synchronised it)
   if (comm) { c.shard_stats.host_syncs++; lap(c.shard_stats.merge_ms); }
   if (!fl[FLAG_OVERFLOW] && c.signal_seen) c.flags_clean = 2; // (the signal was seen: the kernel's last workgroup has zeroed its counters)
   else if (hipMemsetAsync(dflags, 0, 64, c.stream) == hipSuccess) c.flags_clean = true;

@@ -130,3 +130,39 @@ def test_noalloc_rejects_what_it_cannot_hold():
     assert g.value == 40
     s = ov.cpu().numpy()[:40]
     assert np.all((s == n // 40) | (s == n // 40 + 1)) and s.sum() == n
+
+
+def test_noalloc_allocates_nothing():
+    """The entry point's one contract: no device allocation.  After a warm-up call, the device's free memory
+    (hipMemGetInfo through torch) and the library's pooled result buffers must be the same before and after a run of calls."""
+    import torch
+
+    L = _ffi.lib()
+    _ffi.check(L.plhip_init(0))
+    n, groups = 500_000, 200
+    rng = np.random.default_rng(3)
+    tk = _dev(rng.integers(0, groups, n).astype(np.int32), torch)
+    tv = _dev(rng.random(n), torch)
+    karr = (_ffi.ColumnStruct * 1)(_col(tk, _ffi.I32))
+    varr = (_ffi.ColumnStruct * 1)(_col(tv, _ffi.F64))
+    aarr = (_ffi.AggStruct * 2)(_ffi.AggStruct(0, _ffi.AGG_SUM), _ffi.AggStruct(0, _ffi.AGG_COUNT))
+    cap = groups + 8
+    ok = torch.zeros(cap, dtype=torch.int32, device="cuda:0")
+    ov = torch.zeros(cap, dtype=torch.float64, device="cuda:0")
+    oc = torch.zeros(cap, dtype=torch.int32, device="cuda:0")
+    oarr = (_ffi.ColumnStruct * 3)(_ffi.ColumnStruct(ok.data_ptr(), None, 0, cap, _ffi.I32, _ffi.DEVICE),
+                                   _ffi.ColumnStruct(ov.data_ptr(), None, 0, cap, _ffi.F64, _ffi.DEVICE),
+                                   _ffi.ColumnStruct(oc.data_ptr(), None, 0, cap, _ffi.U32, _ffi.DEVICE))
+    g = C.c_int64(-1)
+    _ffi.check(L.plhip_group_by_agg_noalloc(karr, 1, varr, 1, aarr, 2, 0, groups, oarr, 3, C.byref(g)))  # warm-up
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info(0)
+    pooled0 = L.plhip_pooled_buffers(0)
+    for _ in range(20):
+        _ffi.check(L.plhip_group_by_agg_noalloc(karr, 1, varr, 1, aarr, 2, 0, groups, oarr, 3, C.byref(g)))
+        assert g.value == groups
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info(0)
+    assert free1 == free0, f"device memory changed across no-alloc calls: {free0} -> {free1}"
+    assert L.plhip_pooled_buffers(0) == pooled0
+    assert int(oc.cpu().numpy()[:groups].view(np.uint32).sum()) == n
