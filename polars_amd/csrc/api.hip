@@ -326,11 +326,16 @@ struct plhip_result {
 
 struct plhip_groups {
   uint32_t *first = nullptr, *offsets = nullptr, *indices = nullptr;
+  size_t cap_first = 0, cap_offsets = 0, cap_indices = 0; // != 0: the device buffer came from the pool and goes back to it
+  int device = 0;
   int64_t n_groups = 0, n_rows = 0;
   bool on_device = false;
   ~plhip_groups() {
-    if (on_device) { hipFree(first); hipFree(offsets); hipFree(indices); }
-    else { free(first); free(offsets); free(indices); }
+    if (on_device) {
+      if (cap_first) g_pool.put(device, first, cap_first); else hipFree(first);
+      if (cap_offsets) g_pool.put(device, offsets, cap_offsets); else hipFree(offsets);
+      if (cap_indices) g_pool.put(device, indices, cap_indices); else hipFree(indices);
+    } else { free(first); free(offsets); free(indices); }
   }
 };
 
@@ -654,8 +659,9 @@ int wait_signal(TableRef t, uint32_t seq, uint32_t *out8) {
 void resolve_timing() {
   Ctx &c = g_ctx;
   if (!c.timing_pending) return;
-  const bool dense = c.timing_pending == 4;
-  const bool direct = c.timing_pending == 1 || dense, merged = c.timing_pending != 2;
+  const bool dense_part = c.timing_pending == 5; // range partition, dense fold, dense merge
+  const bool dense = c.timing_pending == 4 || dense_part;
+  const bool direct = c.timing_pending == 1 || c.timing_pending == 4, merged = c.timing_pending != 2;
   c.timing_pending = 0;
   if (hipEventSynchronize(merged ? c.ev[2] : c.ev[5]) != hipSuccess) { (void)hipGetLastError(); return; }
   hipEventElapsedTime(&c.total_ms, c.ev[1], merged ? c.ev[2] : c.ev[5]);
@@ -664,7 +670,7 @@ void resolve_timing() {
   hipEventElapsedTime(&c.k_ms[1], direct ? c.ev[1] : c.ev[4], c.ev[5]);
   if (merged) hipEventElapsedTime(&c.k_ms[2], c.ev[5], c.ev[2]);
   const bool leaf = c.strategy == "leafsort";
-  const char *names[3] = {"k_tile_sort", dense ? "k_dense_fold" : (direct ? "k_fold_rows" : (leaf ? "k_leaf_sort" : "k_fold_runs")),
+  const char *names[3] = {dense_part ? "k_dense_part_hist+k_tile_sort(scatter)" : "k_tile_sort", dense ? "k_dense_fold" : (direct ? "k_fold_rows" : (leaf ? "k_leaf_sort" : "k_fold_runs")),
                           dense ? "k_dense_merge" : "k_merge_emit"};
   int dom = 0;
   for (int i = 1; i < 3; i++) if (c.k_ms[i] > c.k_ms[dom]) dom = i;
@@ -1402,8 +1408,30 @@ int run_dense(const Lowered &L0, const std::vector<DevCol> &dk, uint32_t flags, 
   uint32_t R = (uint32_t)(((uint64_t)A.n_slots * state_max + LDS_CAP - 1) / LDS_CAP);
   if (dbg_r) R = std::max<uint32_t>(R, (uint32_t)atoi(dbg_r));
   const uint32_t rep = dk[0].validity ? 64u : 0u; // a nullable key: 64 replicas of the null slot behind a range's entries (dense_path.hip)
+  // More groups than DENSE_MAX_RANGES ranges hold (q3 at 1e8 .. 1e9 rows: 1e6 .. 1e7 ids): PARTITION MODE.  The rows are scattered
+  // by code range first -- exact and hash-free: partition = code / gpr, sized by one histogram pass over the key column -- and
+  // every partition is then a dense problem of ONE range: read, write partitioned, read partitioned; three passes over the row
+  // bytes where the hashed two-level pipeline makes five.  Needs a key without nulls and up to 2^TS_MAX_PBITS partitions.
+  bool pmode = false;
+  uint32_t np_pow2 = 0, pbits = 0;
+  const uint64_t n_pad = (uint64_t)n + ((uint64_t)1 << TS_MAX_PBITS) * TS_TILE; // every partition starts on a tile boundary
   for (;; R++) {
-    if (R > DENSE_MAX_RANGES) return PLHIP_OK; // too many groups: every row would be read R times
+    if (R > DENSE_MAX_RANGES) { // too many groups: every row would be read R times
+      // (up to ~1.2e6 groups the hashed single-level tile sort is the faster pipeline -- measured, q3 at 1e8 rows / 1e6 ids: 1.20 ms
+      // against 1.55 here, the scatter's returning LDS atomics meet on 50 counters -- beyond it the alternative makes two partition
+      // levels: q3 at 1e9 rows / 1e7 ids 23.3 -> 18.8 ms)
+      static const bool part_any = getenv("PLHIP_DENSE_PARTITION_ANY") != nullptr; // (tests: the mode at small sizes)
+      if (comm || dk[0].validity || n_pad > 0xFFFFFFFFull || getenv("PLHIP_NO_DENSE_PARTITION")) return PLHIP_OK;
+      if (!part_any && !forced && (n < (1 << 22) || A.n_slots <= 1200000u)) return PLHIP_OK;
+      A.gpr = (uint32_t)((LDS_CAP - 16 * DENSE_MAX_PART_ACCS) / state_max) & ~3u;
+      const uint64_t np = ((uint64_t)A.n_slots + A.gpr - 1) / A.gpr;
+      if (np > (1u << TS_MAX_PBITS)) return PLHIP_OK;
+      R = (uint32_t)np;
+      while ((1u << pbits) < R) pbits++;
+      np_pow2 = 1u << pbits;
+      pmode = true;
+      break;
+    }
     A.gpr = (((A.n_slots + R - 1) / R) + 3u) & ~3u;
     const bool fits = (uint64_t)(A.gpr + rep) * state_max + 16 * DENSE_MAX_PART_ACCS <= LDS_CAP;
     if (fits && (uint64_t)(R - 1) * A.gpr < A.n_slots) break;
@@ -1420,7 +1448,7 @@ int run_dense(const Lowered &L0, const std::vector<DevCol> &dk, uint32_t flags, 
     uint64_t dof = 0;
     for (uint32_t i = 0; i < D.n_accs; i++) {
       D.loff[i] = lo; lo += ((A.gpr + rep) * D.lw[i] + 15u) & ~15u;
-      D.doff[i] = (uint32_t)dof; dof += ((uint64_t)R * A.gpr * D.lw[i] + 15u) & ~15ull;
+      D.doff[i] = (uint32_t)dof; dof += ((uint64_t)(pmode ? 1u : R) * A.gpr * D.lw[i] + 15u) & ~15ull; // (partition mode: a slice holds ONE range)
     }
     if (dof > 0xFFFFFFFFull) return PLHIP_OK;
     D.slice_stride = (dof + 255) & ~255ull;
@@ -1435,7 +1463,7 @@ int run_dense(const Lowered &L0, const std::vector<DevCol> &dk, uint32_t flags, 
       const uint32_t vd = V.dtype;
       const bool i4 = vd == PLHIP_I32 || vd == PLHIP_U32;
       auto is = [&](uint32_t i, uint32_t op, uint32_t lw) { return P.accs[D.acc[i]].op == op && D.lw[i] == lw; };
-      if (!vv || (!V.valid_bytes && (V.boff & 3) == 0)) {
+      if (!vv || (!pmode && !V.valid_bytes && (V.boff & 3) == 0)) { // (the partitioned copies carry a validity BYTE per row: run-time kind)
         if (i4 && D.n_accs == 2 && is(0, ACC_CNT_ALL, 4) && is(1, ACC_ADD_U64, 4)) D.kind = DENSE_KIND_CNT_SUM32;
         else if (i4 && D.n_accs == 1 && is(0, ACC_ADD_U64, 4)) D.kind = DENSE_KIND_SUM32;
         else if (vd == PLHIP_F64 && D.n_accs == 1 && is(0, ACC_ADD_F64, 8)) D.kind = DENSE_KIND_SUMF64;
@@ -1454,7 +1482,7 @@ int run_dense(const Lowered &L0, const std::vector<DevCol> &dk, uint32_t flags, 
   const uint32_t slots = dbg_slots ? (uint32_t)atoi(dbg_slots) : (uint32_t)std::max(1, cus / 8) * wg_per_cu;
   // group slots: every XCD lane holds slots / R of them; they are dealt to the parts in proportion to the bytes a part
   // reads per row, so that every workgroup streams about the same number of bytes
-  const uint32_t n_gs = (slots / R) * A.xcds;
+  const uint32_t n_gs = pmode ? A.n_parts : (slots / R) * A.xcds;
   if (n_gs < A.n_parts) return PLHIP_OK;
   uint32_t nsl[DENSE_MAX_PARTS];
   for (uint32_t p = 0; p < A.n_parts; p++) nsl[p] = 1;
@@ -1486,7 +1514,7 @@ int run_dense(const Lowered &L0, const std::vector<DevCol> &dk, uint32_t flags, 
     slot += D.n_slices;
     const int64_t per = (n + D.n_slices - 1) / D.n_slices;
     D.rows_per_slice = (per + DENSE_BATCH - 1) / DENSE_BATCH * DENSE_BATCH;
-    if ((uint64_t)D.rows_per_slice * 8u >= 0xFFFFFFFFull) { // the row loop addresses a slice with 32-bit byte offsets
+    if (!pmode && (uint64_t)D.rows_per_slice * 8u >= 0xFFFFFFFFull) { // the row loop addresses a slice with 32-bit byte offsets
       if (!comm) return PLHIP_OK;
       local_bad = true;
     }
@@ -1494,7 +1522,19 @@ int run_dense(const Lowered &L0, const std::vector<DevCol> &dk, uint32_t flags, 
     dump_bytes += D.slice_stride * D.n_slices;
   }
   const uint32_t q = ((slot + A.xcds - 1) / A.xcds) * R; // positions per XCD lane
-  const uint32_t n_wgs = q * A.xcds;
+  uint32_t n_wgs = q * A.xcds;
+  if (pmode) { // S slices per (part, partition): about two workgroups per CU and part in flight, whatever the partition count
+    A.pmode = 1;
+    A.S = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, ((uint64_t)2 * cus * wg_per_cu + (uint64_t)R * A.n_parts - 1) / ((uint64_t)R * A.n_parts)));
+    dump_bytes = 0;
+    for (uint32_t p = 0; p < A.n_parts; p++) {
+      DensePart &D = A.part[p];
+      D.n_slices = A.S; D.slot0 = 0; D.rows_per_slice = 0;
+      D.dump_off = dump_bytes;
+      dump_bytes += D.slice_stride * A.S * R;
+    }
+    n_wgs = A.n_parts * R * A.S;
+  }
   HIP_TRY(c.dump.reserve(dump_bytes + 256));
   HIP_TRY(c.flags.reserve(FLAGS_BYTES));
   A.dump = (uint8_t *)c.dump.p;
@@ -1562,7 +1602,44 @@ int run_dense(const Lowered &L0, const std::vector<DevCol> &dk, uint32_t flags, 
   const uint32_t seq = c.seq;
   const bool timed = c.timed();
   if (timed) hipEventRecord(c.ev[1], c.stream);
-  if (fold_runs) launch_dense_fold(P, A, n_wgs, lds_bytes, c.stream);
+  Plan P2 = P; // partition mode: the fold and the merge read the partitioned copies
+  if (pmode) {
+    const uint32_t n_tiles = (uint32_t)((n + TS_TILE - 1) / TS_TILE);
+    size_t off_totals = (size_t)np_pow2 * n_tiles * 4, off_start = off_totals + (size_t)np_pow2 * 4;
+    size_t off_cnt = (off_start + (size_t)(np_pow2 + 1) * 4 + 63) & ~(size_t)63;
+    HIP_TRY(c.items.reserve(off_cnt + 64));
+    uint8_t *sb = (uint8_t *)c.items.p;
+    uint32_t *counts = (uint32_t *)sb, *totals = (uint32_t *)(sb + off_totals), *pstart = (uint32_t *)(sb + off_start), *cnt = (uint32_t *)(sb + off_cnt);
+    PartOut PO{};
+    PO.key_bytes = 4;
+    size_t bytes = ((size_t)n_pad * 4 + 511) & ~(size_t)255;
+    size_t off_val[PLHIP_MAX_VALS], off_valid[PLHIP_MAX_VALS];
+    for (int v = 0; v < P.n_vals; v++) {
+      off_val[v] = bytes;
+      bytes += ((size_t)n_pad * dtype_width((int)P.vals[v].dtype) + 511) & ~(size_t)255;
+      off_valid[v] = bytes;
+      if (P.vals[v].validity) bytes += ((size_t)n_pad + 511) & ~(size_t)255;
+    }
+    HIP_TRY(c.part.reserve(bytes + 256));
+    uint8_t *pa = (uint8_t *)c.part.p;
+    PO.keys = pa;
+    for (int v = 0; v < P.n_vals; v++) { PO.vals[v] = pa + off_val[v]; PO.valid[v] = P.vals[v].validity ? pa + off_valid[v] : nullptr; }
+    const uint32_t recip = (uint32_t)((((uint64_t)1 << 32) + A.gpr - 1) / A.gpr);
+    launch_dense_part_hist(P, key_bias, A.gpr, recip, R, np_pow2, A.hint, n_tiles, counts, dflags, c.stream);
+    launch_part_scan(counts, np_pow2, n_tiles, totals, c.stream);
+    launch_part_plan(totals, np_pow2, pstart, nullptr, cnt, cnt + 1, 1u << 30, c.stream, (uint32_t)TS_TILE);
+    TileSortLevel1 S1{pstart, totals, np_pow2, 0u};
+    S1.range_gpr = A.gpr; S1.range_bias = key_bias; S1.range_recip = recip; S1.range_np = R;
+    launch_tile_sort(P, PO, pbits, n_tiles, counts, 1 /* the key's raw 32 bits */, 0ull, 4, c.stream, &S1, true);
+    hipError_t pe = hipGetLastError();
+    if (pe != hipSuccess) return fail_hip(pe, "range partition launch");
+    if (timed) hipEventRecord(c.ev[4], c.stream);
+    P2.n_rows = (int64_t)n_pad;
+    P2.keys[0].values = PO.keys; P2.keys[0].validity = nullptr; P2.keys[0].boff = 0;
+    for (int v = 0; v < P.n_vals; v++) { P2.vals[v].values = PO.vals[v]; P2.vals[v].validity = PO.valid[v]; P2.vals[v].boff = 0; P2.vals[v].valid_bytes = 1; }
+    A.part_start = pstart; A.part_rows = totals;
+  }
+  if (fold_runs) launch_dense_fold(P2, A, n_wgs, lds_bytes, c.stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail_hip(e, "k_dense_fold launch");
   if (timed) hipEventRecord(c.ev[5], c.stream);
@@ -1579,7 +1656,7 @@ int run_dense(const Lowered &L0, const std::vector<DevCol> &dk, uint32_t flags, 
     S.shuffle_bytes = (int64_t)(X.slot_bytes * X.world);
     S.host_syncs = comm->nccl ? 0 : 1; // (the host's transport drains the stream before it moves the bytes)
   }
-  launch_dense_merge(P, comm ? A2 : A, OP, out_cap, c.host_sig_dev, seq, c.stream);
+  launch_dense_merge(P2, comm ? A2 : A, OP, out_cap, c.host_sig_dev, seq, c.stream);
   if ((e = hipGetLastError()) != hipSuccess) return fail_hip(e, "k_dense_merge launch");
   if (timed) hipEventRecord(c.ev[2], c.stream);
   uint32_t fl[16] = {0};
@@ -1590,8 +1667,8 @@ int run_dense(const Lowered &L0, const std::vector<DevCol> &dk, uint32_t flags, 
   if (comm) { c.shard_stats.host_syncs++; lap(c.shard_stats.merge_ms); }
   if (!fl[FLAG_OVERFLOW] && c.signal_seen) c.flags_clean = 2; // (the signal was seen: the kernel's last workgroup has zeroed its counters)
   else if (hipMemsetAsync(dflags, 0, 64, c.stream) == hipSuccess) c.flags_clean = true;
-  if (timed) c.timing_pending = 4;
-  c.strategy = "dense";
+  if (timed) c.timing_pending = pmode ? 5 : 4;
+  c.strategy = pmode ? "dense_part" : "dense";
   if (getenv("PLHIP_DENSE_VERBOSE"))
     fprintf(stderr, "dense: parts %u R %u gpr %u lds %zu B wgs %u dump %llu B slices %u %u kinds %u %u\n", A.n_parts, R, A.gpr, lds_bytes, n_wgs,
             (unsigned long long)dump_bytes, A.part[0].n_slices, A.part[1].n_slices, A.part[0].kind, A.part[1].kind);
@@ -2988,7 +3065,10 @@ int32_t plhip_group_tuples(const plhip_column_t *keys, int32_t n_keys, int32_t s
   Gp->n_rows = n;
   Gp->on_device = true;
   uint64_t G = 0;
-  auto dev_alloc = [&](uint32_t **p, size_t count) { return hipMalloc((void **)p, (count ? count : 1) * 4); };
+  Gp->device = c.device;
+  // the CSR arrays come from the result-buffer pool and the scratch from the thread's workspace: at 1e7 rows the four hipMalloc, the
+  // hipFree and the sort helper's own allocations were 10 of the call's 12.6 ms
+  auto dev_alloc = [&](uint32_t **p, size_t *cap, size_t count) { return g_pool.get(c.device, (count ? count : 1) * 4, (void **)p, cap); };
   if (n > 0) {
     Staging st;
     std::vector<DevCol> dk(n_keys);
@@ -2997,51 +3077,67 @@ int32_t plhip_group_tuples(const plhip_column_t *keys, int32_t n_keys, int32_t s
     L.P.n_rows = n;
     if ((rc = build_keys(L.P, dk, st, L.KG))) { delete Gp; return rc; }
     Plan &P = L.P;
+    // the table is sized from a sampled estimate of the groups (the general path's, estimate_unique_count's analogue): a table
+    // for n distinct keys is 2^25 slots at 1e7 rows, and initialising and compacting it cost 1.1 ms for 1e5 groups.  A low
+    // estimate overflows (probe limit) and the second attempt takes the table every input fits.
+    uint64_t g_est = (uint64_t)n;
+    if (n >= (1 << 14) && (rc = estimate_groups(P, g_est))) { delete Gp; return rc; }
     const int first_acc = add_acc(P, ACC_FIRST_ROW, CONV_NONE, -1, 4, 0xFFFFFFFFull);
-    const uint64_t cap = next_pow2(std::max<uint64_t>(2 * (uint64_t)n, 1024));
-    const uint64_t n_slots = cap + 2;
-    plan_layout(P, n_slots);
-    hipError_t e = c.table.reserve(table_bytes(P, n_slots));
-    if (e == hipSuccess) e = c.flags.reserve(FLAGS_BYTES);
-    if (e == hipSuccess) e = c.slots.reserve(n_slots * 8);
-    if (e == hipSuccess) e = c.rank.reserve(n_slots * 4);
-    if (e != hipSuccess) { delete Gp; return fail_hip(e, "group_tuples scratch"); }
-    TableRef T{(uint8_t *)c.table.p, cap, (uint32_t *)c.flags.p};
-    uint64_t *slots = (uint64_t *)c.slots.p;
-    launch_table_init(P, T, c.stream);
-    launch_agg_global(P, T, c.stream);
-    launch_compact(P, T, slots, c.stream);
+    TableRef T{};
+    uint64_t *slots = nullptr;
     uint32_t fl[16];
-    if ((rc = read_flags(T, fl))) { delete Gp; return rc; }
-    if (fl[FLAG_OVERFLOW]) { delete Gp; return fail(PLHIP_ERR_COMPUTE, "hash table overflow at load factor <= 0.5"); }
-    G = fl[FLAG_NGROUPS];
-    if (sorted && G > 1) { // groups ordered by their first row (hashing.rs:32-79)
-      if ((e = c.sortkeys.reserve(G * 8)) != hipSuccess) { delete Gp; return fail_hip(e, "group_tuples scratch"); }
-      launch_gather_sort_keys(P, T, slots, G, first_acc, (uint64_t *)c.sortkeys.p, c.stream);
-      if ((e = sort_pairs_u64((uint64_t *)c.sortkeys.p, slots, G, 32, c.stream)) != hipSuccess) { delete Gp; return fail_hip(e, "sort"); }
+    hipError_t e = hipSuccess;
+    for (int attempt = 0;; attempt++) {
+      const uint64_t want = attempt == 0 ? std::min<uint64_t>((uint64_t)n, g_est * 2 + 1024) : (uint64_t)n;
+      const uint64_t cap = next_pow2(std::max<uint64_t>(2 * want, 1024));
+      const uint64_t n_slots = cap + 2;
+      plan_layout(P, n_slots);
+      e = c.table.reserve(table_bytes(P, n_slots));
+      if (e == hipSuccess) e = c.flags.reserve(FLAGS_BYTES);
+      if (e == hipSuccess) e = c.slots.reserve(2 * n_slots * 8); // the slot list, and its copy in first-row order
+      if (e == hipSuccess) e = c.rank.reserve(n_slots * 4);
+      if (e != hipSuccess) { delete Gp; return fail_hip(e, "group_tuples scratch"); }
+      T = TableRef{(uint8_t *)c.table.p, cap, (uint32_t *)c.flags.p};
+      slots = (uint64_t *)c.slots.p;
+      launch_table_init(P, T, c.stream);
+      launch_agg_global(P, T, c.stream);
+      launch_compact(P, T, slots, c.stream);
+      if ((rc = read_flags(T, fl))) { delete Gp; return rc; }
+      if (!fl[FLAG_OVERFLOW]) break;
+      if (attempt >= 1) { delete Gp; return fail(PLHIP_ERR_COMPUTE, "hash table overflow at load factor <= 0.5"); }
     }
-    uint32_t *ids = nullptr;
-    e = dev_alloc(&ids, (size_t)n);
-    if (e == hipSuccess) e = dev_alloc(&Gp->indices, (size_t)n);
-    if (e == hipSuccess) e = dev_alloc(&Gp->offsets, (size_t)G + 1);
-    if (e == hipSuccess) e = dev_alloc(&Gp->first, (size_t)G);
+    G = fl[FLAG_NGROUPS];
+    const size_t tmp_bytes = sort_pairs_tmp_bytes((uint64_t)n);
+    const size_t n4 = ((size_t)n * 4 + 255) & ~(size_t)255, g8 = ((size_t)G * 8 + 255) & ~(size_t)255;
+    if ((e = c.sortkeys.reserve(tmp_bytes + 2 * g8)) != hipSuccess || (e = c.part.reserve(3 * n4)) != hipSuccess) { delete Gp; return fail_hip(e, "group_tuples scratch"); }
+    uint8_t *tmp = (uint8_t *)c.sortkeys.p;
+    if (sorted && G > 1) { // groups ordered by their first row (hashing.rs:32-79)
+      uint64_t *k_in = (uint64_t *)(tmp + tmp_bytes), *k_out = (uint64_t *)(tmp + tmp_bytes + g8), *slots_out = slots + (T.cap + 2);
+      launch_gather_sort_keys(P, T, slots, G, first_acc, k_in, c.stream);
+      if ((e = sort_pairs_u64_ws(k_in, k_out, slots, slots_out, G, 32, tmp, tmp_bytes, c.stream)) != hipSuccess) { delete Gp; return fail_hip(e, "sort"); }
+      slots = slots_out;
+    }
+    uint32_t *ids = (uint32_t *)c.part.p, *ids_sorted = (uint32_t *)((uint8_t *)c.part.p + n4), *rows = (uint32_t *)((uint8_t *)c.part.p + 2 * n4);
+    e = dev_alloc(&Gp->indices, &Gp->cap_indices, (size_t)n);
+    if (e == hipSuccess) e = dev_alloc(&Gp->offsets, &Gp->cap_offsets, (size_t)G + 1);
+    if (e == hipSuccess) e = dev_alloc(&Gp->first, &Gp->cap_first, (size_t)G);
     if (e == hipSuccess) {
       launch_rank_scatter(slots, G, (uint32_t *)c.rank.p, c.stream);
       launch_encode_rows(P, T, (const uint32_t *)c.rank.p, ids, c.stream);
-      launch_iota_u32(Gp->indices, (uint64_t)n, c.stream);
-      e = sort_pairs_u32(ids, Gp->indices, (uint64_t)n, std::max(1, bit_length(G ? G - 1 : 0)), c.stream);
+      launch_iota_u32(rows, (uint64_t)n, c.stream);
+      // stable: the rows of a group stay ascending (the invariant of GroupsIdx, proxy.rs:16-20)
+      e = sort_pairs_u32_ws(ids, ids_sorted, rows, Gp->indices, (uint64_t)n, std::max(1, bit_length(G ? G - 1 : 0)), tmp, tmp_bytes, c.stream);
     }
     if (e == hipSuccess) {
-      launch_csr(ids, Gp->indices, (uint64_t)n, G, Gp->offsets, Gp->first, c.stream);
+      launch_csr(ids_sorted, Gp->indices, (uint64_t)n, G, Gp->offsets, Gp->first, c.stream);
       e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
-    if (ids) hipFree(ids);
     if (e != hipSuccess) { delete Gp; return fail_hip(e, "group_tuples"); }
   } else {
-    hipError_t e = dev_alloc(&Gp->indices, 0);
-    if (e == hipSuccess) e = dev_alloc(&Gp->offsets, 1);
-    if (e == hipSuccess) e = dev_alloc(&Gp->first, 0);
+    hipError_t e = dev_alloc(&Gp->indices, &Gp->cap_indices, 0);
+    if (e == hipSuccess) e = dev_alloc(&Gp->offsets, &Gp->cap_offsets, 1);
+    if (e == hipSuccess) e = dev_alloc(&Gp->first, &Gp->cap_first, 0);
     if (e == hipSuccess) e = hipMemset(Gp->offsets, 0, 4);
     if (e != hipSuccess) { delete Gp; return fail_hip(e, "group_tuples"); }
   }

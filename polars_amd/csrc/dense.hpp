@@ -66,6 +66,13 @@ struct DenseArgs {
   uint32_t slot_base; // k_dense_merge over received owner slots: entry s is global slot slot_base + s (0 otherwise)
   uint32_t n_hdr;     // ... and the n_hdr slots (part[0].slice_stride apart in `dump`) start with a header whose first word flags a sender
                       // that could not keep the dense promise (0: `dump` holds k_dense_fold's partial arrays, no headers)
+  // Partition mode (more groups than DENSE_MAX_RANGES ranges hold): the rows have been scattered by code range into R = np
+  // partition-contiguous copies first (k_dense_part_hist + the tile sort's scatter variant), and a workgroup owns
+  // (part, partition p, slice of the partition's rows): range p of the codes in ONE table, every row read once per part.
+  uint32_t pmode;     // 1: partition mode
+  uint32_t S;         // slices per partition (= DensePart::n_slices); a slice's partial arrays hold gpr entries
+  const uint32_t *part_start; // [R + 1] first row of every partition in the partitioned copies (multiples of the tile)
+  const uint32_t *part_rows;  // [R] its rows
   uint8_t *dump;
   uint32_t *flags;
   DensePart part[DENSE_MAX_PARTS];
@@ -91,3 +98,7 @@ static_assert(sizeof(Plan) + sizeof(OutPlan) + sizeof(DenseArgs) + 32 <= 4096, "
 void launch_dense_fold(const Plan &p, const DenseArgs &a, uint32_t n_wgs, size_t lds_bytes, hipStream_t s);
 void launch_dense_merge(const Plan &p, const DenseArgs &a, const OutPlan &o, uint64_t out_cap, uint32_t *host_sig, uint32_t seq, hipStream_t s);
 void launch_dense_scatter(const Plan &p, const DenseArgs &a, const DenseXchg &x, hipStream_t s);
+// counts[p * n_tiles + tile] = rows of tile `tile` (TS_TILE rows each) whose code (key - bias) / gpr is p; a code >= n_codes raises
+// flags[FLAG_OVERFLOW] (and is counted in the last partition, as the scatter will place it)
+void launch_dense_part_hist(const Plan &p, uint32_t bias, uint32_t gpr, uint32_t recip, uint32_t np, uint32_t np_pow2, uint32_t n_codes,
+                            uint32_t n_tiles, uint32_t *counts, uint32_t *flags, hipStream_t s);

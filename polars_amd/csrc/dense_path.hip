@@ -10,6 +10,7 @@
 
 #include "dense.hpp"
 #include "device.hpp"
+#include "fast.hpp"
 #include "kernels.hpp"
 
 extern __shared__ __align__(16) uint8_t dsm[];
@@ -354,14 +355,25 @@ __global__ void __launch_bounds__(DENSE_BLOCK) k_dense_fold(Plan P, DenseArgs A)
   __shared__ uint32_t sh[4];
   // workgroup -> (group slot, range): the R workgroups of a slot share blockIdx.x % xcds, i.e. (as observed, for speed only)
   // an XCD and its L2, which serves R - 1 of the slot's R reads of every row; part p owns the slots [slot0, slot0 + n_slices)
-  const uint32_t x = blockIdx.x % A.xcds, q = blockIdx.x / A.xcds;
-  const uint32_t gs = (q / A.R) * A.xcds + x, range = q % A.R;
+  uint32_t range, slice;
   int p = -1;
-  for (uint32_t i = 0; i < A.n_parts; i++)
-    if (gs >= A.part[i].slot0 && gs < A.part[i].slot0 + A.part[i].n_slices) p = (int)i;
-  if (p < 0) return;
+  if (A.pmode) { // partition mode: workgroup -> (part, partition, slice of the partition); the partition's index is the range's
+    // (32-bit divisions run on the vector unit; readfirstlane hands the wave-uniform results back to the scalar side, where the
+    // row loop's inline-asm loads want their base pointers)
+    slice = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x % A.S));
+    range = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x / A.S) % A.R));
+    p = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / (A.S * A.R)));
+    if (p >= (int)A.n_parts) return;
+  } else {
+    const uint32_t x = blockIdx.x % A.xcds, q = blockIdx.x / A.xcds;
+    const uint32_t gs = (q / A.R) * A.xcds + x;
+    range = q % A.R;
+    for (uint32_t i = 0; i < A.n_parts; i++)
+      if (gs >= A.part[i].slot0 && gs < A.part[i].slot0 + A.part[i].n_slices) p = (int)i;
+    if (p < 0) return;
+    slice = gs - A.part[p].slot0;
+  }
   const DensePart &D = A.part[p];
-  const uint32_t slice = gs - D.slot0;
   const uint32_t c0 = range * A.gpr;
   const uint32_t cnt = c0 < A.n_slots ? (A.n_slots - c0 < A.gpr ? A.n_slots - c0 : A.gpr) : 0u;
   const bool is_last = cnt != 0 && c0 + cnt == A.n_slots;
@@ -374,8 +386,21 @@ __global__ void __launch_bounds__(DENSE_BLOCK) k_dense_fold(Plan P, DenseArgs A)
   }
   __syncthreads();
   int64_t row0 = (int64_t)slice * D.rows_per_slice, row1 = row0 + D.rows_per_slice;
-  if (row1 > P.n_rows) row1 = P.n_rows;
+  if (A.pmode) { // the partition's rows, cut into S slices of whole batches
+    const int64_t pr = (int64_t)A.part_rows[range], p0 = (int64_t)A.part_start[range];
+    const int64_t per = ((pr + A.S - 1) / A.S + DENSE_BATCH - 1) / DENSE_BATCH * DENSE_BATCH;
+    row0 = p0 + (int64_t)slice * per; row1 = row0 + per;
+    if (row1 > p0 + pr) row1 = p0 + pr;
+    if ((uint64_t)per * 8u >= 0xFFFFFFFFull) { // (the row loop addresses a slice with 32-bit byte offsets: a partition this large -- extreme
+      if (threadIdx.x == 0) A.flags[FLAG_OVERFLOW] = 1; // skew at >= 5e8 rows -- goes back to the hashed path)
+      row1 = row0;
+    }
+  } else if (row1 > P.n_rows) row1 = P.n_rows;
   if (row0 > row1) row0 = row1;
+  { // wave-uniform by construction (block index, uniform loads); said so to the compiler: the row loop's loads take their base in SGPRs
+    row0 = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)row0 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)row0));
+    row1 = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)row1 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)row1));
+  }
   uint32_t bad = 0;
   if (cnt) {
     switch (D.kind) {
@@ -401,11 +426,11 @@ __global__ void __launch_bounds__(DENSE_BLOCK) k_dense_fold(Plan P, DenseArgs A)
   }
   __syncthreads();
   // the range's arrays -> the slice's partial arrays (plain 16-byte stores)
-  uint8_t *dslice = A.dump + D.dump_off + (uint64_t)slice * D.slice_stride;
+  uint8_t *dslice = A.dump + D.dump_off + (uint64_t)(A.pmode ? range * A.S + slice : slice) * D.slice_stride;
   for (uint32_t i = 0; i < D.n_accs; i++) {
     const uint32_t lw = D.lw[i], chunks = al16u(A.gpr * lw) >> 4;
     const uint4 *src = (const uint4 *)(dsm + D.loff[i]);
-    uint4 *dst = (uint4 *)(dslice + D.doff[i] + (uint64_t)c0 * lw);
+    uint4 *dst = (uint4 *)(dslice + D.doff[i] + (uint64_t)(A.pmode ? 0u : c0) * lw); // (partition mode: a slice's arrays hold its range only)
     for (uint32_t c = threadIdx.x; c < chunks; c += DENSE_BLOCK) dst[c] = src[c];
   }
 }
@@ -434,6 +459,10 @@ __device__ __forceinline__ void dense_sum_slices(const Plan &P, const DenseArgs 
       uint64_t acc[4] = {init, init, init, init};
       if (have) {
         const uint8_t *col = A.dump + D.dump_off + D.doff[i] + (uint64_t)g0 * lw;
+        if (A.pmode) { // the S slices of the quad's partition, gpr entries each (gpr is a multiple of 4: a quad has one partition)
+          const uint32_t pp = g0 / A.gpr;
+          col = A.dump + D.dump_off + (uint64_t)pp * A.S * D.slice_stride + D.doff[i] + (uint64_t)(g0 - pp * A.gpr) * lw;
+        }
         for (uint32_t s0 = w4; s0 < D.n_slices; s0 += MG_U * W) {
           uint64_t v[MG_U][4];
 #pragma unroll
@@ -586,7 +615,42 @@ __global__ void __launch_bounds__(DENSE_BLOCK) k_dense_scatter(Plan P, DenseArgs
   }
 }
 
+// Partition mode, pass 1: rows per (code range, tile) -- what the tile sort's scatter variant places its runs by.  One
+// workgroup per TS_TILE rows, the key column in 16-byte loads, LDS atomics on the range counters.
+__global__ void __launch_bounds__(1024) k_dense_part_hist(Plan P, uint32_t bias, uint32_t gpr, uint32_t recip, uint32_t np, uint32_t np_pow2,
+                                                         uint32_t n_codes, uint32_t n_tiles, uint32_t *__restrict__ counts, uint32_t *__restrict__ flags) {
+  __shared__ uint32_t h[1u << TS_MAX_PBITS];
+  __shared__ uint32_t s_bad;
+  for (uint32_t i = threadIdx.x; i < np_pow2; i += 1024) h[i] = 0;
+  if (threadIdx.x == 0) s_bad = 0;
+  __syncthreads();
+  const int64_t r0 = (int64_t)blockIdx.x * TS_TILE;
+  const int64_t r1 = r0 + TS_TILE < P.n_rows ? r0 + TS_TILE : P.n_rows;
+  const uint32_t *keys = (const uint32_t *)P.keys[0].values;
+  uint32_t bad = 0;
+  for (int64_t q = r0 + (int64_t)threadIdx.x * 4; q < r1; q += 4096) {
+    uint32_t k[4];
+    uint32_t nk = 4;
+    if (q + 4 <= r1 && (((uintptr_t)(keys + q)) & 15u) == 0) { const uint4 v = *(const uint4 *)(keys + q); k[0] = v.x; k[1] = v.y; k[2] = v.z; k[3] = v.w; }
+    else { nk = (uint32_t)(r1 - q < 4 ? r1 - q : 4); for (uint32_t b = 0; b < nk; b++) k[b] = keys[q + b]; }
+    for (uint32_t b = 0; b < nk; b++) {
+      const uint32_t code = k[b] - bias;
+      if (code >= n_codes) bad = 1;
+      atomicAdd(&h[range_part(code, gpr, recip, np)], 1u);
+    }
+  }
+  if (bad) s_bad = 1;
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < np_pow2; i += 1024) counts[(uint64_t)i * n_tiles + blockIdx.x] = h[i];
+  if (threadIdx.x == 0 && s_bad) flags[FLAG_OVERFLOW] = 1; // a code outside the promised range: the caller falls back to the hashed path
+}
+
 } // namespace
+
+void launch_dense_part_hist(const Plan &p, uint32_t bias, uint32_t gpr, uint32_t recip, uint32_t np, uint32_t np_pow2, uint32_t n_codes,
+                            uint32_t n_tiles, uint32_t *counts, uint32_t *flags, hipStream_t s) {
+  hipLaunchKernelGGL(k_dense_part_hist, dim3(n_tiles), dim3(1024), 0, s, p, bias, gpr, recip, np, np_pow2, n_codes, n_tiles, counts, flags);
+}
 
 template <bool RT, bool KV>
 static void launch_dense_fold_t(const Plan &p, const DenseArgs &a, uint32_t n_wgs, size_t lds_bytes, hipStream_t s) {

@@ -138,7 +138,17 @@ struct TileSortLevel1 {
   uint32_t *hot_rows;         // level 2, may be nullptr: [np1 << pbits] zeroed; runs of at least hot_run rows are added to their leaf's word
   uint32_t hot_run, pad;
   uint32_t *hot_any;          // single level, may be nullptr: set to 1 when any long run was seen
+  // scatter variant only, range partitions of dense codes (dense_path.hip, k_dense_part_hist has the same function): range_gpr != 0
+  // -> partition = min((key - range_bias) / range_gpr, range_np - 1) instead of hash bits (range_recip = ceil(2^32 / range_gpr))
+  uint32_t range_gpr, range_bias, range_recip, range_np;
 };
+// code / gpr for code < 2^31 without a division: the reciprocal estimate is off by at most one
+__device__ __forceinline__ uint32_t range_part(uint32_t code, uint32_t gpr, uint32_t recip, uint32_t np) {
+  uint32_t q = __umulhi(code, recip);
+  if ((uint64_t)q * gpr > code) q--;
+  else if ((uint64_t)(q + 1) * gpr <= code) q++;
+  return q < np ? q : np - 1u; // (a code beyond the promised range: the histogram pass has raised the overflow flag)
+}
 // hot_rows[] (rows in long runs per leaf) -> H + hot_rows[] rewritten as entry index + 1 / 0.  A leaf is split when it has
 // at least min_rows such rows, into ceil(rows / chunk_rows) chunks (at most HOT_MAX_CHUNKS, at most its tiles).
 void launch_hot_plan(uint32_t *hot_rows, uint32_t n_leaves, uint32_t n_pg, const uint32_t *seg_start, uint32_t min_rows, uint32_t chunk_rows,

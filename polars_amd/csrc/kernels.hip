@@ -476,6 +476,23 @@ hipError_t sort_pairs_u32(uint32_t *keys, uint32_t *vals, uint64_t n, int end_bi
   return e;
 }
 
+// The same sorts on caller-supplied buffers: no allocation, no copy back, no host wait (the hipMalloc / hipFree / synchronise
+// of the forms above cost 10 of plhip_group_tuples' 12.6 ms at 1e7 rows).  `tmp` holds sort_pairs_tmp_bytes(n) bytes.
+size_t sort_pairs_tmp_bytes(uint64_t n) {
+  size_t a = 0, b = 0;
+  if (rocprim::radix_sort_pairs(nullptr, a, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, n, 0, 32) != hipSuccess) a = 0;
+  if (rocprim::radix_sort_pairs(nullptr, b, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint64_t *)nullptr, n, 0, 64) != hipSuccess) b = 0;
+  return (a > b ? a : b) + 256;
+}
+hipError_t sort_pairs_u32_ws(const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, uint64_t n, int end_bit, void *tmp,
+                             size_t tmp_bytes, hipStream_t s) { // stable
+  return rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, n, 0, end_bit, s);
+}
+hipError_t sort_pairs_u64_ws(const uint64_t *kin, uint64_t *kout, const uint64_t *vin, uint64_t *vout, uint64_t n, int end_bit, void *tmp,
+                             size_t tmp_bytes, hipStream_t s) {
+  return rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, n, 0, end_bit, s);
+}
+
 void launch_iota_u32(uint32_t *out, uint64_t n, hipStream_t s) {
   if (n) hipLaunchKernelGGL(k_iota_u32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, n);
 }

@@ -76,6 +76,12 @@ hipError_t sort_pairs_u64(uint64_t *keys, uint64_t *vals, uint64_t n, int end_bi
 
 // two-step API
 hipError_t sort_pairs_u32(uint32_t *keys, uint32_t *vals, uint64_t n, int end_bit, hipStream_t s); // stable
+// on caller-supplied buffers (no allocation, no copy back, no host wait); tmp: sort_pairs_tmp_bytes(n) bytes
+size_t sort_pairs_tmp_bytes(uint64_t n);
+hipError_t sort_pairs_u32_ws(const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, uint64_t n, int end_bit, void *tmp,
+                             size_t tmp_bytes, hipStream_t s); // stable
+hipError_t sort_pairs_u64_ws(const uint64_t *kin, uint64_t *kout, const uint64_t *vin, uint64_t *vout, uint64_t n, int end_bit, void *tmp,
+                             size_t tmp_bytes, hipStream_t s);
 void launch_iota_u32(uint32_t *out, uint64_t n, hipStream_t s);
 void launch_csr(const uint32_t *ids_sorted, const uint32_t *indices, uint64_t n, uint64_t G, uint32_t *offsets, uint32_t *first, hipStream_t s);
 // `o.outs[0]` is the one output column; at most 4 accumulators; o.outs[0].validity must be zeroed

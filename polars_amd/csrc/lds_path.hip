@@ -464,25 +464,37 @@ __global__ void __launch_bounds__(PART_BLOCK) k_part_hist(Plan P, uint32_t pbits
   for (uint32_t p = threadIdx.x; p < np; p += PART_BLOCK) counts[(uint64_t)p * n_tiles + blockIdx.x] = h[p];
 }
 
-// one workgroup per partition: counts[p][*] -> exclusive prefix over tiles (in place), totals[p]
+// one workgroup per partition: counts[p][*] -> exclusive prefix over tiles (in place), totals[p].  The row is walked in
+// blocks of 1024 entries -- thread t takes the four consecutive entries 4t .. 4t + 3, so a wave reads and writes 1 KB
+// contiguous -- with the running total carried from block to block (the first version gave every thread one long contiguous
+// chunk: lanes strided by the chunk, 0.84 ms for the 512 x 122 071 counts of a 1e9-row input, 0.6 TB/s).
 __global__ void __launch_bounds__(256) k_part_scan(uint32_t *__restrict__ counts, uint32_t n_tiles, uint32_t *__restrict__ totals) {
-  __shared__ uint32_t sums[256];
+  __shared__ uint32_t wsum[4];
+  __shared__ uint32_t carry;
   uint32_t *c = counts + (uint64_t)blockIdx.x * n_tiles;
-  const uint32_t chunk = (n_tiles + 255) / 256;
-  const uint32_t b = threadIdx.x * chunk, e = b + chunk < n_tiles ? b + chunk : n_tiles;
-  uint32_t s = 0;
-  for (uint32_t i = b; i < e; i++) s += c[i];
-  sums[threadIdx.x] = s;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry = 0;
   __syncthreads();
-  for (int off = 1; off < 256; off <<= 1) { // Hillis-Steele inclusive scan over the 256 chunk sums
-    uint32_t v = threadIdx.x >= (uint32_t)off ? sums[threadIdx.x - off] : 0;
+  for (uint32_t base = 0; base < n_tiles; base += 1024) {
+    const uint32_t i0 = base + threadIdx.x * 4u;
+    uint32_t v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = i0 + k < n_tiles ? c[i0 + k] : 0u;
+    const uint32_t mine = v[0] + v[1] + v[2] + v[3];
+    uint32_t incl = mine; // inclusive scan over the wave
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, off); if (lane >= (uint32_t)off) incl += o; }
+    if (lane == 63) wsum[wave] = incl;
     __syncthreads();
-    sums[threadIdx.x] += v;
+    uint32_t before = carry;
+    for (uint32_t w = 0; w < wave; w++) before += wsum[w];
+    uint32_t run = before + incl - mine;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { if (i0 + k < n_tiles) c[i0 + k] = run; run += v[k]; }
+    __syncthreads();
+    if (threadIdx.x == 255) carry = run; // (the last thread's running total is the block's)
     __syncthreads();
   }
-  uint32_t run = threadIdx.x ? sums[threadIdx.x - 1] : 0;
-  for (uint32_t i = b; i < e; i++) { const uint32_t v = c[i]; c[i] = run; run += v; }
-  if (threadIdx.x == 255) totals[blockIdx.x] = sums[255];
+  if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
 // single workgroup: partition starts (exclusive scan of totals) + the aggregation pass's work items

@@ -193,11 +193,16 @@ def test_range_boundaries(oracle, ncat):
 
 
 def test_too_many_categories_declines(oracle):
+    # beyond eight code ranges: under AUTO the hashed pipelines take a query of this size (the partition mode starts at 2^22 rows and
+    # 1.2e6 codes); the forced strategy takes the partition mode; a nullable key has no partition mode and declines even when forced
     rng = np.random.default_rng(9)
     n = 400_000
     key = codes(rng, n, 300_000)
     v = Column("v", rng.uniform(0, 1, n))
-    check(oracle, key, [v], [(0, "sum"), (0, "mean")], 300_000, expect=("tilesort", "tilesort2", "sort", "partitioned", "global"), what="beyond eight ranges")
+    hashed = ("tilesort", "tilesort2", "sort", "partitioned", "global")
+    check(oracle, key, [v], [(0, "sum"), (0, "mean")], 300_000, expect=hashed, what="beyond eight ranges, auto", strategy="auto")
+    check(oracle, key, [v], [(0, "sum"), (0, "mean")], 300_000, expect="dense_part", what="beyond eight ranges, forced")
+    check(oracle, codes(rng, n, 300_000, 0.02), [v], [(0, "sum"), (0, "mean")], 300_000, expect=hashed, what="beyond eight ranges, nullable key")
 
 
 def test_arrow_offsets_and_partial_flag(oracle):
@@ -232,3 +237,62 @@ def test_arrow_offsets_and_partial_flag(oracle):
         finally:
             _ffi.lib().plhip_result_free(handle)
     util.assert_frames_match(frames[0], frames[1], 1, what="partial frames: dense vs direct")
+
+
+# ---- partition mode: more groups than DENSE_MAX_RANGES code ranges hold (the counterpart stays group_tuples_perfect, perfect.rs:24-185:
+# codes index the tables; here the rows are first scattered by code range, api.hip run_dense) ----------------------------------------
+PART_N = 4_400_000  # (under AUTO the mode starts at 2^22 rows and 1.2e6 codes; forced strategy "dense" takes it at any size)
+
+
+def _part_case(rng, ncat, skew=None, never=()):
+    k = rng.integers(0, ncat, PART_N).astype(np.uint32)
+    if skew is not None:  # one code range holds most rows
+        hot = rng.random(PART_N) < 0.6
+        k[hot] = rng.integers(skew, skew + 50, int(hot.sum())).astype(np.uint32)
+    for c in never:
+        k[k == c] = (c + 1) % ncat
+    return Column("k", k)
+
+
+@pytest.mark.parametrize("ncat", [250_000, 1_300_000])
+def test_partition_mode_q3_shape(oracle, ncat):
+    rng = np.random.default_rng(ncat)
+    key = _part_case(rng, ncat, never=(0, 17, ncat - 1))
+    v1 = Column("v1", rng.integers(1, 6, PART_N).astype(np.int32))
+    v3 = Column("v3", np.round(rng.uniform(0, 100, PART_N), 6))
+    check(oracle, key, [v1, v3], [(0, "sum"), (1, "mean")], ncat, expect="dense_part", what=f"partition mode q3, {ncat} codes",
+          strategy="auto" if ncat > 1_200_000 else "dense")
+
+
+def test_partition_mode_all_aggregations_nullable_values_and_skew(oracle):
+    rng = np.random.default_rng(99)
+    ncat = 400_000
+    key = _part_case(rng, ncat, skew=123_456)
+    v1 = Column("v1", rng.integers(-1000, 1000, PART_N).astype(np.int32), rng.random(PART_N) >= 0.07)
+    v3 = Column("v3", np.round(rng.uniform(0, 100, PART_N), 6), rng.random(PART_N) >= 0.1)  # (one sign: the f64 bound is relative to sum |x|)
+    v8 = Column("v8", rng.integers(-2**40, 2**40, PART_N).astype(np.int64))
+    aggs = [(0, a) for a in ALL_AGGS] + [(1, a) for a in ALL_AGGS] + [(2, "sum"), (2, "min"), (2, "max")]
+    check(oracle, key, [v1, v3, v8], aggs, ncat, expect="dense_part", what="partition mode, every aggregation", strategy="dense")
+
+
+def test_partition_mode_plain_i32_key_with_a_compact_range(oracle):
+    # db-benchmark's id6 at scale: no flag from the caller, AUTO measures the key's range and takes the partition mode
+    rng = np.random.default_rng(5)
+    lo, span = -70_000, 1_500_000
+    k = Column("k", rng.integers(lo, lo + span, PART_N).astype(np.int32))
+    v = Column("v", rng.integers(0, 100, PART_N).astype(np.int32))
+    want, _ = oracle.group_by_agg([k], [v], [(0, "sum"), (0, "count")])
+    pa.set_strategy("auto")
+    df = pa.DataFrame({"k": k, "v": v})
+    got = df.group_by("k").agg(pa.col("v").sum().alias("s"), pa.count().alias("c"))
+    assert pa.last_strategy() == "dense_part", pa.last_strategy()
+    util.assert_frames_match(util.frame_to_np(got), util.oracle_to_np(want), 1, what="partition mode, plain i32 key")
+
+
+def test_partition_mode_code_beyond_the_hint_falls_back(oracle):
+    rng = np.random.default_rng(6)
+    ncat = 1_250_000
+    key = _part_case(rng, ncat)
+    key.values[12345] = ncat + 7  # the caller's promise is broken: the hashed path redoes the query
+    v = Column("v", rng.integers(0, 9, PART_N).astype(np.int32))
+    check(oracle, key, [v], [(0, "sum"), (0, "count")], ncat, expect=("tilesort", "tilesort2", "sort"), what="partition mode, bad code", strategy="auto")
