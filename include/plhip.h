@@ -257,6 +257,19 @@ int32_t plhip_last_kernel_breakdown(float *tile_sort_ms, float *fold_ms, float *
 int32_t plhip_vec_hash(const plhip_column_t *keys, int32_t n_keys, uint64_t null_hash, uint64_t *out,
                        int32_t out_location);
 
+/* The same with Boolean key columns among the keys (dtype PLHIP_BOOL: values = the Arrow bitmap).  VecHash for BooleanChunked
+ * (vector_hasher.rs:241-302): a Boolean value hashes to random_state.hash_one(true) / hash_one(false) -- seed dependent like the
+ * null hash, so the caller supplies both -- and a Boolean column behind the first one combines with
+ *   _boost_hash_combine(l, h) = l ^ (h + 0x9e3779b9 + (l << 6) + (h >> 2))     (hashing/mod.rs:20-22)
+ * instead of folded_multiply.  Integer and float columns hash as in plhip_vec_hash. */
+typedef struct plhip_hash_seeds {
+  uint64_t null_hash;  /* get_null_hash_value(random_state) */
+  uint64_t true_hash;  /* random_state.hash_one(true) */
+  uint64_t false_hash; /* random_state.hash_one(false) */
+} plhip_hash_seeds_t;
+int32_t plhip_vec_hash_seeded(const plhip_column_t *keys, int32_t n_keys, const plhip_hash_seeds_t *seeds, uint64_t *out,
+                              int32_t out_location);
+
 /* ---- fused group-by + aggregation ------------------------------------------------------------- */
 
 /* Replaces group_by_helper / GroupByExec::execute end to end

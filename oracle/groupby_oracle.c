@@ -97,6 +97,36 @@ int orc_vec_hash(const plhip_column_t *keys, int n_keys, uint64_t null_h, uint64
   return PLHIP_OK;
 }
 
+/* _boost_hash_combine (crates/polars-core/src/hashing/mod.rs:20-22) */
+static inline uint64_t orc_boost_hash_combine(uint64_t l, uint64_t r) { return l ^ (r + (0x9e3779b9ULL + (l << 6) + (r >> 2))); }
+
+/* series_to_hashes (vector_hasher.rs:467-483) with Boolean columns among the keys (PLHIP_BOOL: values = a bitmap).
+ * VecHash for BooleanChunked (:241-302): the first column's hash is true_h / false_h / null_h (random_state.hash_one(bool):
+ * seed dependent, so the caller supplies the two constants as it supplies null_h); a later Boolean column combines with
+ * _boost_hash_combine(l, h), l in {true_h, false_h, null_h} -- not with folded_multiply as the integer columns do. */
+int orc_vec_hash_seeded(const plhip_column_t *keys, int n_keys, uint64_t null_h, uint64_t true_h, uint64_t false_h, uint64_t *out) {
+  if (n_keys < 1 || !keys || !out) return PLHIP_ERR_INVALID;
+  int64_t n = keys[0].length;
+  for (int k = 0; k < n_keys; k++) {
+    if (keys[k].length != n) return PLHIP_ERR_SHAPE_MISMATCH;
+    if (keys[k].dtype != PLHIP_BOOL && !col_width(keys[k].dtype)) return PLHIP_ERR_UNSUPPORTED_DTYPE;
+  }
+  for (int k = 0; k < n_keys; k++) {
+    const plhip_column_t *c = &keys[k];
+    for (int64_t i = 0; i < n; i++) {
+      const int valid = col_valid(c, i);
+      if (c->dtype == PLHIP_BOOL) {
+        const int64_t b = c->offset + i;
+        const int v = (((const uint8_t *)c->values)[b >> 3] >> (b & 7)) & 1;
+        const uint64_t l = !valid ? null_h : (v ? true_h : false_h);
+        out[i] = k == 0 ? l : orc_boost_hash_combine(l, out[i]);
+      } else if (k == 0) out[i] = valid ? orc_folded_multiply(col_as_u64(c, i), ORC_MULTIPLE) : null_h;
+      else out[i] = orc_folded_multiply((valid ? col_as_u64(c, i) : null_h) ^ out[i], ORC_MULTIPLE);
+    }
+  }
+  return PLHIP_OK;
+}
+
 /* ---------------------------------------------------------------------------------------------- */
 /* group tuples                                                                                   */
 /* ---------------------------------------------------------------------------------------------- */

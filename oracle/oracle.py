@@ -43,6 +43,7 @@ def lib():
         L.orc_folded_multiply.argtypes = [C.c_uint64, C.c_uint64]
         L.orc_folded_multiply.restype = C.c_uint64
         L.orc_vec_hash.argtypes = [P(_ffi.ColumnStruct), C.c_int, C.c_uint64, C.c_void_p]
+        L.orc_vec_hash_seeded.argtypes = [P(_ffi.ColumnStruct), C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]
         L.orc_group_tuples.argtypes = [P(_ffi.ColumnStruct), C.c_int, C.c_int, C.c_int, P(_Groups)]
         L.orc_groups_free.argtypes = [P(_Groups)]
         L.orc_groups_free.restype = None
@@ -83,6 +84,13 @@ def folded_multiply(s: int, by: int) -> int:
 def vec_hash(keys: list[Column], null_h: int) -> np.ndarray:
     out = np.empty(len(keys[0]), dtype=np.uint64)
     _check(lib().orc_vec_hash(_structs(keys), len(keys), null_h, out.ctypes.data))
+    return out
+
+
+def vec_hash_seeded(keys: list[Column], null_h: int, true_h: int, false_h: int) -> np.ndarray:
+    """series_to_hashes with Boolean columns (dtype BOOL: values = a packed bitmap): orc_vec_hash_seeded."""
+    out = np.empty(len(keys[0]), dtype=np.uint64)
+    _check(lib().orc_vec_hash_seeded(_structs(keys), len(keys), null_h, true_h, false_h, out.ctypes.data))
     return out
 
 

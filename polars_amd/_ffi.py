@@ -77,6 +77,12 @@ class ColumnStruct(C.Structure):
     ]
 
 
+class HashSeeds(C.Structure):
+    """plhip_hash_seeds_t"""
+
+    _fields_ = [("null_hash", C.c_uint64), ("true_hash", C.c_uint64), ("false_hash", C.c_uint64)]
+
+
 class AggStruct(C.Structure):
     """plhip_agg_t"""
 
@@ -184,6 +190,8 @@ def lib():
     L.plhip_last_kernel_breakdown.restype = i32
     L.plhip_vec_hash.argtypes = [P(ColumnStruct), i32, u64, vp, i32]
     L.plhip_vec_hash.restype = i32
+    L.plhip_vec_hash_seeded.argtypes = [P(ColumnStruct), i32, P(HashSeeds), vp, i32]
+    L.plhip_vec_hash_seeded.restype = i32
     L.plhip_group_by_agg.argtypes = [P(ColumnStruct), i32, P(ColumnStruct), i32, P(AggStruct), i32, u32, P(vp)]
     L.plhip_group_by_agg.restype = i32
     L.plhip_group_by_agg_opts.argtypes = [P(ColumnStruct), i32, P(ColumnStruct), i32, P(AggStruct), i32, u32,
@@ -290,7 +298,7 @@ def check(status: int) -> None:
 
 EXPORTED_SYMBOLS = [
     "plhip_abi_version", "plhip_init", "plhip_last_error", "plhip_set_strategy", "plhip_last_strategy",
-    "plhip_last_kernel_ms", "plhip_memcpy", "plhip_last_kernel_breakdown", "plhip_vec_hash", "plhip_group_by_agg", "plhip_group_by_agg_opts", "plhip_result_num_rows",
+    "plhip_last_kernel_ms", "plhip_memcpy", "plhip_last_kernel_breakdown", "plhip_vec_hash", "plhip_vec_hash_seeded", "plhip_group_by_agg", "plhip_group_by_agg_opts", "plhip_result_num_rows",
     "plhip_result_num_columns", "plhip_result_column", "plhip_result_free", "plhip_group_tuples",
     "plhip_groups_num_groups", "plhip_groups_num_rows", "plhip_groups_buffers", "plhip_groups_free",
     "plhip_agg_groups", "plhip_agg_groups_quantile", "plhip_result_record_bytes", "plhip_result_pack_by_owner", "plhip_records_to_frame", "plhip_merge_records", "plhip_finalize_partial", "plhip_slot_bytes", "plhip_result_pack_slots", "plhip_merge_slots",

@@ -2119,9 +2119,9 @@ int32_t plhip_last_kernel_breakdown(float *tile_sort_ms, float *fold_ms, float *
   return PLHIP_OK;
 }
 
-int32_t plhip_vec_hash(const plhip_column_t *keys, int32_t n_keys, uint64_t null_hash, uint64_t *out,
-                       int32_t out_location) {
+int32_t plhip_vec_hash_seeded(const plhip_column_t *keys, int32_t n_keys, const plhip_hash_seeds_t *seeds, uint64_t *out, int32_t out_location) {
   if (!keys || n_keys < 1 || n_keys > PLHIP_MAX_KEYS) return fail(PLHIP_ERR_INVALID, "bad key columns");
+  if (!seeds) return fail(PLHIP_ERR_INVALID, "seeds is NULL");
   int rc = ensure_ctx();
   if (rc) return rc;
   Ctx &c = g_ctx;
@@ -2131,10 +2131,31 @@ int32_t plhip_vec_hash(const plhip_column_t *keys, int32_t n_keys, uint64_t null
   if (n > 0 && !out) return fail(PLHIP_ERR_INVALID, "output pointer is NULL");
   Staging st;
   std::vector<DevCol> dk(n_keys);
-  for (int i = 0; i < n_keys; i++) if ((rc = stage_column(keys[i], dk[i], st, c.stream))) return rc;
   Plan P{};
   P.n_rows = n; P.n_keys = n_keys;
   for (int i = 0; i < n_keys; i++) {
+    if (keys[i].dtype == PLHIP_BOOL) { // an Arrow boolean array: the values buffer is a bitmap; staged as the bytes that hold the slice
+      plhip_column_t bytes = keys[i];
+      const int64_t b0 = keys[i].offset >> 3, b1 = (keys[i].offset + n + 7) >> 3;
+      bytes.dtype = PLHIP_U8; bytes.values = keys[i].values ? (const uint8_t *)keys[i].values + b0 : nullptr; bytes.offset = 0; bytes.length = b1 - b0;
+      bytes.validity = nullptr;
+      DevCol vb, vd;
+      if ((rc = stage_column(bytes, vb, st, c.stream))) return rc;
+      if (keys[i].validity) { // (its validity bitmap: device columns stay put, host bitmaps are staged like the values')
+        if (keys[i].location == PLHIP_DEVICE) { vd.validity = keys[i].validity; vd.boff = keys[i].offset; }
+        else {
+          plhip_column_t vv = keys[i];
+          vv.dtype = PLHIP_U8; vv.values = (const uint8_t *)keys[i].validity + b0; vv.offset = 0; vv.length = b1 - b0; vv.validity = nullptr;
+          DevCol t;
+          if ((rc = stage_column(vv, t, st, c.stream))) return rc;
+          vd.validity = t.values; vd.boff = keys[i].offset & 7;
+        }
+      }
+      P.keys[i].values = vb.values; P.keys[i].minv = (uint64_t)(keys[i].offset & 7);
+      P.keys[i].validity = vd.validity; P.keys[i].boff = vd.boff; P.keys[i].dtype = PLHIP_BOOL;
+      continue;
+    }
+    if ((rc = stage_column(keys[i], dk[i], st, c.stream))) return rc;
     P.keys[i].values = dk[i].values; P.keys[i].validity = dk[i].validity; P.keys[i].boff = dk[i].boff;
     P.keys[i].dtype = dk[i].dtype;
   }
@@ -2144,11 +2165,19 @@ int32_t plhip_vec_hash(const plhip_column_t *keys, int32_t n_keys, uint64_t null
     HIP_TRY(c.misc.reserve((size_t)n * 8));
     dout = (uint64_t *)c.misc.p;
   }
-  launch_vec_hash(P, null_hash, dout, c.stream);
+  launch_vec_hash(P, seeds->null_hash, seeds->true_hash, seeds->false_hash, dout, c.stream);
   HIP_TRY(hipGetLastError());
   if (out_location == PLHIP_HOST) HIP_TRY(hipMemcpyAsync(out, dout, (size_t)n * 8, hipMemcpyDeviceToHost, c.stream));
   HIP_TRY(hipStreamSynchronize(c.stream));
   return PLHIP_OK;
+}
+
+int32_t plhip_vec_hash(const plhip_column_t *keys, int32_t n_keys, uint64_t null_hash, uint64_t *out, int32_t out_location) {
+  if (keys && n_keys >= 1 && n_keys <= PLHIP_MAX_KEYS)
+    for (int i = 0; i < n_keys; i++)
+      if (keys[i].dtype == PLHIP_BOOL) return fail(PLHIP_ERR_UNSUPPORTED_DTYPE, "a Boolean key hashes to seed-dependent constants: plhip_vec_hash_seeded takes them");
+  const plhip_hash_seeds_t seeds{null_hash, 0, 0};
+  return plhip_vec_hash_seeded(keys, n_keys, &seeds, out, out_location);
 }
 
 int32_t group_by_agg_impl(const plhip_column_t *keys, int32_t n_keys, const plhip_column_t *values, int32_t n_values,

@@ -413,26 +413,32 @@ void launch_copy_bits(uint32_t *dst, int64_t dst_off, const uint8_t *src, int64_
 // ---------------------------------------------------------------------------------------------------------
 // VecHash (crates/polars-core/src/hashing/vector_hasher.rs:78-139, 467-483)
 // ---------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_vec_hash(Plan P, uint64_t null_h, uint64_t *out) {
+// A Boolean key column (PLHIP_BOOL: `values` is a bitmap; KeySpec::minv carries the bit offset of element 0) hashes to one of the
+// caller's constants and, behind the first column, combines with _boost_hash_combine (hashing/mod.rs:20-22) instead of
+// folded_multiply: VecHash for BooleanChunked, vector_hasher.rs:241-302.
+DEVINL uint64_t boost_hash_combine(uint64_t l, uint64_t r) { return l ^ (r + (0x9e3779b9ull + (l << 6) + (r >> 2))); }
+__global__ void __launch_bounds__(256) k_vec_hash(Plan P, uint64_t null_h, uint64_t true_h, uint64_t false_h, uint64_t *out) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < P.n_rows; row += stride) {
-    const KeySpec &K0 = P.keys[0];
-    uint64_t h = bit_valid(K0.validity, K0.boff, row)
-                     ? folded_multiply(load_as_u64(K0.values, K0.dtype, row), PLHIP_MULTIPLE)
-                     : null_h;
-    for (int k = 1; k < P.n_keys; k++) {
+    uint64_t h = 0;
+    for (int k = 0; k < P.n_keys; k++) {
       const KeySpec &K = P.keys[k];
-      const uint64_t v = bit_valid(K.validity, K.boff, row) ? load_as_u64(K.values, K.dtype, row) : null_h;
-      h = folded_multiply(v ^ h, PLHIP_MULTIPLE);
+      const bool valid = bit_valid(K.validity, K.boff, row);
+      if (K.dtype == PLHIP_BOOL) {
+        const int64_t b = (int64_t)K.minv + row;
+        const uint64_t l = !valid ? null_h : (((K.values[b >> 3] >> (b & 7)) & 1) ? true_h : false_h);
+        h = k == 0 ? l : boost_hash_combine(l, h);
+      } else if (k == 0) h = valid ? folded_multiply(load_as_u64(K.values, K.dtype, row), PLHIP_MULTIPLE) : null_h;
+      else h = folded_multiply((valid ? load_as_u64(K.values, K.dtype, row) : null_h) ^ h, PLHIP_MULTIPLE);
     }
     out[row] = h;
   }
 }
 
-void launch_vec_hash(const Plan &p, uint64_t null_hash, uint64_t *out, hipStream_t s) {
+void launch_vec_hash(const Plan &p, uint64_t null_hash, uint64_t true_hash, uint64_t false_hash, uint64_t *out, hipStream_t s) {
   int64_t blocks = (p.n_rows + 255) / 256;
   int grid = (int)(blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks));
-  hipLaunchKernelGGL(k_vec_hash, dim3(grid), dim3(256), 0, s, p, null_hash, out);
+  hipLaunchKernelGGL(k_vec_hash, dim3(grid), dim3(256), 0, s, p, null_hash, true_hash, false_hash, out);
 }
 
 // ---------------------------------------------------------------------------------------------------------

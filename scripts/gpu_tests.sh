@@ -1,7 +1,7 @@
 #!/bin/bash
-# Runs the GPU parity tests on the box; output goes to gpurun_out/.
+# Runs the GPU parity tests on the box as the driver does at round end; output goes to gpurun_out/.
 mkdir -p gpurun_out
-timeout -k 10 ${1:-600} python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread ${@:2} > gpurun_out/pytest_gpu.log 2>&1
+timeout -k 10 ${1:-1100} python -u -m pytest tests -m gpu -x -q --timeout 600 --timeout-method thread ${@:2} > gpurun_out/pytest_gpu.log 2>&1
 rc=$?
-tail -40 gpurun_out/pytest_gpu.log
+tail -15 gpurun_out/pytest_gpu.log
 exit $rc

@@ -132,3 +132,34 @@ def test_agg_quantile_known_answers(oracle):
     assert v.tolist() == [1.0, 1.0] and m.all()
     v, m = oracle.agg_quantile(Column("a", np.array([1, 2, 3, 4, 5], dtype=np.int64)), 1.5, "nearest", g5)
     assert v.dtype == np.int64 and not m.any()  # aggregations/mod.rs:346-349
+
+
+def test_boolean_vec_hash_combine_formula(oracle):
+    """VecHash for BooleanChunked (vector_hasher.rs:241-302) + _boost_hash_combine (hashing/mod.rs:20-22), restated in plain Python:
+    the first column hashes to true_h / false_h / null_h, a later Boolean column combines as l ^ (h + 0x9e3779b9 + (l << 6) + (h >> 2));
+    integer columns keep folded_multiply.  The three constants are seed dependent in the reference (random_state.hash_one), hence
+    arguments here: what is pinned is the combine arithmetic."""
+    import numpy as np
+
+    from polars_amd.column import Column
+
+    M64 = (1 << 64) - 1
+    MULT = 6364136223846793005
+    fm = lambda s, by: ((s * by) & M64) ^ ((s * by) >> 64)
+    boost = lambda l, r: l ^ ((r + ((0x9E3779B9 + ((l << 6) & M64) + (r >> 2)) & M64)) & M64)
+    null_h, true_h, false_h = 0x0123456789ABCDEF, 0xF00DFACE12345678, 0x0BADC0DE87654321
+    rng = np.random.default_rng(1)
+    n = 301
+    b1, b2 = rng.random(n) < 0.5, rng.random(n) < 0.3
+    m2 = rng.random(n) >= 0.2
+    k = rng.integers(-5, 5, n).astype(np.int32)
+    cols = [Column("b1", b1), Column("k", k), Column("b2", b2, m2)]
+    got = oracle.vec_hash_seeded(cols, null_h, true_h, false_h)
+    for i in range(n):
+        h = true_h if b1[i] else false_h
+        h = fm((int(k[i]) & 0xFFFFFFFF) ^ h, MULT)
+        l = null_h if not m2[i] else (true_h if b2[i] else false_h)
+        h = boost(l, h)
+        assert int(got[i]) == h, (i, hex(int(got[i])), hex(h))
+    # without Boolean columns it is plhip_vec_hash / orc_vec_hash
+    assert np.array_equal(oracle.vec_hash_seeded([Column("k", k)], null_h, 1, 2), oracle.vec_hash([Column("k", k)], null_h))

@@ -291,6 +291,49 @@ def test_vec_hash_parity(oracle):
     assert np.array_equal(out, want)
 
 
+def test_vec_hash_boolean_columns(oracle):
+    """plhip_vec_hash_seeded: Boolean keys hash to the caller's true / false / null constants and combine with
+    _boost_hash_combine (VecHash for BooleanChunked, vector_hasher.rs:241-302; hashing/mod.rs:20-22): against the oracle, host and
+    device bitmaps, with an Arrow offset that is not a multiple of 8."""
+    import ctypes as C
+
+    import torch
+
+    rng = np.random.default_rng(33)
+    n = 50_003
+    seeds = _ffi.HashSeeds(0x0123456789ABCDEF, 0xF00DFACE12345678, 0x0BADC0DE87654321)
+    b1 = Column("b1", rng.random(n) < 0.5)
+    b2 = Column("b2", rng.random(n) < 0.3, rng.random(n) >= 0.2)
+    k = rand_col(rng, "k", np.int64, n, null_frac=0.1)
+    for keys in ([b1], [b1, k, b2], [k, b2, b1], [b2]):
+        want = oracle.vec_hash_seeded(keys, seeds.null_hash, seeds.true_hash, seeds.false_hash)
+        out = np.empty(n, dtype=np.uint64)
+        arr = (_ffi.ColumnStruct * len(keys))(*[c.struct() for c in keys])
+        _ffi.check(_ffi.lib().plhip_vec_hash_seeded(arr, len(keys), C.byref(seeds), out.ctypes.data, _ffi.HOST))
+        assert np.array_equal(out, want), [c.name for c in keys]
+    # a slice at an odd bit offset, bitmaps resident in HBM
+    off, m = 13, 20_000
+    structs, keep = [], []
+    for c in (b2, b1):
+        cs = c.struct()
+        nb = (n + 7) // 8
+        tv = torch.from_numpy(np.ctypeslib.as_array(C.cast(cs.values, C.POINTER(C.c_uint8)), shape=(nb,)).copy()).to("cuda:0")
+        tm = None
+        if cs.validity:
+            tm = torch.from_numpy(np.ctypeslib.as_array(C.cast(cs.validity, C.POINTER(C.c_uint8)), shape=(nb,)).copy()).to("cuda:0")
+        keep += [tv, tm]
+        structs.append(_ffi.ColumnStruct(tv.data_ptr(), tm.data_ptr() if tm is not None else None, off, m, _ffi.BOOL, _ffi.DEVICE))
+    torch.cuda.synchronize()
+    want = oracle.vec_hash_seeded([b2, b1], seeds.null_hash, seeds.true_hash, seeds.false_hash)[off:off + m]  # (row-wise: a slice of the hashes)
+    out = np.empty(m, dtype=np.uint64)
+    _ffi.check(_ffi.lib().plhip_vec_hash_seeded((_ffi.ColumnStruct * 2)(*structs), 2, C.byref(seeds), out.ctypes.data, _ffi.HOST))
+    assert np.array_equal(out, want)
+    # the unseeded entry point refuses Boolean keys instead of hashing them with made-up constants
+    out1 = np.empty(n, dtype=np.uint64)
+    rc = _ffi.lib().plhip_vec_hash((_ffi.ColumnStruct * 1)(b1.struct()), 1, 7, out1.ctypes.data, _ffi.HOST)
+    assert rc == 4 and b"plhip_vec_hash_seeded" in _ffi.lib().plhip_last_error()
+
+
 def test_error_kinds():
     with pytest.raises(pa.ComputeError):
         pa.DataFrame({"a": np.zeros(3, np.int32)}).group_by().agg(pa.count())
