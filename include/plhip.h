@@ -518,6 +518,18 @@ int32_t plhip_hash_join(const plhip_column_t *left, const plhip_column_t *right,
 int32_t plhip_hash_join_multi(const plhip_column_t *left_keys, const plhip_column_t *right_keys, int32_t n_keys, int32_t how,
                               int32_t out_location, plhip_join_t **out);
 int64_t plhip_join_num_rows(const plhip_join_t *j);
+
+/* The other half of a join: the payload gather.  DataFrame::_finish_join's inputs are `df.take_unchecked(left_idx)` and
+ * `other._take_opt_chunked_unchecked(right_idx)` (crates/polars-ops/src/frame/join/hash_join/mod.rs:105-201; general.rs:9-): row i of
+ * every output column is row idx[i] of the input column, null where idx[i] == PLHIP_JOIN_NONE (the missing side of a left / outer
+ * join) or where the source row is null.  One call gathers all payload columns of a side on the device: `cols` fixed-width columns
+ * of equal length (host or device), `idx` the join's index array (plhip_join_buffers: device-resident after a PLHIP_DEVICE join, so
+ * the pairs never leave HBM between the two calls).  The result frame has n_cols columns of n_idx rows; a column carries a
+ * validity bitmap when its source does or when PLHIP_TAKE_NULLABLE_IDX says the indices may hold PLHIP_JOIN_NONE.  Indices are
+ * trusted (< the columns' length), as in the reference's unchecked takes.  flags: PLHIP_FLAG_OUTPUT_DEVICE, PLHIP_TAKE_NULLABLE_IDX. */
+#define PLHIP_TAKE_NULLABLE_IDX 256u
+int32_t plhip_take(const plhip_column_t *cols, int32_t n_cols, const uint32_t *idx, int64_t n_idx, int32_t idx_location, uint32_t flags,
+                   plhip_result_t **out);
 /* u32 = IdxSize pairs, owned by the handle, in `*location` memory */
 int32_t plhip_join_buffers(const plhip_join_t *j, const uint32_t **left_idx, const uint32_t **right_idx, int32_t *location);
 void plhip_join_free(plhip_join_t *j);

@@ -36,6 +36,7 @@ FLAG_KEYS_SORTED = 8
 FLAG_PARTIAL = 4
 FLAG_KEYS_DENSE = 16
 FLAG_EXACT_FOLD = 64
+TAKE_NULLABLE_IDX = 256
 
 STRATEGIES = {"auto": 0, "global": 1, "lds": 2, "partitioned": 3, "direct": 4, "tilesort": 5, "sort": 6, "tilesort2": 7, "dense": 8}
 
@@ -190,6 +191,8 @@ def lib():
     L.plhip_last_kernel_breakdown.restype = i32
     L.plhip_vec_hash.argtypes = [P(ColumnStruct), i32, u64, vp, i32]
     L.plhip_vec_hash.restype = i32
+    L.plhip_take.argtypes = [P(ColumnStruct), i32, vp, i64, i32, u32, P(vp)]
+    L.plhip_take.restype = i32
     L.plhip_vec_hash_seeded.argtypes = [P(ColumnStruct), i32, P(HashSeeds), vp, i32]
     L.plhip_vec_hash_seeded.restype = i32
     L.plhip_group_by_agg.argtypes = [P(ColumnStruct), i32, P(ColumnStruct), i32, P(AggStruct), i32, u32, P(vp)]
@@ -298,7 +301,7 @@ def check(status: int) -> None:
 
 EXPORTED_SYMBOLS = [
     "plhip_abi_version", "plhip_init", "plhip_last_error", "plhip_set_strategy", "plhip_last_strategy",
-    "plhip_last_kernel_ms", "plhip_memcpy", "plhip_last_kernel_breakdown", "plhip_vec_hash", "plhip_vec_hash_seeded", "plhip_group_by_agg", "plhip_group_by_agg_opts", "plhip_result_num_rows",
+    "plhip_last_kernel_ms", "plhip_memcpy", "plhip_last_kernel_breakdown", "plhip_vec_hash", "plhip_vec_hash_seeded", "plhip_take", "plhip_group_by_agg", "plhip_group_by_agg_opts", "plhip_result_num_rows",
     "plhip_result_num_columns", "plhip_result_column", "plhip_result_free", "plhip_group_tuples",
     "plhip_groups_num_groups", "plhip_groups_num_rows", "plhip_groups_buffers", "plhip_groups_free",
     "plhip_agg_groups", "plhip_agg_groups_quantile", "plhip_result_record_bytes", "plhip_result_pack_by_owner", "plhip_records_to_frame", "plhip_merge_records", "plhip_finalize_partial", "plhip_slot_bytes", "plhip_result_pack_slots", "plhip_merge_slots",

@@ -2726,6 +2726,51 @@ int32_t plhip_join_buffers(const plhip_join_t *j, const uint32_t **left_idx, con
 
 void plhip_join_free(plhip_join_t *j) { delete j; }
 
+int32_t plhip_take(const plhip_column_t *cols, int32_t n_cols, const uint32_t *idx, int64_t n_idx, int32_t idx_location, uint32_t flags,
+                   plhip_result_t **out) {
+  if (!out) return fail(PLHIP_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  if (n_cols < 1 || n_cols > PLHIP_MAX_OUTS || !cols) return fail(PLHIP_ERR_INVALID, "bad column list");
+  if (n_idx < 0 || (n_idx > 0 && !idx) || n_idx > 0xFFFFFFFFll) return fail(PLHIP_ERR_INVALID, "bad index array");
+  if (idx_location != PLHIP_HOST && idx_location != PLHIP_DEVICE) return fail(PLHIP_ERR_INVALID, "bad idx_location");
+  int rc = ensure_ctx();
+  if (rc) return rc;
+  Ctx &c = g_ctx;
+  Staging st;
+  const uint32_t *d_idx = idx;
+  if (idx_location == PLHIP_HOST && n_idx > 0) {
+    void *p = nullptr;
+    HIP_TRY(hipMalloc(&p, (size_t)n_idx * 4));
+    st.owned.push_back(p);
+    HIP_TRY(hipMemcpyAsync(p, idx, (size_t)n_idx * 4, hipMemcpyHostToDevice, c.stream));
+    d_idx = (const uint32_t *)p;
+  }
+  std::unique_ptr<plhip_result> R_own(new (std::nothrow) plhip_result());
+  plhip_result *R = R_own.get();
+  if (!R) return fail(PLHIP_ERR_OOM, "host allocation failed");
+  R->on_device = true; R->device = c.device; R->n_rows = n_idx;
+  StreamDrain drain(c.stream); // (staged inputs and pooled outputs outlive the kernels on every path out)
+  for (int i = 0; i < n_cols; i++) {
+    if (cols[i].dtype == PLHIP_BOOL) return fail(PLHIP_ERR_UNSUPPORTED_DTYPE, "plhip_take gathers fixed-width columns (cast a Boolean payload to u8)");
+    DevCol d;
+    if ((rc = stage_column(cols[i], d, st, c.stream))) return rc;
+    const int w = dtype_width(cols[i].dtype);
+    ResultCol col;
+    col.dtype = cols[i].dtype;
+    hipError_t e = g_pool.get(c.device, (size_t)std::max<int64_t>(n_idx, 1) * w, &col.values, &col.vcap);
+    const bool nullable = d.validity != nullptr || (flags & PLHIP_TAKE_NULLABLE_IDX);
+    if (e == hipSuccess && nullable) e = g_pool.get(c.device, (size_t)(n_idx / 64 + 2) * 8, (void **)&col.validity, &col.bcap);
+    R->cols.push_back(col);
+    if (e != hipSuccess) return fail_hip(e, "hipMalloc(output)");
+    if (cols[i].length == 0 && n_idx > 0 && !(flags & PLHIP_TAKE_NULLABLE_IDX)) return fail(PLHIP_ERR_INVALID, "indices into an empty column");
+    launch_take(d.values, w, d.validity, d.boff, d_idx, n_idx, (uint8_t *)col.values, (uint64_t *)col.validity, c.stream);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c.stream));
+  drain.s = nullptr;
+  return finish_result(R_own.release(), (uint64_t)n_idx, flags & PLHIP_FLAG_OUTPUT_DEVICE, out);
+}
+
 int32_t plhip_group_by_agg_noalloc(const plhip_column_t *keys, int32_t n_keys, const plhip_column_t *values, int32_t n_values,
                                    const plhip_agg_t *aggs, int32_t n_aggs, uint32_t flags, int64_t n_groups_hint,
                                    const plhip_column_t *out_cols, int32_t n_out_cols, int64_t *n_groups) {

@@ -58,3 +58,7 @@ void launch_join_fill(int64_t n, const uint32_t *gid, const uint64_t *pos, const
                       uint32_t *out_build, hipStream_t s);
 // CSR groups (first / offsets / indices of plhip_group_tuples) -> the group of every row: gid[indices[j]] = g for offsets[g] <= j < offsets[g + 1]
 void launch_csr_to_gid(const uint32_t *offsets, const uint32_t *indices, uint32_t G, int64_t n, uint32_t *gid, hipStream_t s);
+// out[i] = vals[idx[i]] (elements of `width` bytes), null (bit 0 in out_valid, value 0) where idx[i] == JOIN_NONE or the source row is
+// null; out_valid: (n + 63) / 64 whole words, or nullptr when neither can happen
+void launch_take(const uint8_t *vals, int width, const uint8_t *validity, int64_t boff, const uint32_t *idx, int64_t n, uint8_t *out, uint64_t *out_valid,
+                 hipStream_t s);

@@ -145,3 +145,35 @@ void launch_join_fill(int64_t n, const uint32_t *gid, const uint64_t *pos, const
   if (n <= 0) return;
   hipLaunchKernelGGL(k_join_fill, dim3((unsigned)((n + JOIN_BLOCK - 1) / JOIN_BLOCK)), dim3(JOIN_BLOCK), 0, s, n, gid, pos, offsets, indices, out_probe, out_build);
 }
+
+// ---- payload gather (DataFrame::take_unchecked / _take_opt_chunked_unchecked behind _finish_join, crates/polars-ops/src/frame/join/
+// hash_join/mod.rs:105-201, general.rs:9-): out[i] = col[idx[i]], null where idx[i] == JOIN_NONE or the source row is null.  A thread per
+// output row, the width as a template argument, validity as one 64-bit ballot per wave (whole words: the bitmap is written, never ORed).
+template <typename T>
+__global__ void __launch_bounds__(256) k_take(const T *__restrict__ vals, const uint8_t *__restrict__ validity, int64_t boff, const uint32_t *__restrict__ idx,
+                                              int64_t n, T *__restrict__ out, uint64_t *__restrict__ out_valid) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; // (no early return: the wave votes)
+  bool ok = false;
+  T v = 0;
+  if (i < n) {
+    const uint32_t r = idx[i];
+    ok = r != JOIN_NONE;
+    if (ok && validity) { const int64_t b = boff + (int64_t)r; ok = (validity[b >> 3] >> (b & 7)) & 1; }
+    if (ok) v = vals[r];
+    out[i] = v;
+  }
+  const unsigned long long m = __ballot(ok);
+  if (out_valid && (threadIdx.x & 63) == 0 && (i & ~(int64_t)63) < n) out_valid[i >> 6] = m;
+}
+
+void launch_take(const uint8_t *vals, int width, const uint8_t *validity, int64_t boff, const uint32_t *idx, int64_t n, uint8_t *out, uint64_t *out_valid,
+                 hipStream_t s) {
+  if (n <= 0) return;
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  switch (width) {
+    case 1: hipLaunchKernelGGL(k_take<uint8_t>, grid, block, 0, s, (const uint8_t *)vals, validity, boff, idx, n, (uint8_t *)out, out_valid); break;
+    case 2: hipLaunchKernelGGL(k_take<uint16_t>, grid, block, 0, s, (const uint16_t *)vals, validity, boff, idx, n, (uint16_t *)out, out_valid); break;
+    case 4: hipLaunchKernelGGL(k_take<uint32_t>, grid, block, 0, s, (const uint32_t *)vals, validity, boff, idx, n, (uint32_t *)out, out_valid); break;
+    default: hipLaunchKernelGGL(k_take<uint64_t>, grid, block, 0, s, (const uint64_t *)vals, validity, boff, idx, n, (uint64_t *)out, out_valid); break;
+  }
+}

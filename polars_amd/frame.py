@@ -160,8 +160,9 @@ class DataFrame:
     def join(self, other: "DataFrame", on: str | None = None, how: str = "inner", *, left_on: str | None = None,
              right_on: str | None = None, suffix: str = "_right") -> "DataFrame":
         """DataFrame.join on one integer key, `how` = 'inner' | 'left' | 'semi' | 'anti' | 'outer' (py-polars/polars/dataframe/frame.py:5856): the index
-        pairs come from plhip_hash_join in the reference's order; the payload gather (`_finish_join`: left columns, then the
-        right ones without the key, clashing names suffixed) runs on the host."""
+        pairs come from plhip_hash_join in the reference's order and stay in HBM; the payload gather behind `_finish_join` (left
+        columns, then the right ones without the key, clashing names suffixed) is plhip_take on the device for fixed-width columns,
+        on the host for strings."""
         from .join import join_indices, take
 
         if on is not None:
@@ -176,10 +177,28 @@ class DataFrame:
                 from .strings import encode_together
 
                 lk[i], rk[i] = encode_together(lk[i], rk[i])
-        li, ri = join_indices(lk, rk, how)
+        from .join import Join
+
+        for c in lk + rk:  # (device-resident key columns: torch's queued work must have landed before the library reads them)
+            if c.location == _ffi.DEVICE and type(c.values).__module__.startswith("torch"):
+                import torch
+
+                torch.cuda.current_stream(c.values.device).synchronize()
+                break
+        jn = Join(lk, rk, how)  # the pairs stay in HBM: fixed-width payload columns are gathered there (plhip_take)
+        li, ri = jn.indices()   # (host copies: string payloads and the outer join's key coalescing)
         right_on = ro
-        out = [take(c, li, n) for n, c in self._cols.items()]
+        fixed = lambda c: type(c).__name__ == "Column" and c.dtype != _ffi.BOOL and len(c) > 0
+
+        def gather(frame_cols, side, idx, rename):
+            items = list(frame_cols.items())
+            dev = jn.take([c for _, c in items if fixed(c)], side, [rename(n) for n, c in items if fixed(c)])
+            it = iter(dev)
+            return [next(it) if fixed(c) else take(c, idx, rename(n)) for n, c in items]
+
+        out = gather(self._cols, "left", li, lambda n: n)
         if how in ("semi", "anti"):  # only the left frame's rows
+            jn.close()
             return DataFrame(out)
         if how == "outer":  # the key columns are coalesced: the right frame's key where the left side has no row
             from .join import NONE
@@ -198,10 +217,8 @@ class DataFrame:
                 mask = np.array([x is not None for x in merged], dtype=bool)
                 out[i] = Column(ln, np.array([0 if x is None else x for x in merged], dtype=dt), None if mask.all() else mask)
         taken = set(self._cols)
-        for n, c in other._cols.items():
-            if n in right_on:
-                continue
-            out.append(take(c, ri, n + suffix if n in taken else n))
+        out += gather({n: c for n, c in other._cols.items() if n not in right_on}, "right", ri, lambda n: n + suffix if n in taken else n)
+        jn.close()
         return DataFrame(out)
 
     def group_by_stable(self, *by) -> "GroupBy":

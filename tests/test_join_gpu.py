@@ -157,3 +157,51 @@ def test_string_key_join_reference_docstring():
             assert rows(out) == rows(want), how
         else:
             assert out == want, how
+
+
+def test_take_gathers_payload_on_the_device():
+    """plhip_take: the payload half of a join (`take_unchecked` / `_take_opt_chunked_unchecked` behind DataFrame::_finish_join,
+    crates/polars-ops/src/frame/join/hash_join/mod.rs:105-201): out[i] = col[idx[i]], null where idx[i] is PLHIP_JOIN_NONE or the
+    source row is null -- against numpy's take, every width, host and device-resident indices."""
+    import ctypes as C
+
+    import torch
+
+    from polars_amd.join import NONE
+
+    L = _ffi.lib()
+    rng = np.random.default_rng(8)
+    n, m = 100_003, 250_001
+    cols = [Column("a", rng.integers(-100, 100, n).astype(np.int8)), Column("b", rng.integers(0, 60000, n).astype(np.uint16), rng.random(n) >= 0.1),
+            Column("c", rng.standard_normal(n).astype(np.float32)), Column("d", rng.integers(-2**60, 2**60, n).astype(np.int64), rng.random(n) >= 0.3),
+            Column("e", rng.standard_normal(n))]
+    idx = rng.integers(0, n, m).astype(np.uint32)
+    idx[rng.random(m) < 0.05] = NONE
+    tidx = torch.from_numpy(idx.view(np.int32)).to("cuda:0")
+    torch.cuda.synchronize()
+    arr = (_ffi.ColumnStruct * len(cols))(*[c.struct() for c in cols])
+    for ptr, loc in ((idx.ctypes.data, _ffi.HOST), (tidx.data_ptr(), _ffi.DEVICE)):
+        h = C.c_void_p()
+        _ffi.check(L.plhip_take(arr, len(cols), ptr, m, loc, _ffi.TAKE_NULLABLE_IDX, C.byref(h)))
+        try:
+            assert L.plhip_result_num_rows(h) == m and L.plhip_result_num_columns(h) == len(cols)
+            for j, c in enumerate(cols):
+                cs = _ffi.ColumnStruct()
+                _ffi.check(L.plhip_result_column(h, j, C.byref(cs)))
+                got = pa.frame._host_column("x", cs)
+                miss = idx == NONE
+                safe = np.where(miss, 0, idx).astype(np.int64)
+                want_valid = ~miss if c.valid_mask() is None else (c.valid_mask()[safe] & ~miss)
+                assert np.array_equal(got.valid_mask(), want_valid), c.name
+                gv, wv = got.to_numpy()[want_valid], c.to_numpy()[safe][want_valid]
+                assert np.array_equal(gv.view(np.uint8), wv.view(np.uint8)), c.name
+        finally:
+            L.plhip_result_free(h)
+    # without the flag and without nulls in the source no bitmap is made
+    h = C.c_void_p()
+    ok_idx = np.where(idx == NONE, 0, idx).astype(np.uint32)
+    _ffi.check(L.plhip_take((_ffi.ColumnStruct * 1)(cols[0].struct()), 1, ok_idx.ctypes.data, m, _ffi.HOST, 0, C.byref(h)))
+    cs = _ffi.ColumnStruct()
+    _ffi.check(L.plhip_result_column(h, 0, C.byref(cs)))
+    assert not cs.validity and np.array_equal(pa.frame._host_column("x", cs).to_numpy(), cols[0].to_numpy()[ok_idx])
+    L.plhip_result_free(h)
