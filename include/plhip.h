@@ -347,7 +347,15 @@ int32_t plhip_group_by_agg_noalloc(const plhip_column_t *keys, int32_t n_keys, c
 int64_t plhip_result_num_rows(const plhip_result_t *r);    /* number of groups */
 int32_t plhip_result_num_columns(const plhip_result_t *r); /* n_keys + n output columns */
 /* Fills `col` with the i-th output column (location = host unless PLHIP_FLAG_OUTPUT_DEVICE). The
- * buffers belong to the result and die with plhip_result_free. */
+ * buffers belong to the result and die with plhip_result_free.
+ * Deferred completion: plhip_group_by_agg[_opts] with PLHIP_FLAG_OUTPUT_DEVICE returns as soon as the frame's row
+ * count is on the host (the last kernel publishes it through pinned memory); that kernel may still be retiring.
+ * This call -- like plhip_result_pack_* and plhip_finalize_partial -- waits for it once, so a device pointer obtained
+ * here always names complete data, readable from any stream; an error of the kernels that surfaces only then is
+ * returned here.  plhip_result_num_rows / _num_columns / _record_bytes / _free never wait: a caller that chains queries
+ * or wants only the count does not pay the ~7 us stream wait per call (a freed frame's pooled buffers carry the
+ * producing stream with them, and whoever reuses them from another stream waits first).
+ * PLHIP_NO_DEFERRED_SYNC=1 in the environment restores the blocking behaviour. */
 int32_t plhip_result_column(const plhip_result_t *r, int32_t i, plhip_column_t *col);
 void plhip_result_free(plhip_result_t *r);
 

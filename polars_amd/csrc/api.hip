@@ -52,9 +52,30 @@ struct Scratch { // grow-only device buffer reused across calls (hipMalloc/hipFr
   void release() { if (p) hipFree(p); p = nullptr; bytes = 0; }
 };
 
+// A result frame may be handed to the caller while the tail of its last kernel is still retiring (wait_signal, `defer`): whoever
+// touches its buffers next from outside the producing stream waits through this token.  The token outlives the thread's stream: a
+// thread that ends drains its stream and clears `s`, and later waits become no-ops.
+struct StreamToken {
+  std::mutex mu;
+  hipStream_t s = nullptr;
+};
+using TokenRef = std::shared_ptr<StreamToken>;
+inline hipError_t settle_token(TokenRef &t) {
+  hipError_t e = hipSuccess;
+  if (t) {
+    std::lock_guard<std::mutex> g(t->mu);
+    if (t->s) e = hipStreamSynchronize(t->s);
+  }
+  t.reset();
+  return e;
+}
+
 struct Ctx {
   int device = -1;
   hipStream_t stream = nullptr;
+  TokenRef token;             // this thread's stream, as results and pooled buffers refer to it
+  bool allow_defer = false;   // set by plhip_group_by_agg_opts around a DEVICE-output query: the last wait may skip the stream's retirement
+  bool deferred = false;      // ... and did: the result frame carries the token
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   std::string err;
   std::string strategy = "";
@@ -98,6 +119,7 @@ struct Ctx {
     if (host_flags) hipHostFree(host_flags);
     if (host_sig) hipHostFree(host_sig);
     if (host_hdr) hipHostFree(host_hdr);
+    if (token) { std::lock_guard<std::mutex> g(token->mu); token->s = nullptr; } // (drained by release_workspace above)
     if (stream) hipStreamDestroy(stream);
     device = -1;
   }
@@ -142,6 +164,8 @@ int ensure_ctx() {
   if (e != hipSuccess) dev = 0;
   HIP_TRY(hipSetDevice(dev));
   HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+  c.token = std::make_shared<StreamToken>();
+  c.token->s = c.stream;
   for (auto &ev : c.ev) HIP_TRY(hipEventCreate(&ev));
   HIP_TRY(hipHostMalloc((void **)&c.host_flags, 64, hipHostMallocDefault));
   HIP_TRY(hipHostMalloc((void **)&c.host_sig, 64, hipHostMallocMapped | hipHostMallocCoherent));
@@ -257,35 +281,48 @@ namespace {
 // Device buffers of result frames are recycled: hipMalloc / hipFree cost more than a whole small query.
 // Entries are keyed by (device, size): a thread bound to one GPU must never be handed another GPU's memory.
 struct DevPool {
-  struct Entry { int dev; size_t cap; void *p; };
+  struct Entry { int dev; size_t cap; void *p; TokenRef busy; }; // busy: the stream whose last kernel may still be writing the buffer
   std::mutex mu;
   std::vector<Entry> free_list;
   size_t pooled = 0;
   static size_t round_up(size_t b) { size_t c = 4096; while (c < b) c <<= 1; return c; }
-  // a buffer of the CURRENT device `dev` (the calling thread's Ctx::device)
-  hipError_t get(int dev, size_t bytes, void **p, size_t *cap) {
+  // a buffer of the CURRENT device `dev` (the calling thread's Ctx::device).  on_own_stream: the caller only touches the buffer from
+  // work queued on its thread's stream, so a buffer that stream is still finishing with needs no wait (stream order); anyone else
+  // waits for the producer first.
+  hipError_t get(int dev, size_t bytes, void **p, size_t *cap, bool on_own_stream = false) {
     const size_t c = round_up(bytes);
+    TokenRef busy;
+    bool hit = false;
     {
       std::lock_guard<std::mutex> g(mu);
       for (size_t i = 0; i < free_list.size(); i++)
         if (free_list[i].dev == dev && free_list[i].cap == c) {
           *p = free_list[i].p; *cap = c; pooled -= c;
-          free_list[i] = free_list.back(); free_list.pop_back();
-          return hipSuccess;
+          busy = std::move(free_list[i].busy);
+          free_list[i] = std::move(free_list.back()); free_list.pop_back();
+          hit = true;
+          break;
         }
+    }
+    if (hit) {
+      if (busy && !(on_own_stream && busy == g_ctx.token)) {
+        const hipError_t e = settle_token(busy);
+        if (e != hipSuccess) { hipFree(*p); *p = nullptr; return e; }
+      }
+      return hipSuccess;
     }
     *cap = c;
     return hipMalloc(p, c);
   }
-  void put(int dev, void *p, size_t cap) {
+  void put(int dev, void *p, size_t cap, const TokenRef &busy = nullptr) {
     if (!p) return;
     {
       std::lock_guard<std::mutex> g(mu);
       // sized for 288 GB of HBM: a one-row-per-group result at 1e8 rows is 7 GB of output columns, and handing them to
       // hipFree / hipMalloc every query costs more than a millisecond
-      if (pooled + cap <= ((size_t)48 << 30) && free_list.size() < 256) { free_list.push_back(Entry{dev, cap, p}); pooled += cap; return; }
+      if (pooled + cap <= ((size_t)48 << 30) && free_list.size() < 256) { free_list.push_back(Entry{dev, cap, p, busy}); pooled += cap; return; }
     }
-    hipFree(p);
+    hipFree(p); // (waits for the device)
   }
   // test hook / trim: how many pooled buffers belong to `dev`
   int64_t count(int dev) {
@@ -299,7 +336,7 @@ struct DevPool {
     {
       std::lock_guard<std::mutex> g(mu);
       for (size_t i = 0; i < free_list.size();)
-        if (free_list[i].dev == dev) { drop.push_back(free_list[i].p); pooled -= free_list[i].cap; free_list[i] = free_list.back(); free_list.pop_back(); }
+        if (free_list[i].dev == dev) { drop.push_back(free_list[i].p); pooled -= free_list[i].cap; free_list[i] = std::move(free_list.back()); free_list.pop_back(); }
         else i++;
     }
     for (void *q : drop) hipFree(q);
@@ -314,11 +351,14 @@ struct plhip_result {
   int64_t row_offset = 0; // a sliced frame (plhip_options_t::slice_*): the columns' Arrow offset
   bool on_device = false;
   int device = 0;
+  // set while the producing stream may still be retiring the frame's last kernel (the row count is already final): cleared by the
+  // first access to the buffers from outside that stream (settle_result)
+  mutable TokenRef pending;
   ~plhip_result() {
     for (auto &c : cols) {
       if (on_device) {
-        if (c.vcap) g_pool.put(device, c.values, c.vcap); else if (c.values) hipFree(c.values);
-        if (c.bcap) g_pool.put(device, c.validity, c.bcap); else if (c.validity) hipFree(c.validity);
+        if (c.vcap) g_pool.put(device, c.values, c.vcap, pending); else if (c.values) hipFree(c.values);
+        if (c.bcap) g_pool.put(device, c.validity, c.bcap, pending); else if (c.validity) hipFree(c.validity);
       } else { free(c.values); free(c.validity); }
     }
   }
@@ -623,7 +663,7 @@ int read_flags(TableRef t, uint32_t *out8) {
 // Waits for publish_done (fast_path.hip) of the query tagged `seq`.  The stream is polled now and then so
 // that a failed launch cannot leave the host spinning; if the stream drained without the signal the flags are
 // fetched the ordinary way.
-int wait_signal(TableRef t, uint32_t seq, uint32_t *out8) {
+int wait_signal(TableRef t, uint32_t seq, uint32_t *out8, bool defer = false) {
   Ctx &c = g_ctx;
   c.flags_clean = false;
   c.signal_seen = false;
@@ -649,7 +689,12 @@ int wait_signal(TableRef t, uint32_t seq, uint32_t *out8) {
   memset(out8, 0, 32);
   out8[FLAG_OVERFLOW] = (uint32_t)(v >> 31) & 1u;
   out8[FLAG_NGROUPS] = (uint32_t)v & 0x7FFFFFFFu;
-  // the values are here; the result buffers may be handed on only once the kernel has retired
+  // the values are here; the result buffers may be handed on only once the kernel has retired (the signal leaves when the last
+  // workgroup has RESERVED its rows, not when every workgroup has stored them).  That wait is ~7 us of host time per query: a
+  // DEVICE-output query leaves it to the first reader of the frame (plhip_result::pending), so a caller that chains queries or only
+  // wants the row count does not pay it per call.
+  static const bool no_defer = getenv("PLHIP_NO_DEFERRED_SYNC") != nullptr;
+  if (defer && !no_defer && !out8[FLAG_OVERFLOW]) { c.deferred = true; return PLHIP_OK; } // (an overflowed query is redone: its buffers go back first)
   HIP_TRY(hipStreamSynchronize(c.stream));
   return PLHIP_OK;
 }
@@ -1079,9 +1124,9 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
     OutSpec o = L.outs[i];
     ResultCol col;
     col.dtype = (int)o.dtype;
-    hipError_t e = g_pool.get(g_ctx.device, (size_t)out_cap * dtype_width((int)o.dtype), &col.values, &col.vcap);
+    hipError_t e = g_pool.get(g_ctx.device, (size_t)out_cap * dtype_width((int)o.dtype), &col.values, &col.vcap, true);
     if (e == hipSuccess && o.validity) {
-      e = g_pool.get(g_ctx.device, (size_t)(out_cap / 64 + 2) * 8, (void **)&col.validity, &col.bcap);
+      e = g_pool.get(g_ctx.device, (size_t)(out_cap / 64 + 2) * 8, (void **)&col.validity, &col.bcap, true);
       if (e == hipSuccess) e = hipMemsetAsync(col.validity, 0, (size_t)(out_cap / 64 + 2) * 8, c.stream);
     }
     R->cols.push_back(col);
@@ -1146,7 +1191,7 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
   uint32_t fl[16] = {0};
   if (e == hipSuccess) {
     TableRef t{nullptr, 0, dflags};
-    int rc = wait_signal(t, seq, fl);
+    int rc = wait_signal(t, seq, fl, c.allow_defer);
     if (rc) { return rc; }
     // for the next query: the last workgroup has zeroed the words it used when the run was clean (publish_done); otherwise, and
     // for the heavy-hitter words, one memset
@@ -1160,6 +1205,7 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
   if (fl[FLAG_OVERFLOW]) { return PLHIP_OK; } // estimate too low: the general path redoes the query
   const uint64_t G = fl[FLAG_NGROUPS];
   R->n_rows = (int64_t)G;
+  if (c.deferred) R->pending = c.token;
   handled = true;
   return finish_result(R_own.release(), G, flags, out);
 }
@@ -1588,9 +1634,9 @@ int run_dense(const Lowered &L0, const std::vector<DevCol> &dk, uint32_t flags, 
     OutSpec o = L.outs[i];
     ResultCol col;
     col.dtype = (int)o.dtype;
-    hipError_t e = g_pool.get(g_ctx.device, (size_t)out_cap * dtype_width((int)o.dtype), &col.values, &col.vcap);
+    hipError_t e = g_pool.get(g_ctx.device, (size_t)out_cap * dtype_width((int)o.dtype), &col.values, &col.vcap, true);
     if (e == hipSuccess && o.validity) {
-      e = g_pool.get(g_ctx.device, (size_t)(out_cap / 64 + 2) * 8, (void **)&col.validity, &col.bcap);
+      e = g_pool.get(g_ctx.device, (size_t)(out_cap / 64 + 2) * 8, (void **)&col.validity, &col.bcap, true);
       if (e == hipSuccess) e = hipMemsetAsync(col.validity, 0, (size_t)(out_cap / 64 + 2) * 8, c.stream);
     }
     R_->cols.push_back(col);
@@ -1661,9 +1707,9 @@ int run_dense(const Lowered &L0, const std::vector<DevCol> &dk, uint32_t flags, 
   if (timed) hipEventRecord(c.ev[2], c.stream);
   uint32_t fl[16] = {0};
   TableRef t{nullptr, 0, dflags};
-  const int rc = wait_signal(t, seq, fl);
+  const int rc = wait_signal(t, seq, fl, c.allow_defer && !comm);
   if (rc) return rc;
-  drain.s = nullptr; // (the stream is idle: wait_signal synchronised it)
+  drain.s = nullptr; // (the stream is idle: wait_signal synchronised it -- or the frame carries the stream's token, below)
   if (comm) { c.shard_stats.host_syncs++; lap(c.shard_stats.merge_ms); }
   if (!fl[FLAG_OVERFLOW] && c.signal_seen) c.flags_clean = 2; // (the signal was seen: the kernel's last workgroup has zeroed its counters)
   else if (hipMemsetAsync(dflags, 0, 64, c.stream) == hipSuccess) c.flags_clean = true;
@@ -1675,6 +1721,7 @@ int run_dense(const Lowered &L0, const std::vector<DevCol> &dk, uint32_t flags, 
   if (fl[FLAG_OVERFLOW]) return PLHIP_OK; // a code outside the promise: the hashed path redoes the query
   const uint64_t G = fl[FLAG_NGROUPS];
   R_->n_rows = (int64_t)G;
+  if (c.deferred) R_->pending = c.token;
   handled = true;
   return finish_result(R_.release(), G, flags, out);
 }
@@ -1818,9 +1865,9 @@ int run_two_level(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, uint64_t 
     OutSpec o = L.outs[i];
     ResultCol col;
     col.dtype = (int)o.dtype;
-    hipError_t e = g_pool.get(g_ctx.device, (size_t)out_cap * dtype_width((int)o.dtype), &col.values, &col.vcap);
+    hipError_t e = g_pool.get(g_ctx.device, (size_t)out_cap * dtype_width((int)o.dtype), &col.values, &col.vcap, true);
     if (e == hipSuccess && o.validity) {
-      e = g_pool.get(g_ctx.device, (size_t)(out_cap / 64 + 2) * 8, (void **)&col.validity, &col.bcap);
+      e = g_pool.get(g_ctx.device, (size_t)(out_cap / 64 + 2) * 8, (void **)&col.validity, &col.bcap, true);
       if (e == hipSuccess) e = hipMemsetAsync(col.validity, 0, (size_t)(out_cap / 64 + 2) * 8, c.stream);
     }
     R->cols.push_back(col);
@@ -2273,8 +2320,19 @@ int32_t plhip_group_by_agg_opts(const plhip_column_t *keys, int32_t n_keys, cons
   if (keys && n_keys > 0 && n_keys <= PLHIP_MAX_KEYS) for (int i = 0; i < n_keys; i++) any_bool |= keys[i].dtype == PLHIP_BOOL;
   if (values && n_values > 0 && n_values <= PLHIP_MAX_VALS) for (int i = 0; i < n_values; i++) any_bool |= values[i].dtype == PLHIP_BOOL;
   if (any_bool && out) *out = nullptr;
+  // a DEVICE-output frame may come back with its last kernel still retiring (wait_signal): only from this entry point, whose
+  // callers reach the buffers through plhip_result_column
+  Ctx &c = g_ctx;
+  c.deferred = false;
+  c.allow_defer = !any_bool && (flags & PLHIP_FLAG_OUTPUT_DEVICE) != 0;
   const int rc = any_bool && out ? bool_group_by(keys, n_keys, values, n_values, aggs, n_aggs, flags & ~FLAG_INTERNAL_WRAP32, opts, out)
                                  : group_by_agg_impl(keys, n_keys, values, n_values, aggs, n_aggs, flags & ~FLAG_INTERNAL_WRAP32, opts, out);
+  c.allow_defer = false;
+  if (c.deferred && !(out && *out && (*out)->pending)) { // (cannot happen: a deferred wait is the last step of its path)
+    if (c.stream) (void)hipStreamSynchronize(c.stream);
+    if (out && *out) (*out)->pending.reset();
+  }
+  c.deferred = false;
   // slice pushdown (GroupByExec's `slice`, executors/group_by.rs:79-82; offsets as slice_offsets, utils/mod.rs:199-218)
   if (!rc && out && *out && opts && opts->struct_size >= offsetof(plhip_options_t, has_slice) + sizeof(uint32_t) && opts->has_slice) {
     plhip_result *R = *out;
@@ -3091,8 +3149,17 @@ int32_t group_by_agg_impl(const plhip_column_t *keys, int32_t n_keys, const plhi
 
 int64_t plhip_result_num_rows(const plhip_result_t *r) { return r ? r->n_rows : -1; }
 int32_t plhip_result_num_columns(const plhip_result_t *r) { return r ? (int32_t)r->cols.size() : -1; }
+namespace {
+// the frame's buffers are about to be read from outside the stream that produced them: wait for that stream's tail (once)
+int settle_result(const plhip_result_t *r) {
+  if (!r->pending) return PLHIP_OK;
+  const hipError_t e = settle_token(r->pending);
+  return e == hipSuccess ? PLHIP_OK : fail_hip(e, "group-by kernels (reported when the frame was first read)");
+}
+} // namespace
 int32_t plhip_result_column(const plhip_result_t *r, int32_t i, plhip_column_t *col) {
   if (!r || !col || i < 0 || i >= (int32_t)r->cols.size()) return fail(PLHIP_ERR_INVALID, "bad result column index");
+  { const int rc = settle_result(r); if (rc) return rc; }
   col->values = r->cols[i].values;
   col->validity = r->cols[i].validity;
   col->offset = r->row_offset;
@@ -3400,6 +3467,7 @@ int pack_impl(const plhip_result_t *r, int32_t n_keys, uint64_t null_hash, int32
   if (slot_rows < 0 || slot_rows > 0x7FFFFFFFll) return fail(PLHIP_ERR_INVALID, "bad slot capacity");
   int rc = ensure_ctx();
   if (rc) return rc;
+  if ((rc = settle_result(r))) return rc;
   Ctx &c = g_ctx;
   RecPlan R{};
   if ((rc = frame_layout(R, r))) return rc;
@@ -3598,6 +3666,7 @@ int32_t plhip_finalize_partial(const plhip_result_t *merged, int32_t n_keys, con
   if (n_keys < 1 || n_finals < 0 || n_keys + n_finals > PLHIP_MAX_OUTS) return fail(PLHIP_ERR_INVALID, "bad column counts");
   int rc = ensure_ctx();
   if (rc) return rc;
+  if ((rc = settle_result(merged))) return rc;
   Ctx &c = g_ctx;
   const int64_t G = merged->n_rows;
   FinPlan F{};

@@ -1,9 +1,12 @@
 #!/bin/bash
-timeout -k 10 300 python -u -m pytest tests/test_dense_gpu.py -x -q --timeout 300 --timeout-method thread > gpurun_out/t_tests.log 2>&1 || { tail -30 gpurun_out/t_tests.log; exit 1; }
-tail -1 gpurun_out/t_tests.log
-for args in "" "--na" "--workload q5" "--rows 1000000000"; do
-  timeout -k 10 300 python bench.py $args --steps 60 --warmup 10 --no-cpu-baseline --configs none 2>gpurun_out/t.err | python -c "
+# scratch: the deferred final wait -- its tests, then the step time with and without it
+mkdir -p gpurun_out
+timeout -k 10 600 python -u -m pytest tests/test_deferred_sync_gpu.py tests/test_zz_no_alloc.py -x -q --timeout 300 --timeout-method thread > gpurun_out/t_defer.log 2>&1 || { tail -30 gpurun_out/t_defer.log; exit 1; }
+tail -3 gpurun_out/t_defer.log
+for nd in 1 0 1 0; do for wl in q3 q1; do
+  if [ $nd = 1 ]; then export PLHIP_NO_DEFERRED_SYNC=1; else unset PLHIP_NO_DEFERRED_SYNC; fi
+  timeout -k 10 120 python bench.py --workload $wl --steps 300 --warmup 20 --no-cpu-baseline --configs none 2>gpurun_out/t.err | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline']
-print('[$args]','fold_ms',round(r['breakdown_ms']['fold'],4),'merge',round(r['breakdown_ms']['merge_emit'],4),'step',round(d['ms_per_step'],4))" || { tail -5 gpurun_out/t.err; exit 1; }
-done
+print('no_defer',$nd,'$wl','step_ms',round(d['ms_per_step'],4),'kernels',round(r['all_kernels_ms'],4), d.get('parity'))" || { tail -5 gpurun_out/t.err; exit 1; }
+done; done
