@@ -1453,7 +1453,7 @@ int run_dense(const Lowered &L0, const std::vector<DevCol> &dk, uint32_t flags, 
   const char *dbg_r = getenv("PLHIP_DENSE_R");
   uint32_t R = (uint32_t)(((uint64_t)A.n_slots * state_max + LDS_CAP - 1) / LDS_CAP);
   if (dbg_r) R = std::max<uint32_t>(R, (uint32_t)atoi(dbg_r));
-  const uint32_t rep = dk[0].validity ? 64u : 0u; // a nullable key: 64 replicas of the null slot behind a range's entries (dense_path.hip)
+  uint32_t rep = dk[0].validity ? 64u : 0u; // a nullable key: 64 replicas of the null slot behind a range's entries (dense_path.hip)
   // More groups than DENSE_MAX_RANGES ranges hold (q3 at 1e8 .. 1e9 rows: 1e6 .. 1e7 ids): PARTITION MODE.  The rows are scattered
   // by code range first -- exact and hash-free: partition = code / gpr, sized by one histogram pass over the key column -- and
   // every partition is then a dense problem of ONE range: read, write partitioned, read partitioned; three passes over the row
@@ -1467,11 +1467,15 @@ int run_dense(const Lowered &L0, const std::vector<DevCol> &dk, uint32_t flags, 
       // against 1.55 here, the scatter's returning LDS atomics meet on 50 counters -- beyond it the alternative makes two partition
       // levels: q3 at 1e9 rows / 1e7 ids 23.3 -> 18.8 ms)
       static const bool part_any = getenv("PLHIP_DENSE_PARTITION_ANY") != nullptr; // (tests: the mode at small sizes)
-      if (comm || dk[0].validity || n_pad > 0xFFFFFFFFull || getenv("PLHIP_NO_DENSE_PARTITION")) return PLHIP_OK;
-      if (!part_any && !forced && (n < (1 << 22) || A.n_slots <= 1200000u)) return PLHIP_OK;
+      // (sharded: whether the mode applies is a property of the schema and the hint, so every rank decides alike; what only THIS
+      // rank's rows rule out -- a nullable key, too many rows -- is flagged in its slot headers and all ranks fall back together)
+      if (getenv("PLHIP_NO_DENSE_PARTITION")) return PLHIP_OK;
+      if (!comm && !part_any && !forced && (n < (1 << 22) || A.n_slots <= 1200000u)) return PLHIP_OK;
       A.gpr = (uint32_t)((LDS_CAP - 16 * DENSE_MAX_PART_ACCS) / state_max) & ~3u;
       const uint64_t np = ((uint64_t)A.n_slots + A.gpr - 1) / A.gpr;
       if (np > (1u << TS_MAX_PBITS)) return PLHIP_OK;
+      if (dk[0].validity || n_pad > 0xFFFFFFFFull) { if (!comm) return PLHIP_OK; local_bad = true; }
+      rep = 0; // (no null replicas in this mode: a nullable key has just been flagged)
       R = (uint32_t)np;
       while ((1u << pbits) < R) pbits++;
       np_pow2 = 1u << pbits;
@@ -1608,6 +1612,7 @@ int run_dense(const Lowered &L0, const std::vector<DevCol> &dk, uint32_t flags, 
     A2 = A;
     A2.dump = (uint8_t *)c.xrecv.p;
     A2.R = 1; A2.gpr = X.per;
+    A2.pmode = 0; A2.S = 0; // (the received slots are plain dense arrays, whatever the local pass looked like)
     A2.slot_base = (uint32_t)comm->rank * X.per;
     A2.n_slots = A2.slot_base >= A.n_slots ? 0u : std::min<uint32_t>(X.per, A.n_slots - A2.slot_base);
     A2.n_hdr = world;
@@ -1649,7 +1654,7 @@ int run_dense(const Lowered &L0, const std::vector<DevCol> &dk, uint32_t flags, 
   const bool timed = c.timed();
   if (timed) hipEventRecord(c.ev[1], c.stream);
   Plan P2 = P; // partition mode: the fold and the merge read the partitioned copies
-  if (pmode) {
+  if (pmode && fold_runs) {
     const uint32_t n_tiles = (uint32_t)((n + TS_TILE - 1) / TS_TILE);
     size_t off_totals = (size_t)np_pow2 * n_tiles * 4, off_start = off_totals + (size_t)np_pow2 * 4;
     size_t off_cnt = (off_start + (size_t)(np_pow2 + 1) * 4 + 63) & ~(size_t)63;

@@ -46,6 +46,16 @@ def test_bench_gpus_3_strong_scaling_hashed_protocol():
     assert line["shuffle"]["protocol"].startswith("slots")
 
 
+def test_bench_gpus_2_many_codes_keep_the_dense_exchange():
+    # config 4's regime in small: more ids than eight LDS ranges hold -> the local pass range-partitions (dense_part), the
+    # exchange stays the dense one (one host wait)
+    line = _bench("--gpus", "2", "--total-rows", "20000000", "--steps", "2", "--warmup", "1")
+    assert line["n_gpus"] == 2 and line["config"]["groups"] == 200_000
+    assert line["config"]["strategy"] == "dense_part", line["config"]["strategy"]
+    assert line["shuffle"]["protocol"].startswith("dense"), line["shuffle"]
+    assert line["parity"]["ok"], line["parity"]
+
+
 def test_bench_rejects_a_world_size_that_contradicts_gpus():
     e = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "4"], env=e, capture_output=True, text=True, timeout=60)

@@ -100,6 +100,37 @@ def test_sharded_rccl_world1_dense_codes_and_device_inputs(oracle, rccl_world1):
     util.assert_frames_match(_frame(res), util.oracle_to_np(want), 1, what="sharded, dense local pass")
 
 
+@pytest.mark.parametrize("case", ["plain", "nullable_key"])
+def test_sharded_dense_exchange_beyond_eight_ranges(oracle, rccl_world1, case):
+    """More codes than eight LDS ranges hold (config 4's shards: 1e7 ids): the local pass range-partitions the rows first
+    (strategy dense_part) and the exchange stays the dense one; a nullable key is what this mode does not take: the rank flags
+    its slot headers and every rank falls back to the hashed protocol together."""
+    import torch
+
+    from polars_amd import distributed as pd_
+
+    rng = np.random.default_rng(43)
+    n, ncat = 3_000_000, 600_000
+    k = rng.integers(0, ncat, n).astype(np.uint32)
+    km = rng.random(n) >= 0.02 if case == "nullable_key" else None
+    v1 = rng.integers(-5, 6, n).astype(np.int32)
+    v3 = np.round(rng.uniform(0, 100, n), 6)
+    v3m = rng.random(n) >= 0.05
+    keys = [Column("k", k, km).set_categories(ncat)]
+    vals = [Column("v1", v1), Column("v3", v3, v3m)]
+    aggs = [(0, "sum"), (1, "mean"), (1, "min"), (1, "max"), (0, "count"), (1, "sum")]
+    eng = pd_.HipEngine(torch.device("cuda:0"))
+    eng.dense_keys = True
+    res = pd_.group_by_agg_sharded(keys, vals, aggs, device=torch.device("cuda:0"), engine=eng, n_groups_hint=ncat, force_exchange=True)
+    want, _ = oracle.group_by_agg(keys, vals, aggs)
+    util.assert_frames_match(_frame(res), util.oracle_to_np(want), 1, what=f"sharded dense exchange, partition mode, {case}")
+    if case == "plain":
+        assert eng.last_partial_strategy == "dense_part", eng.last_partial_strategy
+        assert eng.last_protocol.startswith("dense") and eng.last_host_syncs == 1, (eng.last_protocol, eng.last_host_syncs)
+    else:
+        assert not eng.last_protocol.startswith("dense"), eng.last_protocol
+
+
 @pytest.mark.parametrize("case", ["nullable", "code_beyond_hint", "misaligned", "tiny", "hashed_forced"])
 def test_sharded_dense_exchange_world1(oracle, rccl_world1, case, monkeypatch):
     """Protocol 3 (owners by code range, raw partial arrays through ncclSend / ncclRecv) against the oracle: null key, nullable
