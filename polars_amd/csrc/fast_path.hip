@@ -516,6 +516,7 @@ __global__ void __launch_bounds__(TS_BLOCK) k_tile_sort(Plan P, PartOut O, uint3
   __shared__ __align__(16) uint32_t hist[(1 << TS_MAX_PBITS) + 4];
   __shared__ __align__(16) uint32_t tmp[TS_BLOCK / 64];
   __shared__ __align__(16) uint32_t gdelta[SCATTER ? (1 << TS_MAX_PBITS) + 4 : 1]; // output row of a run's first element - its sorted position
+  __shared__ __align__(16) uint16_t pid[SCATTER ? TS_TILE : 1];                    // partition of the row at sorted position j
   const uint32_t np = 1u << pbits, nh = np + 1; // partition np holds the rows with a null key
   const uint32_t tid = threadIdx.x;
   uint32_t tile = blockIdx.x;
@@ -564,7 +565,7 @@ __global__ void __launch_bounds__(TS_BLOCK) k_tile_sort(Plan P, PartOut O, uint3
     for (int r = 0; r < TS_R; r++) key[r] = (KS)(raw[r] ^ kxor);
   }
   // the first value columns are requested now and land under the histogram / scan / key phases
-  constexpr int NPRE_ = SCATTER ? 0 : TS_NPRE; // (the scatter variant needs the registers for its destinations)
+  constexpr int NPRE_ = SCATTER ? 1 : TS_NPRE; // (the scatter variant keeps its destinations in registers: one column ahead is what fits without spills)
   uint64_t pre[NPRE_ ? NPRE_ : 1][TS_R];
 #pragma unroll
   for (int c = 0; c < NPRE_; c++)
@@ -593,16 +594,35 @@ __global__ void __launch_bounds__(TS_BLOCK) k_tile_sort(Plan P, PartOut O, uint3
   }
   if (!SCATTER && tid == 0) offs[(uint64_t)(np + 1) * n_tiles + tile] = nt;
   lds_barrier();
-#pragma unroll
-  for (int r = 0; r < TS_R; r++) if ((live >> r) & 1) pos[r] = hist[pos[r] & 0xFFFu] + (pos[r] >> 12);
   uint32_t dest[TS_R]; // SCATTER: output row of sorted element i * TS_BLOCK + tid
-  if (SCATTER) {
+  if (SCATTER && L1.range_gpr) {
+    // which partition's run holds sorted position j: every row writes its partition at its sorted position (the binary search over
+    // the run starts below -- nine dependent, bank-conflicting LDS reads per element -- was a fifth of the kernel at 491 range
+    // partitions: q3 at 3e8 rows 4.42 -> 3.97 ms)
+#pragma unroll
+    for (int r = 0; r < TS_R; r++)
+      if ((live >> r) & 1) {
+        const uint32_t p = pos[r] & 0xFFFu;
+        pos[r] = hist[p] + (pos[r] >> 12);
+        pid[pos[r]] = (uint16_t)(p < np ? p : np - 1u);
+      }
+    lds_barrier();
 #pragma unroll
     for (int i = 0; i < TS_R; i++) {
       const uint32_t j = (uint32_t)i * TS_BLOCK + tid;
-      uint32_t lo = 0, hi = np; // the partition whose run holds sorted position j: last p with hist[p] <= j
-      while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (hist[mid] <= j) lo = mid; else hi = mid; }
-      dest[i] = j + gdelta[lo];
+      dest[i] = j < nt ? j + gdelta[pid[j]] : 0u;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < TS_R; r++) if ((live >> r) & 1) pos[r] = hist[pos[r] & 0xFFFu] + (pos[r] >> 12);
+    if (SCATTER) {
+#pragma unroll
+      for (int i = 0; i < TS_R; i++) {
+        const uint32_t j = (uint32_t)i * TS_BLOCK + tid;
+        uint32_t lo = 0, hi = np; // the partition whose run holds sorted position j: last p with hist[p] <= j
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (hist[mid] <= j) lo = mid; else hi = mid; }
+        dest[i] = j + gdelta[lo];
+      }
     }
   }
 #define TS_STORE(T, x, dstcol)                                                                              \
@@ -612,6 +632,41 @@ __global__ void __launch_bounds__(TS_BLOCK) k_tile_sort(Plan P, PartOut O, uint3
   } while (0)
 
   TS_STORE(KS, key, O.keys);
+  if (SCATTER) {
+    // one workgroup per CU here (the destinations live in registers), so nothing else hides a column's load: column v + 1 is
+    // requested before column v is staged and scattered, and lands under it
+    uint64_t nxt[TS_R];
+#pragma unroll
+    for (int r = 0; r < TS_R; r++) nxt[r] = pre[0][r];
+    for (int v = 0; v < P.n_vals; v++) {
+      const ValSpec V = P.vals[v];
+      uint64_t cur[TS_R];
+#pragma unroll
+      for (int r = 0; r < TS_R; r++) cur[r] = nxt[r];
+      if (v + 1 < P.n_vals) load_raw<TS_R, false>(P.vals[v + 1].values, wbytes(P.vals[v + 1].dtype), row, nxt);
+      switch (wbytes(V.dtype)) {
+#define SCAT_COL(T)                                                                                     \
+  {                                                                                                     \
+    T x[TS_R];                                                                                          \
+    _Pragma("unroll") for (int r = 0; r < TS_R; r++) x[r] = (T)cur[r];                                  \
+    TS_STORE(T, x, O.vals[v]);                                                                          \
+  }                                                                                                     \
+  break;
+        case 1: SCAT_COL(uint8_t)
+        case 2: SCAT_COL(uint16_t)
+        case 4: SCAT_COL(uint32_t)
+        default: SCAT_COL(uint64_t)
+#undef SCAT_COL
+      }
+      if (O.valid[v]) {
+        uint8_t x[TS_R];
+#pragma unroll
+        for (int r = 0; r < TS_R; r++) x[r] = val_valid(V, (int64_t)row[r]) ? 1 : 0;
+        TS_STORE(uint8_t, x, O.valid[v]);
+      }
+    }
+    return;
+  }
   for (int v = 0; v < P.n_vals; v++) {
     const ValSpec V = P.vals[v];
     if (v < NPRE_) {
