@@ -470,9 +470,10 @@ def run_workload(ctx, a, light=False):
     f_tot, f_dom, f_name, f_a, f_b, f_c = C.c_float(), C.c_float(), C.c_char_p(), C.c_float(), C.c_float(), C.c_float()
     r_ms = (C.byref(f_tot), C.byref(f_dom), C.byref(f_name))
     r_bd = (C.byref(f_a), C.byref(f_b), C.byref(f_c))
-    # the library records its HIP events on every TIMING_EVERY-th query (three event records and their read-back cost ~5 % of a
-    # 0.1 ms step); the times below are those of the sampled steps INSIDE the timed region
-    TIMING_EVERY = max(1, min(8, steps // 4)) if not sharded else 1
+    # the library records its HIP events on every TIMING_EVERY-th query (three event records and their read-back -- which waits for
+    # the stream's tail -- cost ~15 us, 15 % of a 0.1 ms step); the times below are those of the sampled steps INSIDE the timed
+    # region (the driver's 20 steps: steps 10 and 20)
+    TIMING_EVERY = max(1, min(10, steps // 2)) if not sharded else 1
     L.plhip_set_timing_interval(TIMING_EVERY)
     t0 = time.perf_counter()
     for i_step in range(steps):
@@ -493,8 +494,11 @@ def run_workload(ctx, a, light=False):
         kernel_ms.append(tot)
         dom_ms.append(dom)
         dom_names.append(dom_name)
+    t_loop = time.perf_counter() - t0
     ctx.sync()
     dt = time.perf_counter() - t0
+    if os.environ.get("PLHIP_BENCH_VERBOSE"):
+        print(f"[bench] loop {t_loop * 1e3:.4f} ms, closing sync {(dt - t_loop) * 1e3:.4f} ms, {steps} steps", file=sys.stderr)
     L.plhip_set_timing_interval(1)
     groups_total = g
     n_ranks = world
