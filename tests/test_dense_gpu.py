@@ -296,3 +296,47 @@ def test_partition_mode_code_beyond_the_hint_falls_back(oracle):
     key.values[12345] = ncat + 7  # the caller's promise is broken: the hashed path redoes the query
     v = Column("v", rng.integers(0, 9, PART_N).astype(np.int32))
     check(oracle, key, [v], [(0, "sum"), (0, "count")], ncat, expect=("tilesort", "tilesort2", "sort"), what="partition mode, bad code", strategy="auto")
+
+
+def test_config4_single_gpu_point_full_size_properties():
+    """BASELINE configs[3]'s N = 1 point at its stated size -- q3 over 1e9 rows / 1e7 ids on ONE GPU, the regime config 4's
+    shards run in -- takes the partition mode (range scatter + one-range dense fold).  No oracle finishes this in seconds:
+    size-independent properties (counts add up to N and match torch's per-id counts exactly, the exact integer checksum, the
+    f64 checksum, mean * count == sum per group, every id at most once)."""
+    import torch
+
+    from polars_amd import h2oai
+    from polars_amd.frame import _host_column
+
+    n = 1_000_000_000
+    dev = torch.device("cuda:0")
+    t = h2oai.generate(n, seed=108, device=dev, columns=["id3", "v1", "v3"])
+    cols = h2oai.to_columns(t)
+    keys, vals = [cols["id3"]], [cols["v1"], cols["v3"]]
+    ncat = keys[0].n_categories
+    assert ncat == n // 100
+    codes = [(0, _ffi.AGG_NAMES["sum"]), (1, _ffi.AGG_NAMES["mean"]), (1, _ffi.AGG_NAMES["sum"]), (0, _ffi.AGG_NAMES["count"])]
+    handle, rcols = pa.group_by_agg_raw(keys, vals, codes, _ffi.FLAG_KEYS_DENSE, ncat)
+    try:
+        assert pa.last_strategy() == "dense_part", pa.last_strategy()
+        got = [_host_column(str(i), cs).to_numpy().copy() for i, cs in enumerate(rcols)]
+    finally:
+        _ffi.lib().plhip_result_free(handle)
+    k, s1, mean3, s3, cnt = got
+    assert len(np.unique(k)) == len(k)
+    ids = t["id3"].view(torch.int32) if t["id3"].dtype != torch.int32 else t["id3"]
+    per_id = torch.bincount(ids, minlength=ncat)
+    present = (per_id > 0).sum().item()
+    assert len(k) == present, (len(k), present)
+    order = np.argsort(k)
+    assert np.array_equal(cnt[order].astype(np.int64), per_id[per_id > 0].cpu().numpy())  # every group's length, exactly
+    assert int(cnt.astype(np.int64).sum()) == n
+    assert int(s1.astype(np.int64).sum()) == int(t["v1"].sum().item())  # (about 100 rows of 1..5 per id: no group's i32 sum wraps)
+    tot3 = float(t["v3"].sum().item())
+    assert abs(float(s3.sum()) - tot3) <= 1e-9 * abs(tot3)
+    assert np.allclose(mean3 * cnt, s3, rtol=1e-12)
+    top = int(np.argmax(cnt))
+    sel = ids == int(k[top])
+    assert int(s1[top]) == int(t["v1"][sel].sum().item())
+    ref = float(t["v3"][sel].sum().item())
+    assert abs(float(s3[top]) - ref) <= 1e-12 * abs(ref)
