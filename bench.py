@@ -475,11 +475,10 @@ def run_workload(ctx, a, light=False):
     # region (the driver's 20 steps: steps 10 and 20)
     TIMING_EVERY = max(1, min(10, steps // 2)) if not sharded else 1
     L.plhip_set_timing_interval(TIMING_EVERY)
-    t0 = time.perf_counter()
-    for i_step in range(steps):
-        g, out_widths = step()
-        if i_step % TIMING_EVERY != TIMING_EVERY - 1:
-            continue
+    verbose = bool(os.environ.get("PLHIP_BENCH_VERBOSE"))
+    t_steps = []
+
+    def read_sample():
         if sharded:
             # the sharded step makes several library calls: the engine kept the kernel times of the LOCAL partial pass
             # (the pass over this rank's rows) and the wall time of every phase of the step
@@ -487,18 +486,42 @@ def run_workload(ctx, a, light=False):
             parts.append(eng.last_partial_breakdown)
             phases.append(dict(eng.last_phase_ms))
         else:
-            L.plhip_last_kernel_ms(*r_ms)  # HIP events on the library's own stream, recorded live
+            L.plhip_last_kernel_ms(*r_ms)  # HIP events on the library's own stream, recorded live inside the timed region
             L.plhip_last_kernel_breakdown(*r_bd)
             tot, dom, dom_name = f_tot.value, f_dom.value, f_name.value
             parts.append((f_a.value, f_b.value, f_c.value))
         kernel_ms.append(tot)
         dom_ms.append(dom)
         dom_names.append(dom_name)
+
+    # A sampled step's events are READ as late as possible: right before the next sampled step (TIMING_EVERY steps later, when they
+    # have long completed and the read costs no wait) or, for the last sample, behind the closing synchronisation.  Reading them
+    # right behind their own step waits for the stream's tail -- the wait that deferred completion took out of every step.
+    lazy = not sharded and TIMING_EVERY >= 2
+    unread = False
+    t0 = time.perf_counter()
+    for i_step in range(steps):
+        sampled = i_step % TIMING_EVERY == TIMING_EVERY - 1
+        if sampled and unread:
+            read_sample()
+            unread = False
+        g, out_widths = step()
+        if verbose:
+            t_steps.append(time.perf_counter())
+        if not sampled:
+            continue
+        if lazy:
+            unread = True
+        else:
+            read_sample()
     t_loop = time.perf_counter() - t0
     ctx.sync()
     dt = time.perf_counter() - t0
-    if os.environ.get("PLHIP_BENCH_VERBOSE"):
-        print(f"[bench] loop {t_loop * 1e3:.4f} ms, closing sync {(dt - t_loop) * 1e3:.4f} ms, {steps} steps", file=sys.stderr)
+    if verbose:  # (diagnostics on stderr: where the timed region's time went)
+        per = [round((b - a) * 1e6, 1) for a, b in zip([t0] + t_steps[:-1], t_steps)]
+        print(f"[bench] loop {t_loop * 1e3:.4f} ms, closing sync {(dt - t_loop) * 1e3:.4f} ms, {steps} steps; per step us: {per[:40]}", file=sys.stderr)
+    if unread:
+        read_sample()
     L.plhip_set_timing_interval(1)
     groups_total = g
     n_ranks = world

@@ -146,13 +146,14 @@ int fail_hip(hipError_t e, const char *what) {
   } while (0)
 
 void resolve_timing();
+void resolve_timing_if_ready();
 int resolve_scratch(int dev, uint8_t **p);
 
 int ensure_ctx() {
   Ctx &c = g_ctx;
   if (c.device >= 0) {
     HIP_TRY(hipSetDevice(c.device));
-    resolve_timing(); // before this call records the events again
+    resolve_timing_if_ready(); // (never waits: a query that records the events again resolves the pending ones first, below)
     return PLHIP_OK;
   }
   int n = 0;
@@ -701,6 +702,17 @@ int wait_signal(TableRef t, uint32_t seq, uint32_t *out8, bool defer = false) {
 
 // event times of the last fast-path query (read lazily: the host returns before the stream has retired the
 // trailing event records)
+// ensure_ctx's variant: the next call usually comes while the previous query's last kernel is still retiring (deferred
+// completion); waiting for its trailing event there would put the stream wait back into every sampled step
+void resolve_timing_if_ready() {
+  Ctx &c = g_ctx;
+  if (!c.timing_pending) return;
+  const bool merged = c.timing_pending != 2;
+  const hipError_t q = hipEventQuery(merged ? c.ev[2] : c.ev[5]);
+  if (q == hipSuccess) resolve_timing();
+  else if (q != hipErrorNotReady) (void)hipGetLastError();
+}
+
 void resolve_timing() {
   Ctx &c = g_ctx;
   if (!c.timing_pending) return;
@@ -1141,7 +1153,7 @@ int run_fast(Lowered &L, const std::vector<DevCol> &dk, uint32_t flags, int64_t 
   if (++c.seq == 0) c.seq = 1;
   const uint32_t seq = c.seq;
   const bool timed = c.timed();
-  if (timed) hipEventRecord(c.ev[1], c.stream);
+  if (timed) { resolve_timing(); hipEventRecord(c.ev[1], c.stream); } // (the previous sample is read before its events are recorded again)
   if (direct) {
     bool quad = true;
     auto aligned = [](const uint8_t *p, int wd) { return ((uintptr_t)p % (size_t)(4 * wd)) == 0; };
@@ -1300,6 +1312,7 @@ int run_direct_noalloc(Lowered &L, const std::vector<DevCol> &dk, int64_t groups
   auto aligned = [](const uint8_t *p, int wd) { return ((uintptr_t)p % (size_t)(4 * wd)) == 0; };
   if (keymode && !aligned(dk[0].values, dtype_width(dk[0].dtype))) quad = false;
   for (int v = 0; v < P.n_vals; v++) if (!aligned(P.vals[v].values, dtype_width((int)P.vals[v].dtype))) quad = false;
+  resolve_timing();
   hipEventRecord(c.ev[1], c.stream);
   FoldRowsArgs A{};
   A.D = D; A.flags = dflags; A.rows_per_item = DS.rows_per_item; A.kxor = kxor; A.lbits = DS.lbits; A.keymode = keymode; A.mbits = DS.mbits;
@@ -1652,7 +1665,7 @@ int run_dense(const Lowered &L0, const std::vector<DevCol> &dk, uint32_t flags, 
   if (++c.seq == 0) c.seq = 1;
   const uint32_t seq = c.seq;
   const bool timed = c.timed();
-  if (timed) hipEventRecord(c.ev[1], c.stream);
+  if (timed) { resolve_timing(); hipEventRecord(c.ev[1], c.stream); } // (the previous sample is read before its events are recorded again)
   Plan P2 = P; // partition mode: the fold and the merge read the partitioned copies
   if (pmode && fold_runs) {
     const uint32_t n_tiles = (uint32_t)((n + TS_TILE - 1) / TS_TILE);
@@ -1883,6 +1896,7 @@ int run_two_level(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, uint64_t 
   if (++c.seq == 0) c.seq = 1;
   const uint32_t seq = c.seq;
   // ---- level 1 -----------------------------------------------------------------------------------------------------
+  resolve_timing();
   hipEventRecord(c.ev[1], c.stream);
   launch_part_hist(P, pbits1, tile_rows1, n_tiles1, counts, c.stream);
   launch_part_scan(counts, np1, n_tiles1, totals, c.stream);
@@ -2016,6 +2030,7 @@ int run_sorted(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, plhip_result
   uint32_t *fl_d = (uint32_t *)c.part.p, *gid = (uint32_t *)((uint8_t *)c.part.p + n4);
   uint32_t *offsets = (uint32_t *)c.rank.p;
   uint32_t *long_count = (uint32_t *)c.items.p, *long_list = long_count + 64;
+  resolve_timing();
   HIP_TRY(hipEventRecord(c.ev[0], c.stream));
   HIP_TRY(hipMemsetAsync(dflags, 0, 64, c.stream));
   c.flags_clean = false;
@@ -2999,6 +3014,7 @@ int32_t group_by_agg_impl(const plhip_column_t *keys, int32_t n_keys, const plhi
     if (handled) return PLHIP_OK;
     strategy = PLHIP_STRATEGY_AUTO;
   }
+  resolve_timing();
   HIP_TRY(hipEventRecord(c.ev[0], c.stream)); // the general path's timing starts here (the LDS-only pipelines above record their own events)
   uint64_t g_est = (uint64_t)n;
   if (n >= (1 << 14) && (rc = estimate_groups(P, g_est))) return rc;
