@@ -2436,7 +2436,7 @@ int32_t plhip_group_by_agg_chunked(const plhip_chunked_column_t *keys, int32_t n
   if (n_values < 0 || n_values > PLHIP_MAX_VALS || (n_values > 0 && !values)) return fail(PLHIP_ERR_INVALID, "bad value columns");
   int rc = ensure_ctx();
   if (rc) return rc;
-  Staging st; // the rechunked buffers live until the query has returned (the group-by ends with the stream drained)
+  Staging st; // the rechunked buffers live until the query has returned (its count comes from its last kernel, which no longer reads inputs; hipFree waits for the device besides)
   std::vector<plhip_column_t> k(n_keys), v(std::max(n_values, 1));
   for (int i = 0; i < n_keys; i++) if ((rc = rechunk_column(keys[i], k[i], st, g_ctx.stream))) return rc;
   for (int i = 0; i < n_values; i++) if ((rc = rechunk_column(values[i], v[i], st, g_ctx.stream))) return rc;
@@ -3674,7 +3674,7 @@ int merge_impl(const void *records, int64_t n_rows, const int32_t *dtypes, const
   }
   rc = plhip_group_by_agg_opts(cols.data(), n_keys, cols.data() + n_keys, nv, aggs.data(), nv, flags, opts, out);
   if (rc) hipStreamSynchronize(g_ctx.stream); // a failed group-by may have left k_unpack / its own kernels queued: F's buffers go back to the pool
-  delete F; // (on success the group-by has synchronised the stream)
+  delete F; // (on success the count has come from the query's LAST kernel: every kernel that read F's columns retired before it started)
   return rc;
 }
 } // namespace
