@@ -68,7 +68,9 @@ typedef enum plhip_dtype {
    * plhip_group_by_agg_opts as a key and as a value column, with the reference's casts: a Boolean key groups as UInt8
    * (into_groups.rs:215-230) and comes back as a Boolean key column; sum(bool) is the u32 sum of the column cast to IdxSize
    * (aggregations/boolean.rs:107-109), mean(bool) the f64 mean of its cast (aggregations/dispatch.rs:164), min / max stay
-   * Boolean (boolean.rs:20-106), count is a count.  Other entry points reject the dtype. */
+   * Boolean (boolean.rs:20-106), count is a count.  Also accepted, with the same casts, by the CSR seams: plhip_group_tuples
+   * (Boolean keys) and plhip_agg_groups (sum, mean, min, max, first, last of a Boolean column; first / last stay Boolean) --
+   * and by plhip_vec_hash_seeded.  Other entry points reject the dtype. */
   PLHIP_BOOL = 10
 } plhip_dtype_t;
 

@@ -2257,19 +2257,11 @@ int32_t plhip_group_by_agg(const plhip_column_t *keys, int32_t n_keys, const plh
 }
 
 namespace {
-// Boolean columns (PLHIP_BOOL): lowered at the boundary with the reference's own casts -- a key to UInt8 (into_groups.rs:215-230), a
-// value column to IdxSize = u32 (boolean.rs:107-109 for sum; the f64 mean of the cast is dispatch.rs:164's) -- and the Boolean outputs
-// (keys, min, max) packed back into bitmaps.
-int bool_group_by(const plhip_column_t *keys, int32_t n_keys, const plhip_column_t *values, int32_t n_values, const plhip_agg_t *aggs,
-                  int32_t n_aggs, uint32_t flags, const plhip_options_t *opts, plhip_result_t **out) {
-  if (flags & PLHIP_FLAG_PARTIAL) return fail(PLHIP_ERR_UNSUPPORTED_DTYPE, "Boolean columns have no partial (mergeable) form");
-  if (n_keys < 1 || n_keys > PLHIP_MAX_KEYS || n_values < 0 || n_values > PLHIP_MAX_VALS) return fail(PLHIP_ERR_INVALID, "bad column counts");
-  int rc = ensure_ctx();
-  if (rc) return rc;
+// A Boolean column (values = the Arrow bitmap, host or device) becomes a device-resident column of `w`-byte integers of dtype `dt`
+// holding 0 / 1 (the reference's casts: into_groups.rs:215-230 to UInt8 for keys, boolean.rs:107-109 to IdxSize for sums); the
+// validity bitmap travels as it is.  The new buffers belong to `st`.
+int lower_bool_column(plhip_column_t &col, uint32_t w, int dt, Staging &st) {
   Ctx &c = g_ctx;
-  Staging st;
-  std::vector<plhip_column_t> lk(keys, keys + n_keys), lv(values, values + n_values);
-  auto lower = [&](plhip_column_t &col, uint32_t w, int dt) -> int {
     if (col.length < 0 || col.offset < 0) return fail(PLHIP_ERR_INVALID, "negative column offset/length");
     if (col.length > 0 && !col.values) return fail(PLHIP_ERR_INVALID, "column values pointer is NULL");
     const int64_t n = col.length, b0 = col.offset >> 3, b1 = (col.offset + n + 7) >> 3;
@@ -2295,7 +2287,21 @@ int bool_group_by(const plhip_column_t *keys, int32_t n_keys, const plhip_column
     col.values = (const void *)((uintptr_t)vals - (uintptr_t)boff * w);
     col.validity = valid; col.offset = boff; col.dtype = dt; col.location = PLHIP_DEVICE;
     return PLHIP_OK;
-  };
+}
+
+// Boolean columns (PLHIP_BOOL): lowered at the boundary with the reference's own casts -- a key to UInt8 (into_groups.rs:215-230), a
+// value column to IdxSize = u32 (boolean.rs:107-109 for sum; the f64 mean of the cast is dispatch.rs:164's) -- and the Boolean outputs
+// (keys, min, max) packed back into bitmaps.
+int bool_group_by(const plhip_column_t *keys, int32_t n_keys, const plhip_column_t *values, int32_t n_values, const plhip_agg_t *aggs,
+                  int32_t n_aggs, uint32_t flags, const plhip_options_t *opts, plhip_result_t **out) {
+  if (flags & PLHIP_FLAG_PARTIAL) return fail(PLHIP_ERR_UNSUPPORTED_DTYPE, "Boolean columns have no partial (mergeable) form");
+  if (n_keys < 1 || n_keys > PLHIP_MAX_KEYS || n_values < 0 || n_values > PLHIP_MAX_VALS) return fail(PLHIP_ERR_INVALID, "bad column counts");
+  int rc = ensure_ctx();
+  if (rc) return rc;
+  Ctx &c = g_ctx;
+  Staging st;
+  std::vector<plhip_column_t> lk(keys, keys + n_keys), lv(values, values + n_values);
+  auto lower = [&](plhip_column_t &col, uint32_t w, int dt) -> int { return lower_bool_column(col, w, dt, st); };
   std::vector<char> bool_out;
   for (int i = 0; i < n_keys; i++) {
     const bool b = keys[i].dtype == PLHIP_BOOL;
@@ -3222,6 +3228,20 @@ int32_t plhip_group_tuples(const plhip_column_t *keys, int32_t n_keys, int32_t s
   int rc = ensure_ctx();
   if (rc) return rc;
   Ctx &c = g_ctx;
+  {
+    // Boolean keys group as their UInt8 cast (IntoGroupsProxy for BooleanChunked, into_groups.rs:215-230): unpacked on the device
+    bool any_bool = false;
+    for (int i = 0; i < n_keys; i++) any_bool |= keys[i].dtype == PLHIP_BOOL;
+    if (any_bool) {
+      Staging bst;
+      std::vector<plhip_column_t> lk(keys, keys + n_keys);
+      for (int i = 0; i < n_keys; i++)
+        if (lk[i].dtype == PLHIP_BOOL && (rc = lower_bool_column(lk[i], 1, PLHIP_U8, bst))) { (void)hipStreamSynchronize(c.stream); return rc; }
+      rc = plhip_group_tuples(lk.data(), n_keys, sorted, out_location, out);
+      (void)hipStreamSynchronize(c.stream); // the unpacked copies are freed on the way out
+      return rc;
+    }
+  }
   plhip_groups *Gp = new (std::nothrow) plhip_groups();
   if (!Gp) return fail(PLHIP_ERR_OOM, "host allocation failed");
   Gp->n_rows = n;
@@ -3523,9 +3543,51 @@ int pack_impl(const plhip_result_t *r, int32_t n_keys, uint64_t null_hash, int32
 
 // Series::agg_sum / agg_mean / agg_min / agg_max and GroupsProxy::group_count over the CSR groups; first / last / var / std /
 // median / n_unique through their own kernels.
+namespace {
+// A Boolean column over CSR groups: the reference casts -- sum over the IdxSize (u32) cast (aggregations/boolean.rs:107-109), mean over
+// the Float64 cast (dispatch.rs:164: the same value as the u32 cast's f64 mean, the terms being 0 and 1) -- and keeps min / max
+// (boolean.rs:20-106; an all-null group is null) and first / last Boolean.  var / std / median / quantile / n_unique of a Boolean
+// column are not on this path.
+int32_t bool_agg_groups(const plhip_column_t *values, int32_t kind, const plhip_groups_t *groups, uint32_t flags, plhip_result_t **out) {
+  if (!out) return fail(PLHIP_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  const bool as_u32 = kind == PLHIP_AGG_SUM || kind == PLHIP_AGG_MEAN;
+  const bool as_bool = kind == PLHIP_AGG_MIN || kind == PLHIP_AGG_MAX || kind == PLHIP_AGG_FIRST || kind == PLHIP_AGG_LAST;
+  if (!as_u32 && !as_bool) return fail(PLHIP_ERR_UNSUPPORTED_DTYPE, "Boolean columns aggregate by sum, mean, min, max, first, last or count over groups");
+  int rc = ensure_ctx();
+  if (rc) return rc;
+  Ctx &c = g_ctx;
+  Staging st;
+  StreamDrain drain(c.stream); // (declared after st: the stream retires the kernels that read the unpacked copy before it is freed)
+  plhip_column_t lv = *values;
+  if ((rc = lower_bool_column(lv, as_u32 ? 4u : 1u, as_u32 ? PLHIP_U32 : PLHIP_U8, st))) return rc;
+  plhip_result_t *R = nullptr;
+  if ((rc = agg_groups_impl(&lv, kind, groups, (flags & 0xFF00u) | PLHIP_FLAG_OUTPUT_DEVICE, 0.5, 4, &R))) return rc;
+  std::unique_ptr<plhip_result> Rg(R);
+  const int64_t G = R->n_rows;
+  if (as_bool) {
+    if (R->cols.size() != 1 || R->cols[0].dtype != PLHIP_U8) return fail(PLHIP_ERR_COMPUTE, "a Boolean output came back with an unexpected type");
+    ResultCol &col = R->cols[0];
+    void *bits = nullptr;
+    size_t cap = 0;
+    HIP_TRY(g_pool.get(c.device, (size_t)((G + 63) / 64) * 8 + 8, &bits, &cap));
+    launch_pack_bool(col.values, 1, G, (uint64_t *)bits, c.stream);
+    const hipError_t e = hipGetLastError() == hipSuccess ? hipStreamSynchronize(c.stream) : hipErrorLaunchFailure;
+    if (e != hipSuccess) { g_pool.put(c.device, bits, cap); return fail_hip(e, "k_pack_bool"); }
+    if (col.vcap) g_pool.put(c.device, col.values, col.vcap); else hipFree(col.values);
+    col.values = bits; col.vcap = cap; col.dtype = PLHIP_BOOL;
+  }
+  return finish_result(Rg.release(), (uint64_t)G, flags & PLHIP_FLAG_OUTPUT_DEVICE, out);
+}
+} // namespace
+
 int32_t plhip_agg_groups(const plhip_column_t *values, int32_t kind, const plhip_groups_t *groups, uint32_t flags,
                          plhip_result_t **out) {
   if (kind < 0 || kind > PLHIP_AGG_N_UNIQUE) { if (out) *out = nullptr; return fail(PLHIP_ERR_INVALID, "bad aggregation kind"); }
+  if (values && values->dtype == PLHIP_BOOL && kind != PLHIP_AGG_COUNT) {
+    if (groups && values->length != groups->n_rows) { if (out) *out = nullptr; return fail(PLHIP_ERR_SHAPE_MISMATCH, "the column and the groups differ in length"); }
+    return bool_agg_groups(values, kind, groups, flags, out);
+  }
   return agg_groups_impl(values, kind, groups, flags, 0.5, 4 /* Linear: agg_median */, out);
 }
 

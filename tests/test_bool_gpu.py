@@ -71,6 +71,53 @@ def test_bool_device_column_and_single_key(oracle):
     util.assert_frames_match(g, util.oracle_to_np(want), 1, what="device-resident bool key")
 
 
-def test_bool_rejected_elsewhere():
-    with pytest.raises(_ffi.PlHipError):
-        pa.DataFrame({"k": np.array([True, False, True])}).group_by("k").groups()
+def _canon(lists):
+    return sorted(tuple(l) for l in lists)
+
+
+@pytest.mark.parametrize("offset", [0, 5])
+def test_bool_in_the_csr_seams(oracle, offset):
+    """Boolean keys in plhip_group_tuples (grouped as their UInt8 cast, into_groups.rs:215-230) and Boolean value columns in
+    plhip_agg_groups: sum over the IdxSize cast (boolean.rs:107-109), mean over the Float64 cast (dispatch.rs:164), min / max
+    (boolean.rs:20-106) and first / last stay Boolean.  Against the oracle's CSR restatement on the cast columns."""
+    rng = np.random.default_rng(17 + offset)
+    n = 40_000
+    tot = n + offset + 3
+    kb, kbm = rng.random(tot) < 0.45, rng.random(tot) >= 0.08
+    k2 = rng.integers(0, 300, tot).astype(np.int32)
+    vb, vbm = rng.random(tot) < 0.6, rng.random(tot) >= 0.25
+    sl = slice(offset, offset + n)
+    keys_b = [Column("kb", kb, kbm, offset=offset, length=n), Column("k2", k2, offset=offset, length=n)]
+    keys_u = [Column("kb", kb[sl].astype(np.uint8), kbm[sl]), Column("k2", k2[sl])]
+    for sorted_ in (True, False):
+        want, got = oracle.Groups(keys_u, sorted_), pa.group_tuples(keys_b, sorted_)
+        assert got.n_groups == want.n_groups and got.n_rows == n
+        first, off, idx = got.buffers()
+        lists = [idx[off[g]:off[g + 1]].tolist() for g in range(got.n_groups)]
+        assert all(l == sorted(l) and first[g] == l[0] for g, l in enumerate(lists))
+        if sorted_:
+            assert lists == want.lists()
+        else:
+            assert _canon(lists) == _canon(want.lists())
+    g_o, g_p = oracle.Groups(keys_u, True), pa.group_tuples(keys_b, True)
+    v_b = Column("vb", vb, vbm, offset=offset, length=n)
+    v_u32, v_u8 = Column("vb", vb[sl].astype(np.uint32), vbm[sl]), Column("vb", vb[sl].astype(np.uint8), vbm[sl])
+    for kind in ("sum", "mean", "min", "max", "first", "last"):
+        src = v_u32 if kind in ("sum", "mean") else v_u8
+        wv, wm = oracle.agg(src, kind, g_o) if kind in ("sum", "mean", "min", "max") else oracle.agg_ext(src, kind, g_o, 1)
+        col = pa.agg_groups(v_b, kind, g_p)
+        gv, gm = col.to_numpy(), col.valid_mask()
+        gm = np.ones(len(gv), bool) if gm is None else gm
+        assert np.array_equal(gm, wm), f"{kind}: validity"
+        if kind in ("sum", "mean"):
+            assert col.dtype == (_ffi.U32 if kind == "sum" else _ffi.F64) and gv.dtype == wv.dtype
+            assert np.array_equal(gv[gm], wv[wm]), kind  # 0 / 1 terms: the sums are exact integers, the means their exact quotients
+        else:
+            assert col.dtype == _ffi.BOOL, kind
+            assert np.array_equal(gv[gm].astype(np.uint8), wv[wm]), kind
+    # a single Boolean key through the mirror: the reference's three possible groups (true, false, null)
+    out = pa.DataFrame({"k": Column("k", kb[sl], kbm[sl])}).group_by("k").groups()
+    assert out.n_groups == 3
+    for kind in ("var", "median", "n_unique"):
+        with pytest.raises(_ffi.PlHipError):
+            pa.agg_groups(v_b, kind, g_p)
