@@ -70,7 +70,7 @@ typedef enum plhip_dtype {
    * (aggregations/boolean.rs:107-109), mean(bool) the f64 mean of its cast (aggregations/dispatch.rs:164), min / max stay
    * Boolean (boolean.rs:20-106), count is a count.  Also accepted, with the same casts, by the CSR seams: plhip_group_tuples
    * (Boolean keys) and plhip_agg_groups (sum, mean, min, max, first, last of a Boolean column; first / last stay Boolean) --
-   * and by plhip_vec_hash_seeded.  Other entry points reject the dtype. */
+   * by plhip_group_by_agg_sharded, and by plhip_vec_hash_seeded.  Other entry points reject the dtype. */
   PLHIP_BOOL = 10
 } plhip_dtype_t;
 

@@ -2292,8 +2292,12 @@ int lower_bool_column(plhip_column_t &col, uint32_t w, int dt, Staging &st) {
 // Boolean columns (PLHIP_BOOL): lowered at the boundary with the reference's own casts -- a key to UInt8 (into_groups.rs:215-230), a
 // value column to IdxSize = u32 (boolean.rs:107-109 for sum; the f64 mean of the cast is dispatch.rs:164's) -- and the Boolean outputs
 // (keys, min, max) packed back into bitmaps.
+int sharded_impl(plhip_comm *comm, const plhip_column_t *keys, int32_t n_keys, const plhip_column_t *values, int32_t n_values,
+                 const plhip_agg_t *aggs, int32_t n_aggs, uint32_t flags, const plhip_options_t *opts, plhip_result_t **out);
+// comm != nullptr: the row-sharded query (plhip_group_by_agg_sharded) over the lowered columns -- every rank lowers alike, the
+// schema is the same everywhere
 int bool_group_by(const plhip_column_t *keys, int32_t n_keys, const plhip_column_t *values, int32_t n_values, const plhip_agg_t *aggs,
-                  int32_t n_aggs, uint32_t flags, const plhip_options_t *opts, plhip_result_t **out) {
+                  int32_t n_aggs, uint32_t flags, const plhip_options_t *opts, plhip_result_t **out, plhip_comm *comm = nullptr) {
   if (flags & PLHIP_FLAG_PARTIAL) return fail(PLHIP_ERR_UNSUPPORTED_DTYPE, "Boolean columns have no partial (mergeable) form");
   if (n_keys < 1 || n_keys > PLHIP_MAX_KEYS || n_values < 0 || n_values > PLHIP_MAX_VALS) return fail(PLHIP_ERR_INVALID, "bad column counts");
   int rc = ensure_ctx();
@@ -2315,7 +2319,9 @@ int bool_group_by(const plhip_column_t *keys, int32_t n_keys, const plhip_column
     bool_out.push_back(on_bool && (aggs[i].kind == PLHIP_AGG_MIN || aggs[i].kind == PLHIP_AGG_MAX));
   }
   plhip_result_t *R = nullptr;
-  if ((rc = group_by_agg_impl(lk.data(), n_keys, lv.data(), n_values, aggs, n_aggs, flags | PLHIP_FLAG_OUTPUT_DEVICE, opts, &R))) return rc;
+  if (comm) rc = sharded_impl(comm, lk.data(), n_keys, lv.data(), n_values, aggs, n_aggs, flags | PLHIP_FLAG_OUTPUT_DEVICE, opts, &R);
+  else rc = group_by_agg_impl(lk.data(), n_keys, lv.data(), n_values, aggs, n_aggs, flags | PLHIP_FLAG_OUTPUT_DEVICE, opts, &R);
+  if (rc) { (void)hipStreamSynchronize(c.stream); return rc; } // (the unpacked copies are freed on the way out)
   std::unique_ptr<plhip_result> Rg(R);
   StreamDrain drain(c.stream);
   const int64_t G = R->n_rows;
@@ -4065,6 +4071,10 @@ int32_t plhip_group_by_agg_sharded(plhip_comm_t *comm, const plhip_column_t *key
   int rc = ensure_ctx();
   if (rc) return rc;
   if (comm->device != g_ctx.device) return fail(PLHIP_ERR_INVALID, "the communicator belongs to another device than the calling thread's");
+  bool any_bool = false; // Boolean columns: the reference's casts at the boundary, as in plhip_group_by_agg (bool_group_by)
+  for (int i = 0; i < n_keys; i++) any_bool |= keys[i].dtype == PLHIP_BOOL;
+  for (int i = 0; i < n_values && i < PLHIP_MAX_VALS; i++) any_bool |= values[i].dtype == PLHIP_BOOL;
+  if (any_bool) return bool_group_by(keys, n_keys, values, n_values, aggs, n_aggs, flags, opts, out, comm);
   return sharded_impl(comm, keys, n_keys, values, n_values, aggs, n_aggs, flags, opts, out);
 }
 

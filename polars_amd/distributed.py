@@ -164,8 +164,11 @@ class HipEngine:
         out = []
         for name, cs in zip(names, cols):
             n = cs.length
-            dt = _torch_dtype(cs.dtype)
-            t = self._alias(cs.values, n * torch.empty(0, dtype=dt).element_size(), owner).view(dt) if n else torch.empty(0, dtype=dt, device=self.device)
+            if cs.dtype == _ffi.BOOL:  # a Boolean output column is a bitmap: unpacked into a bool tensor
+                t = _unpack_bits(self._alias(cs.values, (n + 7) // 8, owner), n) if n else torch.empty(0, dtype=torch.bool, device=self.device)
+            else:
+                dt = _torch_dtype(cs.dtype)
+                t = self._alias(cs.values, n * torch.empty(0, dtype=dt).element_size(), owner).view(dt) if n else torch.empty(0, dtype=dt, device=self.device)
             mask = None
             if cs.validity:
                 nb = (n + 7) // 8

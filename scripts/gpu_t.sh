@@ -1,4 +1,4 @@
 #!/bin/bash
 mkdir -p gpurun_out
-timeout -k 10 600 python -u -m pytest tests/test_bool_gpu.py tests/test_parity_gpu.py -x -q --timeout 300 --timeout-method thread -k "bool or group_tuples or agg_groups" > gpurun_out/t_bool.log 2>&1 || { tail -40 gpurun_out/t_bool.log; exit 1; }
+timeout -k 10 600 python -u -m pytest tests/test_sharded_gpu.py tests/test_bool_gpu.py -x -q --timeout 300 --timeout-method thread > gpurun_out/t_bool.log 2>&1 || { tail -40 gpurun_out/t_bool.log; exit 1; }
 tail -2 gpurun_out/t_bool.log

@@ -172,6 +172,38 @@ def test_sharded_dense_exchange_world1(oracle, rccl_world1, case, monkeypatch):
         assert eng.last_protocol.startswith("dense") and eng.last_host_syncs == 1, (eng.last_protocol, eng.last_host_syncs)
 
 
+@pytest.mark.parametrize("hint", [0, 4000])
+def test_sharded_boolean_columns(oracle, rccl_world1, hint):
+    """Boolean key and value columns through plhip_group_by_agg_sharded: lowered with the reference's casts on every rank (key ->
+    UInt8, into_groups.rs:215-230; values -> IdxSize, boolean.rs:107-109), partials exchanged and finalized as for any integer
+    column, Boolean outputs (the key, min, max) packed back into bitmaps.  Against the oracle on the cast columns."""
+    import torch
+
+    from polars_amd import distributed as pd_
+
+    rng = np.random.default_rng(61 + hint)
+    n = 400_000
+    kb, kbm = rng.random(n) < 0.4, rng.random(n) >= 0.05
+    k2 = rng.integers(0, 900, n).astype(np.int32)
+    vb, vbm = rng.random(n) < 0.7, rng.random(n) >= 0.2
+    w = rng.integers(-50, 50, n).astype(np.int64)
+    keys = [Column("kb", kb, kbm), Column("k2", k2)]
+    vals = [Column("vb", vb, vbm), Column("w", w)]
+    aggs = [(0, "sum"), (0, "mean"), (0, "min"), (0, "max"), (0, "count"), (1, "sum"), (1, "max")]
+    eng = pd_.HipEngine(torch.device("cuda:0"))
+    res = pd_.group_by_agg_sharded(keys, vals, aggs, device=torch.device("cuda:0"), engine=eng, n_groups_hint=hint, force_exchange=True)
+    assert [c.code for c in res] == [_ffi.BOOL, _ffi.I32, _ffi.U32, _ffi.F64, _ffi.BOOL, _ffi.BOOL, _ffi.U32, _ffi.I64, _ffi.I64]
+    ok = [Column("kb", kb.astype(np.uint8), kbm), Column("k2", k2)]
+    ov = [Column("vb", vb.astype(np.uint32), vbm), Column("w", w)]
+    want, _ = oracle.group_by_agg(ok, ov, aggs)
+    got = []
+    for i, c in enumerate(res):
+        v = c.t.cpu().numpy()
+        v = v.astype(np.uint8 if i == 0 else np.uint32) if c.code == _ffi.BOOL else v.view(_ffi.code_np_dtype(c.code))
+        got.append((v, None if c.mask is None else c.mask.cpu().numpy()))
+    util.assert_frames_match(got, util.oracle_to_np(want), 2, what=f"sharded, Boolean columns, hint {hint}")
+
+
 def test_sharded_torch_transport_fallback(oracle, rccl_world1, monkeypatch):
     """When the library's own RCCL communicator cannot be made, every rank falls back to the group's all_to_all_single
     (device tensors) behind the same entry point: forced here."""
