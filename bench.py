@@ -499,6 +499,10 @@ def run_workload(ctx, a, light=False):
     # right behind their own step waits for the stream's tail -- the wait that deferred completion took out of every step.
     lazy = not sharded and TIMING_EVERY >= 2
     unread = False
+    import gc
+
+    gc_was_on = gc.isenabled()
+    gc.disable()  # (no collector pause inside the timed region: a step is ~0.1 ms, a generation-2 pass several)
     t0 = time.perf_counter()
     for i_step in range(steps):
         sampled = i_step % TIMING_EVERY == TIMING_EVERY - 1
@@ -517,6 +521,8 @@ def run_workload(ctx, a, light=False):
     t_loop = time.perf_counter() - t0
     ctx.sync()
     dt = time.perf_counter() - t0
+    if gc_was_on:
+        gc.enable()
     if verbose:  # (diagnostics on stderr: where the timed region's time went)
         per = [round((b - a) * 1e6, 1) for a, b in zip([t0] + t_steps[:-1], t_steps)]
         print(f"[bench] loop {t_loop * 1e3:.4f} ms, closing sync {(dt - t_loop) * 1e3:.4f} ms, {steps} steps; per step us: {per[:40]}", file=sys.stderr)
