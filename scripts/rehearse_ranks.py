@@ -122,4 +122,38 @@ for what in ("dense", "dense, last rank empty", "dense, rank 0 misaligned", "den
         util.assert_frames_match(got, util.oracle_to_np(want), 1, what=f"{what}, {world} ranks")
         print(f"ok: {what} n={len(rows)} world={world} groups={len(got[0][0])} rows per rank={[len(x[0]) for x in gathered]} "
               f"protocol={eng.last_protocol[:12]} host syncs={eng.last_host_syncs}", flush=True)
+# more codes than eight LDS ranges hold (config 4's regime): the local pass range-partitions its rows (dense_part) and the exchange
+# stays the dense one; a last rank without rows sends the accumulators' initial values
+ncat2, n2 = 400_003, 3_000_000
+rng = np.random.default_rng(29)
+kd = rng.integers(0, ncat2, n2).astype(np.uint32)
+u1 = rng.integers(-5, 6, n2).astype(np.int32)
+u3 = np.round(rng.uniform(0, 100, n2), 6)
+u3m = rng.random(n2) >= 0.05
+for what in ("dense beyond eight ranges", "dense beyond eight ranges, last rank empty"):
+    lo, hi = rank * n2 // world, (rank + 1) * n2 // world
+    if "empty" in what and rank == world - 1:
+        lo = hi
+    keys = [Column("id3", kd[lo:hi], dtype=_ffi.U32).set_categories(ncat2)]
+    vals = [Column("v1", u1[lo:hi]), Column("v3", u3[lo:hi], u3m[lo:hi])]
+    res = group_by_agg_sharded(keys, vals, daggs, device=dev, engine=eng, n_groups_hint=ncat2)
+    assert eng.last_protocol.startswith("dense"), (what, eng.last_protocol)
+    assert lo == hi or eng.last_partial_strategy == "dense_part", (what, eng.last_partial_strategy)
+    mine = []
+    for c in res:
+        mine.append(c.t.cpu().numpy().view(_ffi.code_np_dtype(c.code)))
+        mine.append(np.ones(c.t.numel(), bool) if c.mask is None else c.mask.cpu().numpy())
+    mine.append((lo, hi))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    if rank == 0:
+        from oracle import oracle as orc
+
+        ncol = len(daggs) + 1
+        got = [(np.concatenate([x[2 * j] for x in gathered]), np.concatenate([x[2 * j + 1] for x in gathered])) for j in range(ncol)]
+        rows = np.concatenate([np.arange(x[-1][0], x[-1][1]) for x in gathered])
+        want, _ = orc.group_by_agg([Column("id3", kd[rows])], [Column("v1", u1[rows]), Column("v3", u3[rows], u3m[rows])], daggs)
+        util.assert_frames_match(got, util.oracle_to_np(want), 1, what=f"{what}, {world} ranks")
+        print(f"ok: {what} n={len(rows)} world={world} groups={len(got[0][0])} rows per rank={[len(x[0]) for x in gathered]} "
+              f"protocol={eng.last_protocol[:12]} host syncs={eng.last_host_syncs}", flush=True)
 dist.destroy_process_group()
