@@ -325,7 +325,10 @@ __global__ void __launch_bounds__(256) k_key_minmax(Plan P, uint64_t *partials) 
   }
 }
 // minmax[2k] = ~min (0 when no row is valid), minmax[2k + 1] = max: the host's measure_key_columns reads them
-__global__ void __launch_bounds__(256) k_key_minmax_final(const uint64_t *__restrict__ partials, uint32_t n_blocks, uint64_t *minmax) {
+// host_word (may be nullptr; one key column of at most 32 bits): the pair also goes to the host as ONE 64-bit word in pinned memory,
+// min << 32 | max (1 << 32 | 0, i.e. min > max, when no row is valid) -- one relaxed system-scope store, nothing to order
+__global__ void __launch_bounds__(256) k_key_minmax_final(const uint64_t *__restrict__ partials, uint32_t n_blocks, uint64_t *minmax,
+                                                          uint64_t *host_word) {
   __shared__ uint64_t sh[4][2];
   const int k = blockIdx.x;
   uint64_t lo = ~0ull, hi = 0;
@@ -344,17 +347,20 @@ __global__ void __launch_bounds__(256) k_key_minmax_final(const uint64_t *__rest
     for (int w = 1; w < 4; w++) { lo = sh[w][0] < lo ? sh[w][0] : lo; hi = sh[w][1] > hi ? sh[w][1] : hi; }
     minmax[2 * k] = lo <= hi ? ~lo : 0ull;
     minmax[2 * k + 1] = lo <= hi ? hi : 0ull;
+    if (host_word && k == 0)
+      __hip_atomic_store(host_word, lo <= hi ? ((lo & 0xFFFFFFFFull) << 32) | (hi & 0xFFFFFFFFull) : (1ull << 32), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
 size_t key_minmax_scratch_bytes(int n_keys) { return (size_t)n_keys * MM_GRID * 16; }
 
 // partials: key_minmax_scratch_bytes(p.n_keys) bytes of scratch
-void launch_key_minmax(const Plan &p, uint64_t *minmax, uint64_t *partials, hipStream_t s) {
+void launch_key_minmax(const Plan &p, uint64_t *minmax, uint64_t *partials, hipStream_t s, uint64_t *host_word) {
   int64_t blocks = (p.n_rows + 4095) / 4096;
   int grid = (int)(blocks < 1 ? 1 : (blocks > MM_GRID ? MM_GRID : blocks));
   hipLaunchKernelGGL(k_key_minmax, dim3(grid, p.n_keys), dim3(256), 0, s, p, partials);
-  hipLaunchKernelGGL(k_key_minmax_final, dim3(p.n_keys), dim3(256), 0, s, partials, (uint32_t)grid, minmax);
+  hipLaunchKernelGGL(k_key_minmax_final, dim3(p.n_keys), dim3(256), 0, s, partials, (uint32_t)grid, minmax, host_word);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -65,7 +65,8 @@ void launch_rank_scatter(const uint64_t *slots, uint64_t n, uint32_t *rank, hipS
 void launch_encode_rows(const Plan &p, TableRef t, const uint32_t *rank, uint32_t *ids, hipStream_t s);
 void launch_sample_keys(const Plan &p, TableRef t, int64_t n_sample, int64_t stride, hipStream_t s);
 size_t key_minmax_scratch_bytes(int n_keys);
-void launch_key_minmax(const Plan &p, uint64_t *minmax, uint64_t *partials, hipStream_t s); // minmax[2k] = ~min, [2k + 1] = max
+// minmax[2k] = ~min, [2k + 1] = max; host_word: device alias of a pinned host word that receives min << 32 | max of key 0 (k_key_minmax_final)
+void launch_key_minmax(const Plan &p, uint64_t *minmax, uint64_t *partials, hipStream_t s, uint64_t *host_word = nullptr);
 void launch_vec_hash(const Plan &p, uint64_t null_hash, uint64_t true_hash, uint64_t false_hash, uint64_t *out, hipStream_t s);
 // rechunk: n validity bits from bit src_off of `src` (nullptr = all valid) to bit dst_off of the zeroed bitmap `dst`
 // Boolean columns at the boundary: bitmap -> one u8 / u32 (0 or 1) per row, and back (row i of `dst` = src[i] != 0; dst holds whole 64-bit words)

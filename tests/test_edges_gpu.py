@@ -200,3 +200,35 @@ def test_result_pool_is_keyed_by_device():
     t.start()
     t.join(timeout=120)
     assert len(res) == 3 and res[0] == 1000 and res[1] == in_pool0 and res[2] > 0, res
+
+
+@pytest.mark.parametrize("case", ["all_ones_u32", "all_null", "i32_extremes", "u32_compact_high", "nullable_compact", "f32_key"])
+def test_key_range_comes_back_through_one_pinned_word(oracle, case):
+    """One key column of at most 32 bits: its min / max reach the host as ONE pinned 64-bit word (min << 32 | max) that starts
+    as all ones.  Edges: the answer IS all ones (every key 0xFFFFFFFF: the stream going idle settles it); no valid row; the
+    dtype's extremes in one column; a compact range high up (AUTO then takes the dense path with a bias); a nullable compact
+    range; an f32 key (bit patterns).  Sizes above 2^20 rows so that AUTO measures the range."""
+    rng = np.random.default_rng(5)
+    n = (1 << 20) + 12_345
+    km = None
+    if case == "all_ones_u32":
+        k = np.full(n, 0xFFFFFFFF, dtype=np.uint32)
+    elif case == "all_null":
+        k, km = rng.integers(0, 9, n).astype(np.int32), np.zeros(n, bool)
+    elif case == "i32_extremes":
+        k = rng.choice(np.array([-2**31, 2**31 - 1, 0, -1, 7], dtype=np.int32), n)
+    elif case == "u32_compact_high":
+        k = (0xFFFF0000 + rng.integers(0, 40_000, n)).astype(np.uint32)
+    elif case == "nullable_compact":
+        k, km = rng.integers(-20_000, 20_000, n).astype(np.int32), rng.random(n) >= 0.03
+    else:
+        k = rng.choice(np.array([0.0, -0.0, 1.5, -1.5, np.inf, np.nan], dtype=np.float32), n)
+    keys = [Column("k", k, km)]
+    values = [Column("v", rng.integers(-100, 100, n).astype(np.int64)), Column("w", np.round(rng.uniform(0, 1, n), 6))]
+    aggs = [(0, "sum"), (1, "mean"), (0, "min"), (0, "count")]
+    for strategy in ("auto", "sort"):  # (the sort strategy measures a nullable single key too)
+        check_parity(oracle, keys, values, aggs, strategy, what=f"pinned-word key range, {case}, {strategy}")
+    pa.set_strategy("auto")
+    check_parity(oracle, keys, values, aggs, "auto", what=f"pinned-word key range, {case}, again")
+    if case in ("u32_compact_high", "nullable_compact"):
+        assert pa.last_strategy() == "dense", pa.last_strategy()
