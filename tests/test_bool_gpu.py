@@ -121,3 +121,27 @@ def test_bool_in_the_csr_seams(oracle, offset):
     for kind in ("var", "median", "n_unique"):
         with pytest.raises(_ffi.PlHipError):
             pa.agg_groups(v_b, kind, g_p)
+
+
+def test_reference_bool_min_max_known_answers():
+    """py-polars/tests/unit/datatypes/test_bool.py:33-43 (test_bool_min_max), the column as ONE group over the CSR seam: nulls are
+    skipped, min is the AND and max the OR of the valid values; and :29-30 (test_bool_sum_empty): an empty Boolean column sums to 0."""
+    cases = [([None, True], True, True), ([None, True, False], False, True), ([False, True], False, True),
+             ([True, True], True, True), ([False, False], False, False)]
+    for data, want_min, want_max in cases:
+        vals = np.array([bool(x) for x in data])
+        mask = np.array([x is not None for x in data])
+        col = Column("b", vals, None if mask.all() else mask)
+        g = pa.group_tuples([Column("g", np.zeros(len(data), dtype=np.int32))], True)
+        lo, hi = pa.agg_groups(col, "min", g), pa.agg_groups(col, "max", g)
+        assert lo.dtype == _ffi.BOOL and hi.dtype == _ffi.BOOL
+        assert lo.to_list() == [want_min] and hi.to_list() == [want_max], (data, lo.to_list(), hi.to_list())
+        s = pa.agg_groups(col, "sum", g)
+        assert s.dtype == _ffi.U32 and s.to_list() == [sum(1 for x in data if x)]
+    # one group whose every value is null: min / max are null, the sum is 0 (aggregations/boolean.rs:20-106; agg_sum never null)
+    col = Column("b", np.array([True, False]), np.array([False, False]))
+    g = pa.group_tuples([Column("g", np.zeros(2, dtype=np.int32))], True)
+    assert pa.agg_groups(col, "min", g).to_list() == [None] and pa.agg_groups(col, "max", g).to_list() == [None]
+    assert pa.agg_groups(col, "sum", g).to_list() == [0]
+    out = pa.DataFrame({"k": np.zeros(0, np.int64), "b": np.zeros(0, bool)}).group_by("k").agg(pa.col("b").sum().alias("s"))
+    assert out["s"].dtype == _ffi.U32 and out["s"].to_list() == []
