@@ -307,7 +307,8 @@ int32_t plhip_group_by_agg_opts(const plhip_column_t *keys, int32_t n_keys, cons
  * own Arrow offset and optional validity bitmap -- are laid end to end in HBM by the library (values: one copy per chunk on the
  * library's stream; validity: a bit-granular copy kernel, chunks without a bitmap contribute ones) and the query runs on the
  * single-chunk columns.  A column with ONE chunk is passed through untouched (zero-copy for device memory).  All columns must
- * have the same total length; chunk boundaries need not line up between columns. */
+ * have the same total length; chunk boundaries need not line up between columns.  PLHIP_BOOL columns are accepted: their value
+ * bitmaps are laid end to end with the same bit-granular copy. */
 typedef struct plhip_chunked_column {
   const plhip_column_t *chunks; /* n_chunks single-chunk arrays of one dtype */
   int32_t n_chunks;

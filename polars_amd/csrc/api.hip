@@ -2411,7 +2411,8 @@ int rechunk_column(const plhip_chunked_column_t &cc, plhip_column_t &out, Stagin
   if (cc.n_chunks < 1 || !cc.chunks) return fail(PLHIP_ERR_INVALID, "a chunked column needs at least one chunk");
   if (cc.n_chunks == 1) { out = cc.chunks[0]; return PLHIP_OK; }
   const int dt = cc.chunks[0].dtype;
-  const int w = dtype_width(dt);
+  const bool is_bool = dt == PLHIP_BOOL; // the values buffers are bitmaps: laid end to end bit by bit, like the validity below
+  const int w = is_bool ? 1 : dtype_width(dt);
   if (!w) return fail(PLHIP_ERR_UNSUPPORTED_DTYPE, "unsupported dtype code " + std::to_string(dt));
   int64_t total = 0;
   bool any_valid = false;
@@ -2425,9 +2426,10 @@ int rechunk_column(const plhip_chunked_column_t &cc, plhip_column_t &out, Stagin
     any_valid |= c.validity != nullptr;
   }
   void *dv = nullptr, *db = nullptr;
-  HIP_TRY(hipMalloc(&dv, (size_t)std::max<int64_t>(total, 1) * w));
-  st.owned.push_back(dv);
   const size_t bm_bytes = (((size_t)total + 31) / 32) * 4 + 8;
+  HIP_TRY(hipMalloc(&dv, is_bool ? bm_bytes : (size_t)std::max<int64_t>(total, 1) * w));
+  st.owned.push_back(dv);
+  if (is_bool) HIP_TRY(hipMemsetAsync(dv, 0, bm_bytes, s));
   if (any_valid) {
     HIP_TRY(hipMalloc(&db, bm_bytes));
     st.owned.push_back(db);
@@ -2438,7 +2440,21 @@ int rechunk_column(const plhip_chunked_column_t &cc, plhip_column_t &out, Stagin
     const plhip_column_t &c = cc.chunks[i];
     if (!c.length) continue;
     const hipMemcpyKind kind = c.location == PLHIP_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    HIP_TRY(hipMemcpyAsync((uint8_t *)dv + (size_t)pos * w, (const uint8_t *)c.values + (size_t)c.offset * w, (size_t)c.length * w, kind, s));
+    if (is_bool) {
+      const uint8_t *src = (const uint8_t *)c.values;
+      int64_t src_off = c.offset;
+      if (c.location == PLHIP_HOST) { // the bitmap's bytes that cover the chunk travel to the device first
+        const int64_t b0 = c.offset >> 3, b1 = (c.offset + c.length + 7) >> 3;
+        void *tmp = nullptr;
+        HIP_TRY(hipMalloc(&tmp, (size_t)(b1 - b0) + 8));
+        st.owned.push_back(tmp);
+        HIP_TRY(hipMemcpyAsync(tmp, (const uint8_t *)c.values + b0, (size_t)(b1 - b0), hipMemcpyHostToDevice, s));
+        src = (const uint8_t *)tmp; src_off = c.offset & 7;
+      }
+      launch_copy_bits((uint32_t *)dv, pos, src, src_off, c.length, s);
+      HIP_TRY(hipGetLastError());
+    } else
+      HIP_TRY(hipMemcpyAsync((uint8_t *)dv + (size_t)pos * w, (const uint8_t *)c.values + (size_t)c.offset * w, (size_t)c.length * w, kind, s));
     if (any_valid) {
       const uint8_t *src = c.validity;
       int64_t src_off = c.offset;

@@ -432,7 +432,7 @@ def group_by_agg_raw(keys: Sequence[Column], values: Sequence[Column], aggs: Seq
 
 
 def group_by_agg_chunked_raw(keys: Sequence[Sequence[Column]], values: Sequence[Sequence[Column]], aggs: Sequence[tuple[int, int]],
-                             flags: int = 0, n_groups_hint: int = 0):
+                             flags: int = 0, n_groups_hint: int = 0, slice_: tuple[int, int] | None = None):
     """plhip_group_by_agg_chunked: every column is a list of chunks (Columns of one dtype, host or device, each with its own
     offset / validity); the library lays them end to end in HBM as the reference's rechunk does (executors/group_by.rs:66).
     Returns (handle, [ColumnStruct ...]) like group_by_agg_raw."""
@@ -458,6 +458,8 @@ def group_by_agg_chunked_raw(keys: Sequence[Sequence[Column]], values: Sequence[
     aarr = (_ffi.AggStruct * max(1, len(aggs)))(*[_ffi.AggStruct(c, k) for c, k in aggs])
     handle = C.c_void_p()
     opts = _ffi.OptionsStruct(C.sizeof(_ffi.OptionsStruct), int(n_groups_hint))
+    if slice_ is not None:
+        opts.slice_offset, opts.slice_len, opts.has_slice = int(slice_[0]), int(slice_[1]), 1
     _ffi.check(L.plhip_group_by_agg_chunked(karr, len(keys), varr, len(values), aarr, len(aggs), flags, C.byref(opts), C.byref(handle)))
     cols = []
     for i in range(L.plhip_result_num_columns(handle)):
@@ -528,11 +530,26 @@ def _execute(df: DataFrame, by: list[str], exprs: list[Expr], maintain_order: bo
     if len(keys) == 1 and keys[0].n_categories is not None:  # a Categorical's codes: the dense-code path (perfect.rs:190-227)
         flags |= _ffi.FLAG_KEYS_DENSE
         hint = keys[0].n_categories
-    handle, cols = group_by_agg_raw(keys, vals, aggs, flags, hint, slice_=slice_)
+    from .io import ChunkedColumn
+
+    if any(isinstance(c, ChunkedColumn) for c in keys + vals):
+        # columns as a reader delivered them (io.py): the chunks go to the library as they are and are laid end to end in HBM
+        # (plhip_group_by_agg_chunked) -- the reference's df.as_single_chunk_par(), executors/group_by.rs:66, without the host copy
+        as_chunks = lambda c: c.chunks if isinstance(c, ChunkedColumn) else [c]
+        handle, cols = group_by_agg_chunked_raw([as_chunks(k) for k in keys], [as_chunks(v) for v in vals], aggs, flags, hint, slice_=slice_)
+    else:
+        handle, cols = group_by_agg_raw(keys, vals, aggs, flags, hint, slice_=slice_)
     try:
         host = [_host_column(nm, cs) for nm, cs in zip(names, cols)]
     finally:
         _ffi.lib().plhip_result_free(handle)
+    for i, k in enumerate(keys):  # a dictionary-encoded key read from a file: its codes back to the categories
+        cats = getattr(k, "dictionary", None)
+        if isinstance(cats, list) and i not in dicts:
+            from .strings import DecodedColumn
+
+            codes, m = host[i].to_numpy(), host[i].valid_mask()
+            host[i] = DecodedColumn(names[i], [cats[int(c)] if (m is None or m[j]) else None for j, c in enumerate(codes)])
     for i, d in dicts.items():  # the key codes back to their strings, as a Categorical's rev-map does at output
         from .strings import DecodedColumn
 
@@ -582,6 +599,7 @@ class Groups:
 def group_tuples(keys: Sequence[Column], sorted_: bool = False, location: int = _ffi.HOST) -> Groups:
     """IntoGroupsProxy::group_tuples (into_groups.rs:12-19) / group_by_threaded_multiple_keys_flat
     (hashing.rs:380-468) through plhip_group_tuples."""
+    keys = [k.rechunk() if hasattr(k, "rechunk") else k for k in keys]  # (a reader's chunked column: one chunk for this seam)
     karr = (_ffi.ColumnStruct * max(1, len(keys)))(*[k.struct() for k in keys])
     h = C.c_void_p()
     _ffi.check(_ffi.lib().plhip_group_tuples(karr, len(keys), int(sorted_), location, C.byref(h)))
@@ -609,6 +627,8 @@ def agg_groups(values: Column | None, kind: str, groups: Groups, ddof: int = 1) 
     (kind='count') through plhip_agg_groups.  Returns the one output column (host).  `ddof`: var / std."""
     L = _ffi.lib()
     h = C.c_void_p()
+    if values is not None and hasattr(values, "rechunk"):
+        values = values.rechunk()
     vs = C.byref(values.struct()) if values is not None else None
     code = _ffi.AGG_NAMES[kind] if kind in _ffi.AGG_NAMES else _ffi.AGG_GROUPS_ONLY[kind]
     _ffi.check(L.plhip_agg_groups(vs, code, groups._h, (int(ddof) & 0xFF) << 8, C.byref(h)))

@@ -1,0 +1,105 @@
+"""Arrow ingest at the boundary: an IPC / Parquet file read with the chunks left as the reader delivered them
+(polars_amd.io), grouped through plhip_group_by_agg_chunked -- the reference reads the same files into ChunkedArrays and rechunks
+on the host first (executors/group_by.rs:66).  The result must be the in-memory query's: checked against the oracle on the
+concatenated columns.  pyarrow writes the files (several record batches / row groups, nulls, sliced arrays, a dictionary-encoded
+string column, a plain string column, a Boolean column)."""
+import numpy as np
+import pytest
+
+import polars_amd as pa
+from polars_amd import _ffi
+from polars_amd.column import Column
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _table(n, seed, batches):
+    import pyarrow as pyar
+
+    rng = np.random.default_rng(seed)
+    k = rng.integers(-40, 40, n).astype(np.int32)
+    km = rng.random(n) >= 0.05
+    k2 = rng.integers(0, 7, n).astype(np.int64)
+    v = rng.integers(-1000, 1000, n).astype(np.int64)
+    w = np.round(rng.uniform(0, 100, n), 6)
+    wm = rng.random(n) >= 0.1
+    b = rng.random(n) < 0.3
+    cats = np.array([f"id{i:03d}" for i in range(50)])
+    s = cats[rng.integers(0, 50, n)]
+    arrays = {
+        "k": pyar.array(k, mask=~km), "k2": pyar.array(k2), "v": pyar.array(v), "w": pyar.array(w, mask=~wm), "b": pyar.array(b),
+        "cat": pyar.array(s).dictionary_encode(), "s": pyar.array(s),
+    }
+    t = pyar.table(arrays)
+    # several batches of uneven sizes
+    cuts = sorted(set(rng.integers(1, n - 1, batches - 1).tolist()))
+    bounds = [0] + cuts + [n]
+    parts = [t.slice(a, z - a) for a, z in zip(bounds[:-1], bounds[1:])]
+    host = {"k": (k, km), "k2": (k2, None), "v": (v, None), "w": (w, wm), "b": (b, None), "s": s}
+    return t, parts, host
+
+
+def _check(oracle, df, host, what):
+    out = df.group_by("k", "k2").agg(pa.col("v").sum().alias("vs"), pa.col("w").mean().alias("wm"), pa.col("w").min().alias("wlo"),
+                                     pa.col("v").max().alias("vhi"), pa.count().alias("n"), pa.col("b").sum().alias("bs"))
+    keys = [Column("k", *host["k"]), Column("k2", host["k2"][0])]
+    vals = [Column("v", host["v"][0]), Column("w", *host["w"]), Column("b", host["b"][0].astype(np.uint32))]
+    aggs = [(0, "sum"), (1, "mean"), (1, "min"), (0, "max"), (0, "count"), (2, "sum")]
+    want, _ = oracle.group_by_agg(keys, vals, aggs)
+    got = [(out[c].to_numpy(), out[c].valid_mask()) for c in out.columns]
+    util.assert_frames_match(got, util.oracle_to_np(want), 2, what=what)
+
+
+def test_read_ipc_keeps_the_record_batches_as_chunks(oracle, tmp_path):
+    import pyarrow as pyar
+    import pyarrow.ipc as ipc
+
+    t, parts, host = _table(300_000, 3, 7)
+    path = tmp_path / "g.arrow"
+    with ipc.new_file(str(path), t.schema) as w:
+        for p in parts:
+            for batch in p.to_batches():
+                w.write_batch(batch)
+    df = pa.read_ipc(path)
+    assert isinstance(df["k"], pa.ChunkedColumn) and df["k"].n_chunks >= 7 and df.height == 300_000
+    assert df["k"].chunks[0].location == _ffi.HOST
+    _check(oracle, df, host, "IPC file, memory-mapped, 7 record batches")
+    _check(oracle, pa.read_ipc(path, memory_map=False, columns=["k", "k2", "v", "w", "b"]), host, "IPC file, read into memory, projected")
+    # a dictionary-encoded string key (a Categorical on the reference side): the codes take the dense path, the result shows the strings
+    out = df.group_by("cat").agg(pa.col("v").sum().alias("vs"), pa.count().alias("n"))
+    assert pa.last_strategy() in ("dense", "direct"), pa.last_strategy()
+    want = {}
+    for name, val in zip(host["s"].tolist(), host["v"][0].tolist()):
+        a = want.setdefault(name, [0, 0])
+        a[0] += val; a[1] += 1
+    got = {k: [s_, n_] for k, s_, n_ in zip(out["cat"].to_list(), out["vs"].to_list(), out["n"].to_list())}
+    assert got == want
+    # a plain string key goes through the string encoder (one LargeUtf8 chunk)
+    out = df.group_by("s").agg(pa.col("v").sum().alias("vs"), pa.count().alias("n"))
+    got = {k: [s_, n_] for k, s_, n_ in zip(out["s"].to_list(), out["vs"].to_list(), out["n"].to_list())}
+    assert got == want
+
+
+def test_read_parquet_row_groups_and_sliced_arrays(oracle, tmp_path):
+    import pyarrow as pyar
+    import pyarrow.parquet as pq
+
+    t, parts, host = _table(200_000, 5, 4)
+    path = tmp_path / "g.parquet"
+    pq.write_table(t, str(path), row_group_size=37_000)
+    df = pa.read_parquet(path)
+    assert df.height == 200_000
+    _check(oracle, df, host, "Parquet file, row groups of 37 000 rows")
+    # chunks that are SLICES of larger arrays (Arrow offsets into values and validity, not multiples of 8)
+    sl = pyar.concat_tables([p.slice(3, max(len(p) - 5, 0)) for p in parts])
+    lens = [len(q) for q in parts]
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    keep = np.concatenate([np.arange(st + 3, st + 3 + max(ln - 5, 0)) for st, ln in zip(starts.tolist(), lens)])
+    h2 = {k_: (v_[0][keep], None if v_[1] is None else v_[1][keep]) if isinstance(v_, tuple) else v_[keep] for k_, v_ in host.items()}
+    df2 = pa.from_arrow(sl)
+    assert any(c.offset % 8 for c in df2["k"].chunks)
+    _check(oracle, df2, h2, "sliced chunks")
+    # the two-step seams take a reader's column too (rechunked for that call)
+    g = df2.group_by("k", "k2").groups()
+    assert g.n_rows == df2.height
