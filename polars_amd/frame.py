@@ -340,7 +340,7 @@ class LazyFrame:
         return LazyGroupBy(self._df, _flatten(by), maintain_order)
 
     def collect(self) -> DataFrame:
-        return self._df
+        return self._df.materialize() if hasattr(self._df, "materialize") else self._df  # (a scanned file: read it whole)
 
 
 class LazyGroupBy:

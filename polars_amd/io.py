@@ -170,3 +170,56 @@ def read_parquet(path, columns=None):
     import pyarrow.parquet as pq
 
     return from_arrow(pq.read_table(str(path), columns=None if columns is None else list(columns)))
+
+
+class _ScanFrame:
+    """What `scan_ipc` / `scan_parquet` hold until `collect()`: the file's schema and a loader.  A column is read when the query asks
+    for it (`get_column`), so only the columns a group-by names ever leave the file -- the effect of the reference's projection
+    pushdown (crates/polars-plan/src/logical_plan/optimizer/projection_pushdown) for this one query shape."""
+
+    def __init__(self, names, loader):
+        self._names, self._loader, self._cols = list(names), loader, {}
+
+    @property
+    def columns(self) -> list:
+        return list(self._names)
+
+    def get_column(self, name: str):
+        if name not in self._names:
+            raise _ffi.PlHipError(6, f"column {name!r} not found")
+        if name not in self._cols:
+            self._cols[name] = self._loader([name]).get_column(name)
+        return self._cols[name]
+
+    __getitem__ = get_column
+
+    @property
+    def loaded(self) -> list:
+        return list(self._cols)
+
+    def materialize(self):
+        from .frame import DataFrame
+
+        return DataFrame([self.get_column(n) for n in self._names])
+
+
+def scan_ipc(path, memory_map: bool = True):
+    """`pl.scan_ipc(path)`: a LazyFrame over the file; `.group_by(..).agg(..).collect()` reads the named columns only."""
+    import pyarrow as pa
+    import pyarrow.ipc as ipc
+
+    from .frame import LazyFrame
+
+    src = pa.memory_map(str(path), "r") if memory_map else pa.OSFile(str(path), "rb")
+    names = ipc.open_file(src).schema.names
+    return LazyFrame(_ScanFrame(names, lambda cols: read_ipc(path, columns=cols, memory_map=memory_map)))
+
+
+def scan_parquet(path):
+    """`pl.scan_parquet(path)`: as scan_ipc; pyarrow decodes only the requested column chunks of every row group."""
+    import pyarrow.parquet as pq
+
+    from .frame import LazyFrame
+
+    names = pq.read_schema(str(path)).names
+    return LazyFrame(_ScanFrame(names, lambda cols: read_parquet(path, columns=cols)))

@@ -103,3 +103,29 @@ def test_read_parquet_row_groups_and_sliced_arrays(oracle, tmp_path):
     # the two-step seams take a reader's column too (rechunked for that call)
     g = df2.group_by("k", "k2").groups()
     assert g.n_rows == df2.height
+
+
+def test_scan_reads_only_the_columns_the_query_names(oracle, tmp_path):
+    """pl.scan_ipc / pl.scan_parquet + group_by + agg + collect: the lazy query touches the key and value columns it names and
+    nothing else (projection pushdown for this query shape); slice pushdown rides along."""
+    import pyarrow.ipc as ipc
+    import pyarrow.parquet as pq
+
+    t, parts, host = _table(120_000, 9, 3)
+    p_ipc, p_pq = tmp_path / "s.arrow", tmp_path / "s.parquet"
+    with ipc.new_file(str(p_ipc), t.schema) as w:
+        for part in parts:
+            for batch in part.to_batches():
+                w.write_batch(batch)
+    pq.write_table(t, str(p_pq), row_group_size=50_000)
+    keys = [Column("k2", host["k2"][0])]
+    vals = [Column("w", *host["w"])]
+    want, _ = oracle.group_by_agg(keys, vals, [(0, "mean"), (0, "count")])
+    for lf in (pa.scan_ipc(p_ipc), pa.scan_parquet(p_pq)):
+        out = lf.group_by("k2").agg(pa.col("w").mean().alias("m"), pa.count().alias("n")).collect()
+        assert sorted(lf._df.loaded) == ["k2", "w"], lf._df.loaded
+        got = [(out[c].to_numpy(), out[c].valid_mask()) for c in out.columns]
+        util.assert_frames_match(got, util.oracle_to_np(want), 1, what="scan + group_by + agg")
+        head = lf.group_by("k2", maintain_order=True).agg(pa.col("w").mean().alias("m")).head(3).collect()
+        assert head.height == 3
+    assert pa.scan_parquet(p_pq).collect().height == 120_000
