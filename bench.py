@@ -28,6 +28,12 @@ WORKLOADS = {
     "q1": (["id1"], ["v1"], [(0, "sum")], False),
     "q3": (["id3"], ["v1", "v3"], [(0, "sum"), (1, "mean")], False),
     "q5": (["id6"], ["v1", "v2", "v3"], [(0, "sum"), (1, "sum"), (2, "sum")], False),
+    # the other fused queries of the reference's harness (run_h2oai_benchmark.py:66-160; q7's subtraction of the two G-row columns is
+    # the host layer's, q6 = median / std goes through the CSR seams, q8 / q9 are not group-by aggregations of this path)
+    "q2": (["id1", "id2"], ["v1"], [(0, "sum")], False),
+    "q4": (["id4"], ["v1", "v2", "v3"], [(0, "mean"), (1, "mean"), (2, "mean")], False),
+    "q7": (["id3"], ["v1", "v2"], [(0, "max"), (1, "min")], False),
+    "q10": (["id1", "id2", "id3", "id4", "id5", "id6"], ["v3", "v1"], [(0, "sum"), (1, "count")], False),
     "c3": (["id1", "id2", "id3"], ["v1", "v3"], [(0, "sum"), (0, "min"), (0, "max"), (1, "sum"), (1, "mean"), (0, "count")], True),
     # one skewed i64 key, f64 sum/mean + i64 sum/min/max + count
     "c5": (["k"], ["v3", "v1"], [(0, "sum"), (0, "mean"), (1, "sum"), (1, "min"), (1, "max"), (0, "count")], True),
@@ -559,7 +565,8 @@ def run_workload(ctx, a, light=False):
         dom_name = dom_name.decode() if isinstance(dom_name, bytes) else dom_name
         traffic_key = a.workload + ("_na" if a.na else "") + f":{n}:{strategy}"
         traffic, traffic_kernels = measured_traffic(traffic_key)
-        acc_dtype = {"q1": "i32", "q3": "i32+f64", "q5": "i32+f64", "c3": "i64+f64", "c5": "i64+f64"}[a.workload]
+        acc_dtype = {"q1": "i32", "q3": "i32+f64", "q5": "i32+f64", "c3": "i64+f64", "c5": "i64+f64",
+                     "q2": "i32", "q4": "f64", "q7": "i32", "q10": "f64+u32"}[a.workload]
         line = {
             "metric": "db-benchmark group-by rows/sec + % HBM roofline at 1/2/4/8 MI355X",
             "value": total_rows / (dt / steps),

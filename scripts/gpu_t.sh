@@ -1,4 +1,2 @@
 #!/bin/bash
-mkdir -p gpurun_out
-timeout -k 10 300 python -u -m pytest tests/test_io_gpu.py tests/test_chunked_gpu.py -x -q --timeout 200 --timeout-method thread > gpurun_out/t_io.log 2>&1 || { tail -50 gpurun_out/t_io.log; exit 1; }
-tail -2 gpurun_out/t_io.log
+PLHIP_DENSE_VERBOSE=1 timeout -k 10 200 python -u -m pytest tests/test_edges_gpu.py -x -q -s --timeout 100 --timeout-method thread -k "pinned_word" 2>&1 | grep -v amdgpu.ids | tail -30
