@@ -643,6 +643,11 @@ EXTRA_CONFIGS = [
     ("q3_exact_fold", "q3", {"exact_fold": True}, 50, 5, 8),
     ("c3", "c3", {}, 10, 2, 45),
     ("c5", "c5", {}, 4, 1, 90),
+    # the other fused queries of the reference's harness, behind the BASELINE configs (they run if the budget still allows)
+    ("q2", "q2", {}, 100, 10, 8),
+    ("q4", "q4", {}, 100, 10, 8),
+    ("q7", "q7", {}, 100, 10, 8),
+    ("q10", "q10", {}, 30, 3, 15),
 ]
 
 
