@@ -347,6 +347,43 @@ def utf8_group_codes(offsets: np.ndarray, data: np.ndarray, valid: np.ndarray | 
     return codes[:n], first[:g]
 
 
+def agg_utf8(strings: list, kind: str, groups: Groups) -> list:
+    """A string column over GroupsProxy::Idx, restated in plain Python (small cases).  min / max: Utf8Chunked::agg_min / agg_max
+    (aggregations/utf8.rs:21-142): an empty group -> None, a one-row group -> that row (null stays null), otherwise the fold
+    `if acc < v { acc } else { v }` over the group's non-null rows in Rust's `str` order (= byte order), None when all are null.
+    first / last: Series::agg_first / agg_last (aggregations/dispatch.rs:48-78,182-212): the value at the group's first / last row.
+    n_unique: distinct values of the group, a null counting as one (dispatch.rs:82-105).  sum / mean: full-null columns
+    (dispatch.rs:126,177)."""
+    as_b = lambda v: v if isinstance(v, bytes) else v.encode()
+    out = []
+    for g in range(groups.n_groups):
+        idx = groups.indices[groups.offsets[g]:groups.offsets[g + 1]].tolist()
+        if not idx or kind in ("sum", "mean"):
+            out.append(None)
+        elif kind == "first":
+            out.append(strings[int(groups.first[g])])
+        elif kind == "last":
+            out.append(strings[idx[-1]])
+        elif kind == "n_unique":
+            out.append(len({strings[i] for i in idx}))
+        elif kind in ("min", "max"):
+            acc = None
+            for i in idx:
+                v = strings[i]
+                if v is None:
+                    continue
+                if acc is None:
+                    acc = v
+                elif kind == "min":
+                    acc = acc if as_b(acc) < as_b(v) else v
+                else:
+                    acc = acc if as_b(acc) > as_b(v) else v
+            out.append(acc)
+        else:
+            raise ValueError(kind)
+    return out
+
+
 def hash_join(left: Column, right: Column, how: str = "inner"):
     """orc_hash_join: (left_idx, right_idx) u32 arrays in the reference's pair order; right_idx 0xFFFFFFFF = no match (left join)."""
     h = {"inner": 0, "left": 1, "semi": 2, "anti": 3, "outer": 4}[how]

@@ -95,7 +95,7 @@ class DataFrame:
             data = {}
         if isinstance(data, dict):
             for name, v in data.items():
-                self._add(v if isinstance(v, Column) else self._make(name, v), name)
+                self._add(v if isinstance(v, Column) or hasattr(v, "struct") or hasattr(v, "chunks") else self._make(name, v), name)
         else:
             for c in data:
                 self._add(c, c.name)
@@ -105,7 +105,7 @@ class DataFrame:
         if isinstance(v, tuple):  # (values, valid_mask)
             return Column(name, v[0], v[1])
         if isinstance(v, list):
-            if any(isinstance(x, (str, bytes)) for x in v):  # a Utf8 column (group-by key only: strings.py)
+            if any(isinstance(x, (str, bytes)) for x in v):  # a Utf8 column (strings.py: a key, or a value under min / max / first / last)
                 from .strings import Utf8Column
 
                 return Utf8Column.from_list(name, v)
@@ -497,16 +497,15 @@ def _execute(df: DataFrame, by: list[str], exprs: list[Expr], maintain_order: bo
     dicts = {}
     for i, k in enumerate(keys):  # Utf8 keys: dense codes + dictionary on the device (into_groups.rs:232-290), encoded once per column
         if type(k).__name__ == "Utf8Column":
-            from .strings import encode
+            from .strings import codes_of
 
-            if getattr(k, "_encoded", None) is None:
-                k._encoded = encode(k)
-            keys[i] = k._encoded
-            dicts[i] = k._encoded.dictionary
+            keys[i] = codes_of(k)
+            dicts[i] = keys[i].dictionary
     vals: list[Column] = []
     index: dict[str, int] = {}
     aggs: list[tuple[int, int]] = []
     names = list(by)
+    str_outs: dict[int, object] = {}  # output position -> how a string column's aggregate is decoded
     for e in exprs:
         if e.agg is None:
             raise _ffi.ComputeError(1, "only col(x).sum/mean/min/max/count and count() run on the accelerated path")
@@ -514,12 +513,26 @@ def _execute(df: DataFrame, by: list[str], exprs: list[Expr], maintain_order: bo
             aggs.append((-1, _ffi.AGG_COUNT))
         else:
             c = df.get_column(e.column)
+            slot, kind = e.column, e.agg
             if type(c).__name__ == "Utf8Column":
-                raise _ffi.PlHipError(4, f"aggregating the string column {e.column!r} is not on the accelerated path")
-            if e.column not in index:
-                index[e.column] = len(vals)
+                # a string VALUE column (Utf8Chunked::agg_min / agg_max, aggregations/utf8.rs:21-142): the strings are ranked in byte
+                # order once (strings.ranks_of: encode on the device, order the dictionary, code -> rank on the device) and the fused
+                # query takes min / max of the u32 ranks; nulls are skipped, an all-null group yields null.  sum / mean of strings
+                # are full-null columns in the reference (dispatch.rs:126,177; its test_streaming_group_by_types: str_sum = [None])
+                from .strings import codes_of, ranks_of
+
+                if e.agg in ("min", "max"):
+                    c, slot = ranks_of(c), e.column + "\0rank"
+                    str_outs[len(names)] = c
+                else:
+                    c, slot = codes_of(c), e.column + "\0code"
+                    if e.agg in ("sum", "mean"):
+                        kind = "count"
+                        str_outs[len(names)] = None
+            if slot not in index:
+                index[slot] = len(vals)
                 vals.append(c)
-            aggs.append((index[e.column], _ffi.AGG_NAMES[e.agg]))
+            aggs.append((index[slot], _ffi.AGG_NAMES[kind]))
         if e.output_name in names:
             raise _ffi.PlHipError(6, f"column with name {e.output_name!r} has more than one occurrence")  # DuplicateError
         names.append(e.output_name)
@@ -543,6 +556,10 @@ def _execute(df: DataFrame, by: list[str], exprs: list[Expr], maintain_order: bo
         host = [_host_column(nm, cs) for nm, cs in zip(names, cols)]
     finally:
         _ffi.lib().plhip_result_free(handle)
+    for i, r in str_outs.items():  # string aggregates: ranks back to strings; sum / mean of strings: all null
+        from .strings import DecodedColumn
+
+        host[i] = DecodedColumn(names[i], [None] * len(host[i]) if r is None else r.decode(host[i].to_numpy(), host[i].valid_mask()))
     for i, k in enumerate(keys):  # a dictionary-encoded key read from a file: its codes back to the categories
         cats = getattr(k, "dictionary", None)
         if isinstance(cats, list) and i not in dicts:
@@ -600,6 +617,10 @@ def group_tuples(keys: Sequence[Column], sorted_: bool = False, location: int = 
     """IntoGroupsProxy::group_tuples (into_groups.rs:12-19) / group_by_threaded_multiple_keys_flat
     (hashing.rs:380-468) through plhip_group_tuples."""
     keys = [k.rechunk() if hasattr(k, "rechunk") else k for k in keys]  # (a reader's chunked column: one chunk for this seam)
+    if any(type(k).__name__ == "Utf8Column" for k in keys):  # string keys group by their codes (into_groups.rs:232-290)
+        from .strings import codes_of
+
+        keys = [codes_of(k) if type(k).__name__ == "Utf8Column" else k for k in keys]
     karr = (_ffi.ColumnStruct * max(1, len(keys)))(*[k.struct() for k in keys])
     h = C.c_void_p()
     _ffi.check(_ffi.lib().plhip_group_tuples(karr, len(keys), int(sorted_), location, C.byref(h)))
@@ -629,6 +650,27 @@ def agg_groups(values: Column | None, kind: str, groups: Groups, ddof: int = 1) 
     h = C.c_void_p()
     if values is not None and hasattr(values, "rechunk"):
         values = values.rechunk()
+    if type(values).__name__ == "Utf8Column":
+        # a string column over the groups: first / last are the codes at the groups' first / last rows (agg_first / agg_last,
+        # dispatch.rs:48-78,182-212), min / max those of the byte-order ranks (utf8.rs:21-142), decoded on the way out; count and
+        # n_unique are numbers and run on the codes (equal strings <=> equal codes)
+        from .strings import DecodedColumn, codes_of, ranks_of
+
+        if kind in ("first", "last"):
+            codes = codes_of(values)
+            out = agg_groups(codes, kind, groups)
+            return DecodedColumn(f"{values.name}_{kind}", codes.dictionary.decode(out.to_numpy(), out.valid_mask()))
+        if kind in ("min", "max"):
+            ranks = ranks_of(values)
+            out = agg_groups(ranks, kind, groups)
+            return DecodedColumn(f"{values.name}_{kind}", ranks.decode(out.to_numpy(), out.valid_mask()))
+        if kind in ("count", "n_unique"):
+            out = agg_groups(codes_of(values), kind, groups)
+            out.name = f"{values.name}_{kind}"
+            return out
+        if kind in ("sum", "mean"):  # full-null columns in the reference (dispatch.rs:126,177)
+            return DecodedColumn(f"{values.name}_{kind}", [None] * groups.n_groups)
+        raise _ffi.PlHipError(4, f"{kind} of the string column {values.name!r} is not on the accelerated path")
     vs = C.byref(values.struct()) if values is not None else None
     code = _ffi.AGG_NAMES[kind] if kind in _ffi.AGG_NAMES else _ffi.AGG_GROUPS_ONLY[kind]
     _ffi.check(L.plhip_agg_groups(vs, code, groups._h, (int(ddof) & 0xFF) << 8, C.byref(h)))

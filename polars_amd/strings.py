@@ -136,6 +136,67 @@ def encode(col: Utf8Column) -> CodesColumn:
     return CodesColumn(col.name, cs, Dictionary(handle))
 
 
+def codes_of(col: Utf8Column) -> CodesColumn:
+    """The column's codes, encoded once per column object (a frame that aggregates a string column twice pays for one encode)."""
+    if getattr(col, "_encoded", None) is None:
+        col._encoded = encode(col)
+    return col._encoded
+
+
+class RanksColumn(Column):
+    """u32 per row: the position of the row's string among the column's DISTINCT strings in byte order (Rust's `str` Ord, which
+    Utf8Chunked::agg_min / agg_max fold with, aggregations/utf8.rs:48,110) -- min / max of the strings are min / max of the ranks.
+    Device memory of a plhip_take result; the validity is the codes' (owned by the Dictionary, kept alive through `codes`)."""
+
+    def __init__(self, name: str, handle, cs: _ffi.ColumnStruct, codes: CodesColumn, ordered: list):
+        self.name = name
+        self.sorted_flag = None
+        self.n_categories = None
+        self._h, self.codes, self.ordered = handle, codes, ordered
+        self.location = _ffi.DEVICE
+        self.dtype = _ffi.U32
+        self._ptr, self._vptr = cs.values, codes._vptr
+        self.values = None
+        self.validity = None if not codes._vptr else True
+        self.offset, self.length = 0, int(codes.length)
+
+    def decode(self, ranks: np.ndarray, valid: np.ndarray | None = None) -> list:
+        return [self.ordered[int(r)] if valid is None or valid[i] else None for i, r in enumerate(ranks)]
+
+    def __del__(self):
+        try:
+            if self._h:
+                _ffi.lib().plhip_result_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def ranks_of(col: Utf8Column) -> RanksColumn:
+    """Encodes the column (plhip_utf8_encode), orders its dictionary -- G distinct strings, on the host -- and maps every row's code to
+    its string's rank ON THE DEVICE (plhip_take of the G-entry rank table with the device-resident codes as indices: the codes are the
+    library's own group numbers, all < G, null rows included).  Cached on the column object."""
+    if getattr(col, "_ranks", None) is not None:
+        return col._ranks
+    codes = codes_of(col)
+    strs = codes.dictionary.strings()
+    order = sorted((i for i, s in enumerate(strs) if s is not None), key=lambda i: strs[i].encode())
+    table = np.zeros(max(len(strs), 1), np.uint32)
+    table[order] = np.arange(len(order), dtype=np.uint32)
+    ordered = [strs[i] for i in order]
+    L = _ffi.lib()
+    h, cs = C.c_void_p(), _ffi.ColumnStruct()
+    if codes.length == 0:  # nothing to gather
+        col._ranks = Column(col.name, np.empty(0, np.uint32))
+        col._ranks.ordered, col._ranks.decode = ordered, (lambda r, v=None: [])
+        return col._ranks
+    src = (_ffi.ColumnStruct * 1)(Column("rank", table).struct())
+    _ffi.check(L.plhip_take(src, 1, codes._ptr, codes.length, _ffi.DEVICE, _ffi.FLAG_OUTPUT_DEVICE, C.byref(h)))
+    _ffi.check(L.plhip_result_column(h, 0, C.byref(cs)))
+    col._ranks = RanksColumn(col.name, h, cs, codes, ordered)
+    return col._ranks
+
+
 class DecodedColumn:
     """A result key column of strings (what the frame shows for a Utf8 key)."""
 
