@@ -51,8 +51,41 @@ class Expr:
     def count(self) -> "Expr":
         return self._with("count")
 
+    # aggregations the reference evaluates over the GroupsProxy (AggregationExpr::evaluate_on_groups, aggregation.rs:44-258): they
+    # run through the CSR seams (plhip_group_tuples + plhip_agg_groups), as db-benchmark's q6 does (median(v3), std(v3) by id4, id5)
+    def first(self) -> "Expr":
+        return self._with("first")
+
+    def last(self) -> "Expr":
+        return self._with("last")
+
+    def median(self) -> "Expr":
+        return self._with("median")
+
+    def n_unique(self) -> "Expr":
+        return self._with("n_unique")
+
+    def std(self, ddof: int = 1) -> "Expr":
+        e = self._with("std")
+        e.ddof = int(ddof)
+        return e
+
+    def var(self, ddof: int = 1) -> "Expr":
+        e = self._with("var")
+        e.ddof = int(ddof)
+        return e
+
+    def quantile(self, quantile: float, interpolation: str = "nearest") -> "Expr":
+        e = self._with("quantile")
+        e.q, e.interpolation = float(quantile), interpolation
+        return e
+
+    ddof, q, interpolation = 1, 0.5, "nearest"
+
     def alias(self, name: str) -> "Expr":
-        return Expr(self.column, self.agg, name)
+        e = Expr(self.column, self.agg, name)
+        e.ddof, e.q, e.interpolation = self.ddof, self.q, self.interpolation
+        return e
 
     @property
     def output_name(self) -> str:
@@ -493,6 +526,8 @@ def _execute(df: DataFrame, by: list[str], exprs: list[Expr], maintain_order: bo
     """group_by_helper (crates/polars-lazy/src/physical_plan/executors/group_by.rs:57-95): keys then aggs."""
     if not by:
         raise _ffi.ComputeError(1, "at least one key is required in a group_by operation")
+    if any(e.agg in _TWO_STEP_AGGS for e in exprs):
+        return _execute_over_groups(df, by, exprs, maintain_order, slice_)
     keys = [df.get_column(n) for n in by]
     dicts = {}
     for i, k in enumerate(keys):  # Utf8 keys: dense codes + dictionary on the device (into_groups.rs:232-290), encoded once per column
@@ -572,6 +607,61 @@ def _execute(df: DataFrame, by: list[str], exprs: list[Expr], maintain_order: bo
 
         host[i] = DecodedColumn(names[i], d.decode(host[i].to_numpy(), host[i].valid_mask()))
     return DataFrame(host)
+
+
+_TWO_STEP_AGGS = ("first", "last", "median", "n_unique", "std", "var", "quantile")
+
+
+def _slice_rows(c, offset: int, length: int):
+    """A result column's rows [offset, offset + length) with the reference's slice rules (negative offsets count from the end,
+    out-of-range parts are dropped: slice_offsets, crates/polars-core/src/utils/mod.rs)."""
+    n = len(c)
+    if offset < 0:
+        back = min(-offset, n)
+        start, ln = n - back, min(length, back)
+    else:
+        start = min(offset, n)
+        ln = min(length, n - start)
+    if type(c).__name__ == "DecodedColumn":
+        from .strings import DecodedColumn
+
+        return DecodedColumn(c.name, c.to_list()[start:start + ln])
+    m = c.valid_mask()
+    return Column(c.name, c.to_numpy()[start:start + ln].copy(), None if m is None else m[start:start + ln].copy())
+
+
+def _execute_over_groups(df: DataFrame, by: list[str], exprs: list[Expr], maintain_order: bool, slice_=None) -> DataFrame:
+    """A query with an aggregation that has no fused accumulator (first / last / median / n_unique / std / var / quantile): the
+    reference's general route -- the GroupsProxy once, then every expression over it (group_by_helper, executors/group_by.rs:57-95
+    with AggregationExpr::evaluate_on_groups, aggregation.rs:44-258).  Keys are the key columns at the groups' first rows
+    (keys_sliced, group_by/mod.rs:250-297).  The CSR stays in HBM when the key columns are there."""
+    keys = [df.get_column(n) for n in by]
+    on_dev = all(getattr(k, "location", _ffi.HOST) == _ffi.DEVICE for k in keys)
+    g = group_tuples(keys, maintain_order, _ffi.DEVICE if on_dev else _ffi.HOST)
+    try:
+        cols, names = [], list(by)
+        for k, n in zip(keys, by):
+            c = agg_groups(k, "first", g)
+            c.name = n
+            cols.append(c)
+        for e in exprs:
+            if e.agg is None:
+                raise _ffi.ComputeError(1, "every expression of agg() needs an aggregation on the accelerated path")
+            if e.output_name in names:
+                raise _ffi.PlHipError(6, f"column with name {e.output_name!r} has more than one occurrence")  # DuplicateError
+            names.append(e.output_name)
+            v = None if e.column is None else df.get_column(e.column)
+            if e.agg == "quantile":
+                c = agg_groups_quantile(v, e.q, g, e.interpolation)
+            else:
+                c = agg_groups(v, e.agg, g, ddof=e.ddof)
+            c.name = e.output_name
+            cols.append(c)
+    finally:
+        g.close()
+    if slice_ is not None:
+        cols = [_slice_rows(c, int(slice_[0]), int(slice_[1])) for c in cols]
+    return DataFrame(cols)
 
 
 # ---------------------------------------------------------------------------------------------------
