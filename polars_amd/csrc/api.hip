@@ -344,6 +344,59 @@ struct DevPool {
   }
 };
 DevPool g_pool;
+
+// Host-resident result buffers (PLHIP_HOST output).  A large frame copied into freshly malloc'ed pageable memory pays a page fault per
+// 4 KB and the runtime's staged copy -- measured on the reference harness's q10 (1e7 groups x 8 columns = 360 MB): 90 ms, 4 GB/s,
+// against 1.7 ms of kernels.  Buffers of 1 MiB and more are therefore page-locked (hipHostMalloc) and recycled: the copy is one DMA
+// at the link's rate and the pages are touched once per process, not once per query.  Smaller buffers stay malloc'ed (cap == 0).
+// PLHIP_NO_PINNED_RESULTS=1 switches it off; plhip_release_workspace hands the pooled buffers back.
+struct HostPool {
+  struct Entry { size_t cap; void *p; };
+  std::mutex mu;
+  std::vector<Entry> free_list;
+  size_t pooled = 0;
+  static constexpr size_t PIN_FROM = (size_t)1 << 20, KEEP_MAX = (size_t)2 << 30;
+  void *get(size_t bytes, size_t *cap) {
+    *cap = 0;
+    static const bool off = getenv("PLHIP_NO_PINNED_RESULTS") != nullptr;
+    if (bytes < PIN_FROM || off) return malloc(bytes ? bytes : 8);
+    const size_t c = DevPool::round_up(bytes);
+    {
+      std::lock_guard<std::mutex> g(mu);
+      for (size_t i = 0; i < free_list.size(); i++)
+        if (free_list[i].cap == c) {
+          void *p = free_list[i].p;
+          pooled -= c;
+          free_list[i] = free_list.back(); free_list.pop_back();
+          *cap = c;
+          return p;
+        }
+    }
+    void *p = nullptr;
+    if (hipHostMalloc(&p, c, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return malloc(bytes); } // (no pinned memory left: pageable)
+    *cap = c;
+    return p;
+  }
+  void put(void *p, size_t cap) {
+    if (!p) return;
+    if (!cap) { free(p); return; }
+    {
+      std::lock_guard<std::mutex> g(mu);
+      if (pooled + cap <= KEEP_MAX && free_list.size() < 64) { free_list.push_back(Entry{cap, p}); pooled += cap; return; }
+    }
+    (void)hipHostFree(p);
+  }
+  void trim() {
+    std::vector<void *> drop;
+    {
+      std::lock_guard<std::mutex> g(mu);
+      for (auto &e : free_list) drop.push_back(e.p);
+      free_list.clear(); pooled = 0;
+    }
+    for (void *q : drop) (void)hipHostFree(q);
+  }
+};
+HostPool g_hpool;
 } // namespace
 
 struct plhip_result {
@@ -360,14 +413,14 @@ struct plhip_result {
       if (on_device) {
         if (c.vcap) g_pool.put(device, c.values, c.vcap, pending); else if (c.values) hipFree(c.values);
         if (c.bcap) g_pool.put(device, c.validity, c.bcap, pending); else if (c.validity) hipFree(c.validity);
-      } else { free(c.values); free(c.validity); }
+      } else { g_hpool.put(c.values, c.vcap); g_hpool.put(c.validity, c.bcap); } // (host: caps are the host pool's, 0 = malloc)
     }
   }
 };
 
 struct plhip_groups {
   uint32_t *first = nullptr, *offsets = nullptr, *indices = nullptr;
-  size_t cap_first = 0, cap_offsets = 0, cap_indices = 0; // != 0: the device buffer came from the pool and goes back to it
+  size_t cap_first = 0, cap_offsets = 0, cap_indices = 0; // != 0: the buffer came from the (device / host) pool and goes back to it
   int device = 0;
   int64_t n_groups = 0, n_rows = 0;
   bool on_device = false;
@@ -376,7 +429,7 @@ struct plhip_groups {
       if (cap_first) g_pool.put(device, first, cap_first); else hipFree(first);
       if (cap_offsets) g_pool.put(device, offsets, cap_offsets); else hipFree(offsets);
       if (cap_indices) g_pool.put(device, indices, cap_indices); else hipFree(indices);
-    } else { free(first); free(offsets); free(indices); }
+    } else { g_hpool.put(first, cap_first); g_hpool.put(offsets, cap_offsets); g_hpool.put(indices, cap_indices); }
   }
 };
 
@@ -789,8 +842,8 @@ int estimate_groups(const Plan &P, uint64_t &g_est) {
   return PLHIP_OK;
 }
 
-int copy_out(const void *dev, size_t bytes, void **host) {
-  *host = malloc(bytes ? bytes : 8);
+int copy_out(const void *dev, size_t bytes, void **host, size_t *cap) { // *cap: what the owner hands back to g_hpool.put
+  *host = g_hpool.get(bytes, cap);
   if (!*host) return fail(PLHIP_ERR_OOM, "host allocation failed");
   if (bytes) HIP_TRY(hipMemcpy(*host, dev, bytes, hipMemcpyDeviceToHost));
   return PLHIP_OK;
@@ -909,8 +962,8 @@ int finish_result(plhip_result *R, uint64_t G, uint32_t flags, plhip_result_t **
     for (auto &col : R->cols) {
       ResultCol h;
       h.dtype = col.dtype;
-      rc = copy_out(col.values, col.dtype == PLHIP_BOOL ? (size_t)((G + 63) / 64) * 8 : (size_t)G * dtype_width(col.dtype), &h.values);
-      if (!rc && col.validity) rc = copy_out(col.validity, (G / 64 + 1) * 8, (void **)&h.validity);
+      rc = copy_out(col.values, col.dtype == PLHIP_BOOL ? (size_t)((G + 63) / 64) * 8 : (size_t)G * dtype_width(col.dtype), &h.values, &h.vcap);
+      if (!rc && col.validity) rc = copy_out(col.validity, (G / 64 + 1) * 8, (void **)&h.validity, &h.bcap);
       H->cols.push_back(h);
       if (rc) { delete R; delete H; return rc; }
     }
@@ -2173,6 +2226,7 @@ int32_t plhip_release_workspace(void) {
   resolve_timing();
   c.release_workspace();
   g_pool.trim(c.device);
+  g_hpool.trim();
   return PLHIP_OK;
 }
 
@@ -3383,9 +3437,9 @@ int32_t plhip_group_tuples(const plhip_column_t *keys, int32_t n_keys, int32_t s
     plhip_groups *H = new (std::nothrow) plhip_groups();
     if (!H) { delete Gp; return fail(PLHIP_ERR_OOM, "host allocation failed"); }
     H->n_groups = Gp->n_groups; H->n_rows = n; H->on_device = false;
-    rc = copy_out(Gp->first, (size_t)G * 4, (void **)&H->first);
-    if (!rc) rc = copy_out(Gp->offsets, ((size_t)G + 1) * 4, (void **)&H->offsets);
-    if (!rc) rc = copy_out(Gp->indices, (size_t)n * 4, (void **)&H->indices);
+    rc = copy_out(Gp->first, (size_t)G * 4, (void **)&H->first, &H->cap_first);
+    if (!rc) rc = copy_out(Gp->offsets, ((size_t)G + 1) * 4, (void **)&H->offsets, &H->cap_offsets);
+    if (!rc) rc = copy_out(Gp->indices, (size_t)n * 4, (void **)&H->indices, &H->cap_indices);
     delete Gp;
     if (rc) { delete H; return rc; }
     Gp = H;

@@ -502,7 +502,31 @@ def group_by_agg_chunked_raw(keys: Sequence[Sequence[Column]], values: Sequence[
     return handle, cols
 
 
-def _host_column(name: str, cs: _ffi.ColumnStruct) -> Column:
+class _ResultOwner:
+    """Keeps a host-resident plhip_result_t alive for as long as any array that aliases its buffers: the frame `collect()` returns
+    IS the library's result (a DataFrame owns its Series' buffers the same way); plhip_result_free runs when the last view is gone."""
+
+    def __init__(self, handle):
+        self.h = handle
+
+    def __del__(self):
+        try:
+            if self.h:
+                _ffi.lib().plhip_result_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def _bytes_view(ptr, nbytes: int, owner) -> np.ndarray:
+    buf = (C.c_uint8 * nbytes).from_address(ptr)
+    buf._owner = owner  # numpy's base chain holds `buf`, `buf` holds the result
+    return np.frombuffer(buf, dtype=np.uint8)
+
+
+def _host_column(name: str, cs: _ffi.ColumnStruct, owner=None) -> Column:
+    """A host-resident result column.  Without `owner` the buffers are copied (the caller frees the result right away); with one
+    the column aliases them (no second copy of a large frame: q10's 1e7 groups x 8 columns)."""
     n, off = cs.length, cs.offset  # a sliced frame's columns carry an Arrow offset
     dt = _ffi.code_np_dtype(cs.dtype)
     if n == 0:
@@ -510,6 +534,8 @@ def _host_column(name: str, cs: _ffi.ColumnStruct) -> Column:
     if cs.dtype == _ffi.BOOL:  # a bitmap: one bit per row
         bits = np.ctypeslib.as_array(C.cast(cs.values, C.POINTER(C.c_uint8)), shape=((off + n + 7) // 8,))
         vals = np.unpackbits(bits, bitorder="little")[off:off + n].astype(np.bool_)
+    elif owner is not None:
+        vals = _bytes_view(cs.values, (off + n) * dt.itemsize, owner).view(dt)[off:]
     else:
         vals = np.ctypeslib.as_array(C.cast(cs.values, C.POINTER(C.c_uint8)), shape=((off + n) * dt.itemsize,)).view(dt)[off:].copy()
     validity = None
@@ -587,10 +613,9 @@ def _execute(df: DataFrame, by: list[str], exprs: list[Expr], maintain_order: bo
         handle, cols = group_by_agg_chunked_raw([as_chunks(k) for k in keys], [as_chunks(v) for v in vals], aggs, flags, hint, slice_=slice_)
     else:
         handle, cols = group_by_agg_raw(keys, vals, aggs, flags, hint, slice_=slice_)
-    try:
-        host = [_host_column(nm, cs) for nm, cs in zip(names, cols)]
-    finally:
-        _ffi.lib().plhip_result_free(handle)
+    owner = _ResultOwner(handle)  # (freed with the last column that aliases it, or right here when a column cannot be made)
+    host = [_host_column(nm, cs, owner) for nm, cs in zip(names, cols)]
+    del owner
     for i, r in str_outs.items():  # string aggregates: ranks back to strings; sum / mean of strings: all null
         from .strings import DecodedColumn
 
