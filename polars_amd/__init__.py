@@ -9,6 +9,6 @@ from .frame import (DataFrame, Expr, GroupBy, Groups, LazyFrame, agg_groups, col
                     group_tuples,
                     last_kernel_breakdown, last_kernel_ms, last_strategy, set_strategy)
 from .frame import max_ as max, mean_ as mean, min_ as min, sum_ as sum  # noqa: F401,A001
-from .io import ChunkedColumn, from_arrow, read_ipc, read_parquet, scan_ipc, scan_parquet  # noqa: F401
+from .io import ChunkedColumn, from_arrow, read_csv, read_ipc, read_parquet, scan_ipc, scan_parquet  # noqa: F401
 
 __version__ = "0.1.0"

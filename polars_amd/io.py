@@ -172,6 +172,26 @@ def read_parquet(path, columns=None):
     return from_arrow(pq.read_table(str(path), columns=None if columns is None else list(columns)))
 
 
+def read_csv(path, columns=None, dtypes=None, categorical=None, null_values=("", "NA")):
+    """CSV file -> DataFrame of chunked columns, as the reference's harness starts (`pl.read_csv("G1_1e7_1e2_5_0.csv", dtypes={..})`
+    followed by `.cast(pl.Categorical)` of id1 .. id3, run_h2oai_benchmark.py:21-35).  Parsing is pyarrow's, on the host (one chunk
+    per block it read); `dtypes` maps column names to numpy dtypes (the harness's Int32 / Float64 overrides), `categorical` names
+    the string columns to dictionary-encode -- they reach the group-by as u32 codes under one dictionary and take the dense-code
+    path, as a Categorical does."""
+    import pyarrow as pa
+    import pyarrow.compute as pc
+    import pyarrow.csv as pcsv
+
+    types = {n: pa.from_numpy_dtype(np.dtype(t)) for n, t in (dtypes or {}).items()}
+    conv = pcsv.ConvertOptions(column_types=types, null_values=list(null_values), strings_can_be_null=True,
+                               include_columns=None if columns is None else list(columns))
+    table = pcsv.read_csv(str(path), convert_options=conv)
+    for n in categorical or []:
+        i = table.column_names.index(n)
+        table = table.set_column(i, n, pc.dictionary_encode(table.column(n)))
+    return from_arrow(table)
+
+
 class _ScanFrame:
     """What `scan_ipc` / `scan_parquet` hold until `collect()`: the file's schema and a loader.  A column is read when the query asks
     for it (`get_column`), so only the columns a group-by names ever leave the file -- the effect of the reference's projection

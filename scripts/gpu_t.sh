@@ -1,11 +1,2 @@
 #!/bin/bash
-bash scripts/gpu_tests.sh 1000 || exit 1
-timeout -k 10 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | grep -v amdgpu.ids | tail -2 || exit 1
-timeout -k 10 500 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_r3g.json 2> gpurun_out/bench_r3g.err || { tail -5 gpurun_out/bench_r3g.err; exit 1; }
-python - <<'PY'
-import json
-d = json.loads(open("gpurun_out/bench_r3g.json").read().strip().splitlines()[-1])
-print(d["ms_per_step"], d["roofline"]["frac"], d["parity"]["ok"] if isinstance(d.get("parity"), dict) else d.get("parity"))
-for k, v in d.get("configs", {}).items():
-    print(k, v.get("ms_per_step"), v.get("parity"))
-PY
+timeout -k 10 400 python -u -m pytest tests/test_io_gpu.py -x -q --timeout 120 --timeout-method thread 2>&1 | grep -v amdgpu.ids | tail -40

@@ -129,3 +129,50 @@ def test_scan_reads_only_the_columns_the_query_names(oracle, tmp_path):
         head = lf.group_by("k2", maintain_order=True).agg(pa.col("w").mean().alias("m")).head(3).collect()
         assert head.height == 3
     assert pa.scan_parquet(p_pq).collect().height == 120_000
+
+
+def test_read_csv_as_the_harness_starts(oracle, tmp_path):
+    """run_h2oai_benchmark.py:21-35: read_csv with dtype overrides, id1 .. id3 cast to Categorical, then the queries (q1, q3, q6 here) --
+    on a small table of the generator's shape with NAs (empty fields), written as CSV."""
+    rng = np.random.default_rng(8)
+    n, K = 60_000, 20
+    ids = {c: rng.integers(1, K + 1, n) for c in ("id1", "id2", "id4", "id5")}
+    ids["id3"], ids["id6"] = rng.integers(1, n // K + 1, n), rng.integers(1, n // K + 1, n)
+    v1, v2, v3 = rng.integers(1, 6, n), rng.integers(1, 16, n), np.round(rng.uniform(0, 100, n), 6)
+    na = {c: rng.random(n) < 0.05 for c in ("id1", "id3", "id4", "v1", "v3")}
+    path = tmp_path / "G1.csv"
+    with open(path, "w") as f:
+        f.write("id1,id2,id3,id4,id5,id6,v1,v2,v3\n")
+        cell = lambda c, i, txt: "" if c in na and na[c][i] else txt
+        for i in range(n):
+            f.write(",".join([cell("id1", i, f"id{ids['id1'][i]:03d}"), f"id{ids['id2'][i]:03d}", cell("id3", i, f"id{ids['id3'][i]:010d}"),
+                              cell("id4", i, str(ids["id4"][i])), str(ids["id5"][i]), str(ids["id6"][i]),
+                              cell("v1", i, str(v1[i])), str(v2[i]), cell("v3", i, repr(float(v3[i])))]) + "\n")
+    df = pa.read_csv(path, dtypes={"id4": np.int32, "id5": np.int32, "id6": np.int32, "v1": np.int32, "v2": np.int32, "v3": np.float64},
+                     categorical=["id1", "id2", "id3"])
+    assert df.height == n and df["id1"].dictionary is not None and df["v1"].dtype == _ffi.I32
+    x = df.lazy()
+    col = lambda name, arr, dt: Column(name, arr.astype(dt), None if name not in na else ~na[name])
+    # q1: sum(v1) by id1 -- the result shows the categories, the null key is one group
+    out = x.group_by("id1").agg(pa.col("v1").sum().alias("v1_sum")).collect()
+    want, _ = oracle.group_by_agg([col("id1", ids["id1"], np.int32)], [col("v1", v1, np.int32)], [(0, "sum")])
+    got = dict(zip(out["id1"].to_list(), out["v1_sum"].to_list()))
+    exp = {(f"id{int(k):03d}" if ok else None): int(s) for k, ok, s in zip(want[0][1], want[0][2], want[1][1])}
+    assert got == exp
+    # q3: sum(v1), mean(v3) by id3
+    out = x.group_by("id3").agg([pa.col("v1").sum().alias("v1_sum"), pa.col("v3").mean().alias("v3_mean")]).collect()
+    want, _ = oracle.group_by_agg([col("id3", ids["id3"], np.int64)], [col("v1", v1, np.int32), col("v3", v3, np.float64)], [(0, "sum"), (1, "mean")])
+    exp = {(f"id{int(k):010d}" if ok else None): (int(s), (float(m) if mok else None))
+           for k, ok, s, m, mok in zip(want[0][1], want[0][2], want[1][1], want[2][1], want[2][2])}
+    got = dict(zip(out["id3"].to_list(), zip(out["v1_sum"].to_list(), out["v3_mean"].to_list())))
+    assert got.keys() == exp.keys()
+    for k_, (s_, m_) in got.items():
+        assert s_ == exp[k_][0] and ((m_ is None) == (exp[k_][1] is None)) and (m_ is None or abs(m_ - exp[k_][1]) <= 1e-12 * abs(exp[k_][1])), k_
+    # q6: median(v3), std(v3) by id4, id5 -- over the CSR seams
+    out = x.group_by(["id4", "id5"], maintain_order=True).agg([pa.col("v3").median().alias("v3_median"), pa.col("v3").std().alias("v3_std")]).collect()
+    g = oracle.Groups([col("id4", ids["id4"], np.int32), col("id5", ids["id5"], np.int32)], True)
+    for name, kind in (("v3_median", "median"), ("v3_std", "std")):
+        wv, wm = oracle.agg_ext(col("v3", v3, np.float64), kind, g, 1)
+        gv, gm = out[name].to_numpy(), out[name].valid_mask()
+        gm = np.ones(len(gv), bool) if gm is None else gm
+        assert gm.tolist() == wm.tolist() and np.allclose(gv[gm], wv[wm], rtol=1e-11, atol=0), kind
