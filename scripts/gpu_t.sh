@@ -1,2 +1,2 @@
 #!/bin/bash
-timeout -k 10 400 python -u -m pytest tests/test_io_gpu.py -x -q --timeout 120 --timeout-method thread 2>&1 | grep -v amdgpu.ids | tail -40
+timeout -k 10 400 python -u -m pytest tests/test_edges_gpu.py -x -q --timeout 300 --timeout-method thread -k "pinned_buffers or release_workspace" 2>&1 | grep -v amdgpu.ids | tail -30

@@ -160,6 +160,51 @@ def test_release_workspace_then_query_again(oracle):
         assert _ffi.lib().plhip_pooled_buffers(0) == 0
 
 
+def test_large_host_results_live_in_recycled_pinned_buffers(oracle):
+    """Host-resident results of 1 MiB and more come from the page-locked pool (api.hip HostPool): same frames as ever, across
+    reuse of the buffers by results of other sizes, a frame kept alive while later queries run, plhip_release_workspace in between,
+    and with the pool switched off (PLHIP_NO_PINNED_RESULTS=1, a fresh process)."""
+    import os
+    import subprocess
+    import sys
+
+    rng = np.random.default_rng(12)
+    n = 1_500_000
+    k = rand_col(rng, "k", np.int64, n, card=400_000)  # ~4e5 groups x 8 B = 3 MB per column
+    v = rand_col(rng, "v", np.float64, n)
+    df = pa.DataFrame({"k": k, "v": v})
+    want, _ = oracle.group_by_agg([k], [v], [(0, "sum"), (0, "count")])
+    want = util.oracle_to_np(want)
+    kept = []
+    for rep in range(3):
+        out = df.group_by("k").agg([pa.col("v").sum().alias("s"), pa.col("v").count().alias("c")])
+        util.assert_frames_match(util.frame_to_np(out), want, 1, what=f"pass {rep}")
+        kept.append(out)  # (the frame aliases the library's buffers: it must stay intact while later results are made)
+        small = pa.DataFrame({"k": Column("k", k.to_numpy()[:300_000] % 7), "v": Column("v", v.to_numpy()[:300_000])}).group_by("k").agg(pa.col("v").count())
+        assert small.height == 7
+        if rep == 1:
+            _ffi.check(_ffi.lib().plhip_release_workspace())
+    for rep, out in enumerate(kept):
+        util.assert_frames_match(util.frame_to_np(out), want, 1, what=f"kept frame {rep}")
+    # the CSR in host memory: 6 MB of row indices from the same pool
+    g = pa.group_tuples([k], True)
+    g_o = oracle.Groups([k], True)
+    first, offsets, indices = g.buffers()
+    assert np.array_equal(first, g_o.first) and np.array_equal(offsets, g_o.offsets) and np.array_equal(indices, g_o.indices)
+    g.close()
+    del kept, out
+    code = ("import numpy as np, polars_amd as pa\n"
+            "rng = np.random.default_rng(1); n = 1_000_000\n"
+            "k = rng.integers(0, 300_000, n); v = rng.integers(0, 9, n)\n"
+            "out = pa.DataFrame({'k': k, 'v': v}).group_by('k').agg(pa.col('v').sum())\n"
+            "u, inv = np.unique(k, return_inverse=True); s = np.bincount(inv, weights=v).astype(np.int64)\n"
+            "o = np.argsort(out['k'].to_numpy()); assert np.array_equal(out['k'].to_numpy()[o], u) and np.array_equal(out['v'].to_numpy()[o], s)\n"
+            "print('ok')")
+    env = dict(os.environ, PLHIP_NO_PINNED_RESULTS="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
 def test_result_pool_is_keyed_by_device():
     """A freed device-resident frame goes to the pool of ITS device; another device's pool never sees it."""
     import torch
