@@ -954,19 +954,28 @@ namespace {
 // PLHIP_FLAG_OUTPUT_DEVICE is set.
 int finish_result(plhip_result *R, uint64_t G, uint32_t flags, plhip_result_t **out) {
   Ctx &c = g_ctx;
-  int rc = PLHIP_OK;
   if (!(flags & PLHIP_FLAG_OUTPUT_DEVICE)) {
     plhip_result *H = new (std::nothrow) plhip_result();
     if (!H) { delete R; return fail(PLHIP_ERR_OOM, "host allocation failed"); }
     H->n_rows = R->n_rows; H->on_device = false; H->device = c.device;
+    // all columns' copies are queued, then waited for once: page-locked destinations (HostPool) let the copy engines overlap them
+    hipError_t e = settle_token(R->pending);
+    R->pending = nullptr;
     for (auto &col : R->cols) {
+      if (e != hipSuccess) break;
       ResultCol h;
       h.dtype = col.dtype;
-      rc = copy_out(col.values, col.dtype == PLHIP_BOOL ? (size_t)((G + 63) / 64) * 8 : (size_t)G * dtype_width(col.dtype), &h.values, &h.vcap);
-      if (!rc && col.validity) rc = copy_out(col.validity, (G / 64 + 1) * 8, (void **)&h.validity, &h.bcap);
+      const size_t vb = col.dtype == PLHIP_BOOL ? (size_t)((G + 63) / 64) * 8 : (size_t)G * dtype_width(col.dtype), bb = (size_t)(G / 64 + 1) * 8;
+      h.values = g_hpool.get(vb, &h.vcap);
+      if (col.validity) h.validity = (uint8_t *)g_hpool.get(bb, &h.bcap);
       H->cols.push_back(h);
-      if (rc) { delete R; delete H; return rc; }
+      if (!h.values || (col.validity && !h.validity)) { (void)hipStreamSynchronize(c.stream); delete R; delete H; return fail(PLHIP_ERR_OOM, "host allocation failed"); }
+      if (vb) e = hipMemcpyAsync(h.values, col.values, vb, hipMemcpyDeviceToHost, c.stream);
+      if (e == hipSuccess && col.validity) e = hipMemcpyAsync(h.validity, col.validity, bb, hipMemcpyDeviceToHost, c.stream);
     }
+    const hipError_t e2 = hipStreamSynchronize(c.stream); // (also on the error path: the host buffers go back to the pool below)
+    if (e == hipSuccess) e = e2;
+    if (e != hipSuccess) { delete R; delete H; return fail_hip(e, "result copy"); }
     delete R;
     R = H;
   }

@@ -1,2 +1,4 @@
 #!/bin/bash
-timeout -k 10 400 python -u -m pytest tests/test_edges_gpu.py -x -q --timeout 300 --timeout-method thread -k "pinned_buffers or release_workspace" 2>&1 | grep -v amdgpu.ids | tail -30
+bash scripts/gpu_tests.sh 1000 || exit 1
+timeout -k 10 300 python -u scripts/h2oai_harness.py --rows 10000000 > gpurun_out/harness_1e7.json 2> gpurun_out/harness_1e7.err; rc=$?
+grep -v amdgpu.ids gpurun_out/harness_1e7.err | tail -12; exit $rc
