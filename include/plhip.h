@@ -210,7 +210,7 @@ int32_t plhip_init(int32_t device_id);
  * what it needs.  The reference analogue is dropping the per-thread hash tables at the end of a query
  * (crates/polars-core/src/frame/group_by/hashing.rs:380-468 builds them per call); here they are kept between calls
  * because hipMalloc costs more than a small query.  Host-resident results (no PLHIP_FLAG_OUTPUT_DEVICE; plhip_group_tuples with
- * PLHIP_HOST) of 1 MiB and more live in page-locked buffers that are recycled the same way (up to 2 GiB per process; the copy out
+ * PLHIP_HOST) of 32 KiB and more live in page-locked buffers that are recycled the same way (up to 2 GiB per process; the copy out
  * of HBM is then one DMA at the link's rate): this call hands those back as well.  PLHIP_NO_PINNED_RESULTS=1 in the environment
  * keeps host results in plain malloc'ed memory. */
 int32_t plhip_release_workspace(void);

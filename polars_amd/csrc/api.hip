@@ -347,7 +347,7 @@ DevPool g_pool;
 
 // Host-resident result buffers (PLHIP_HOST output).  A large frame copied into freshly malloc'ed pageable memory pays a page fault per
 // 4 KB and the runtime's staged copy -- measured on the reference harness's q10 (1e7 groups x 8 columns = 360 MB): 90 ms, 4 GB/s,
-// against 1.7 ms of kernels.  Buffers of 1 MiB and more are therefore page-locked (hipHostMalloc) and recycled: the copy is one DMA
+// against 1.7 ms of kernels.  Buffers of 32 KiB and more are therefore page-locked (hipHostMalloc) and recycled: the copy is one DMA
 // at the link's rate and the pages are touched once per process, not once per query.  Smaller buffers stay malloc'ed (cap == 0).
 // PLHIP_NO_PINNED_RESULTS=1 switches it off; plhip_release_workspace hands the pooled buffers back.
 struct HostPool {
@@ -355,7 +355,7 @@ struct HostPool {
   std::mutex mu;
   std::vector<Entry> free_list;
   size_t pooled = 0;
-  static constexpr size_t PIN_FROM = (size_t)1 << 20, KEEP_MAX = (size_t)2 << 30;
+  static constexpr size_t PIN_FROM = (size_t)32 << 10, KEEP_MAX = (size_t)2 << 30;
   void *get(size_t bytes, size_t *cap) {
     *cap = 0;
     static const bool off = getenv("PLHIP_NO_PINNED_RESULTS") != nullptr;

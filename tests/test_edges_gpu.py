@@ -161,7 +161,7 @@ def test_release_workspace_then_query_again(oracle):
 
 
 def test_large_host_results_live_in_recycled_pinned_buffers(oracle):
-    """Host-resident results of 1 MiB and more come from the page-locked pool (api.hip HostPool): same frames as ever, across
+    """Host-resident results of 32 KiB and more come from the page-locked pool (api.hip HostPool): same frames as ever, across
     reuse of the buffers by results of other sizes, a frame kept alive while later queries run, plhip_release_workspace in between,
     and with the pool switched off (PLHIP_NO_PINNED_RESULTS=1, a fresh process)."""
     import os
