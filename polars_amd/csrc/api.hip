@@ -2006,6 +2006,9 @@ int run_two_level(Lowered &L, std::vector<DevCol> &dk, uint32_t flags, uint64_t 
       if (w == 8) { keymode1 = 2; kxor1 = dk[0].dtype == PLHIP_I64 ? 0x8000000000000000ull : 0ull; }
     }
     TileSortLevel1 S1{pstart, totals, np1, 0u};
+    // the level-1 copies hold n_pad rows: with the capacity stated the scatter places its runs through the partition-id array
+    // (and clamps every destination to it) instead of a binary search per element
+    if (!getenv("PLHIP_T2_SEARCH_SCATTER") && n_pad <= 0xFFFFFFFFull) S1.out_rows = (uint32_t)n_pad;
     launch_tile_sort(P, A, pbits1, n_tiles1, counts, keymode1, kxor1, key_bytes, c.stream, &S1, true);
   } else {
     launch_part_scatter(P, A, pbits1, tile_rows1, n_tiles1, counts, pstart, c.stream);

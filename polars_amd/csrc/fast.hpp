@@ -136,7 +136,8 @@ struct TileSortLevel1 {
   const uint32_t *part_rows;  // [np1]
   uint32_t np1, pshift;       // pshift: hash bits consumed by level 1
   uint32_t *hot_rows;         // level 2, may be nullptr: [np1 << pbits] zeroed; runs of at least hot_run rows are added to their leaf's word
-  uint32_t hot_run, pad;
+  uint32_t hot_run;
+  uint32_t out_rows;          // scatter variant, hash partitions: rows the output columns hold (0: unknown -> the binary-search placement)
   uint32_t *hot_any;          // single level, may be nullptr: set to 1 when any long run was seen
   // scatter variant only, range partitions of dense codes (dense_path.hip, k_dense_part_hist has the same function): range_gpr != 0
   // -> partition = min((key - range_bias) / range_gpr, range_np - 1) instead of hash bits (range_recip = ceil(2^32 / range_gpr))

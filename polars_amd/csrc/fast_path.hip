@@ -595,10 +595,11 @@ __global__ void __launch_bounds__(TS_BLOCK) k_tile_sort(Plan P, PartOut O, uint3
   if (!SCATTER && tid == 0) offs[(uint64_t)(np + 1) * n_tiles + tile] = nt;
   lds_barrier();
   uint32_t dest[TS_R]; // SCATTER: output row of sorted element i * TS_BLOCK + tid
-  if (SCATTER && L1.range_gpr) {
+  if (SCATTER && (L1.range_gpr || L1.out_rows)) {
     // which partition's run holds sorted position j: every row writes its partition at its sorted position (the binary search over
     // the run starts below -- nine dependent, bank-conflicting LDS reads per element -- was a fifth of the kernel at 491 range
-    // partitions: q3 at 3e8 rows 4.42 -> 3.97 ms)
+    // partitions: q3 at 3e8 rows 4.42 -> 3.97 ms).  Hash partitions take this placement when the host states the output's row
+    // capacity: the destination is then clamped to it, so whatever the placement computes stays inside the output columns.
 #pragma unroll
     for (int r = 0; r < TS_R; r++)
       if ((live >> r) & 1) {
@@ -607,10 +608,12 @@ __global__ void __launch_bounds__(TS_BLOCK) k_tile_sort(Plan P, PartOut O, uint3
         pid[pos[r]] = (uint16_t)(p < np ? p : np - 1u);
       }
     lds_barrier();
+    const uint32_t last_row = L1.out_rows ? L1.out_rows - 1u : 0xFFFFFFFFu;
 #pragma unroll
     for (int i = 0; i < TS_R; i++) {
       const uint32_t j = (uint32_t)i * TS_BLOCK + tid;
-      dest[i] = j < nt ? j + gdelta[pid[j]] : 0u;
+      const uint32_t d = j < nt ? j + gdelta[pid[j] & ((1u << TS_MAX_PBITS) - 1u)] : 0u;
+      dest[i] = d < last_row ? d : last_row;
     }
   } else {
 #pragma unroll
