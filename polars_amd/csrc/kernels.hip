@@ -276,13 +276,18 @@ DEVINL void mm_stream(const uint8_t *values, int64_t n_rows, uint64_t x, uint64_
   const mm_u32x4 *p = (const mm_u32x4 *)values;
   const int64_t nv = n_rows * W / 16; // whole vectors; the last rows are block 0's
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  for (; i + 3 * stride < nv; i += 4 * stride) {
-    const mm_u32x4 a = __builtin_nontemporal_load(p + i), b = __builtin_nontemporal_load(p + i + stride);
-    const mm_u32x4 c = __builtin_nontemporal_load(p + i + 2 * stride), d = __builtin_nontemporal_load(p + i + 3 * stride);
+  // a workgroup takes 4 * blockDim CONSECUTIVE vectors per trip (16 KB at 256 threads): a lane's four requests sit 4 KB apart.  (With
+  // the four a whole grid stride apart -- 4 MB at 1 024 workgroups -- config 3's three 800 MB key columns streamed at 4.9 TB/s, 492 us;
+  // an odd workgroup count 394 us, this shape 347 us = 6.9 TB/s; plain instead of non-temporal loads 443 us.)  Vectors
+  // [n_tiles * tile, nv) are left to the grid-stride loop below.
+  const int64_t tile = (int64_t)blockDim.x * 4, n_tiles = nv / tile;
+  for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const mm_u32x4 *q = p + t * tile + threadIdx.x; // the last one read is q[3 * blockDim.x] = p[(t + 1) * tile - blockDim.x + threadIdx.x], < nv
+    const mm_u32x4 a = __builtin_nontemporal_load(q), b = __builtin_nontemporal_load(q + blockDim.x);
+    const mm_u32x4 c = __builtin_nontemporal_load(q + 2 * blockDim.x), d = __builtin_nontemporal_load(q + 3 * blockDim.x);
     mm_fold_vec<W>(a, x, lo, hi); mm_fold_vec<W>(b, x, lo, hi); mm_fold_vec<W>(c, x, lo, hi); mm_fold_vec<W>(d, x, lo, hi);
   }
-  for (; i < nv; i += stride) mm_fold_vec<W>(p[i], x, lo, hi);
+  for (int64_t i = n_tiles * tile + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) mm_fold_vec<W>(p[i], x, lo, hi);
   if (blockIdx.x == 0) {
     const int64_t r = nv * (16 / W) + threadIdx.x;
     if (r < n_rows) mm_fold(W == 8 ? ((const uint64_t *)values)[r] ^ x : (uint64_t)(((const uint32_t *)values)[r] ^ (uint32_t)x), lo, hi);
@@ -358,7 +363,8 @@ size_t key_minmax_scratch_bytes(int n_keys) { return (size_t)n_keys * MM_GRID * 
 // partials: key_minmax_scratch_bytes(p.n_keys) bytes of scratch
 void launch_key_minmax(const Plan &p, uint64_t *minmax, uint64_t *partials, hipStream_t s, uint64_t *host_word) {
   int64_t blocks = (p.n_rows + 4095) / 4096;
-  int grid = (int)(blocks < 1 ? 1 : (blocks > MM_GRID ? MM_GRID : blocks));
+  // (an odd count once the column is long: the workgroups' trips are then not a power of two apart)
+  int grid = (int)(blocks < 1 ? 1 : (blocks > MM_GRID - 3 ? MM_GRID - 3 : blocks));
   hipLaunchKernelGGL(k_key_minmax, dim3(grid, p.n_keys), dim3(256), 0, s, p, partials);
   hipLaunchKernelGGL(k_key_minmax_final, dim3(p.n_keys), dim3(256), 0, s, partials, (uint32_t)grid, minmax, host_word);
 }

@@ -1,6 +1,7 @@
 // ubench.hip — hardware-rate microbenchmarks behind the design choices in DESIGN.md (development aid,
 // not part of libplhip.so).  Build: make -C scripts/ubench ; run on the GPU box: scripts/ubench/ubench <test>
 //   bw       streaming reads: 1..3 columns, dwordx4 loads, grid sweep
+//   mm       the key min / max pass over an 800 MB column: loop shapes x non-temporal loads x grid
 //   ldsatom  LDS atomic throughput by type and table size (random slots)
 //   gatom    global atomic throughput, random slots, by table size
 #include <hip/hip_runtime.h>
@@ -9,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <vector>
 
 #define CHECK(x)                                                                      \
@@ -78,6 +80,75 @@ static void test_bw() {
     }
     CHECK(hipFree(a)); CHECK(hipFree(b)); CHECK(hipFree(c)); CHECK(hipFree(out));
   }
+}
+
+// ---- mm: the key min / max pass (kernels.hip k_key_minmax) as loop shapes, 64-bit keys ------------------------------
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+struct MmArgs { const uint8_t *values; uint64_t pad[40]; int64_t n_rows; }; // (the pointer arrives inside a by-value struct, as in Plan)
+__device__ __forceinline__ void mmf(uint64_t v, uint64_t &lo, uint64_t &hi) { lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+__device__ __forceinline__ void mmv(const u32x4 &q, uint64_t &lo, uint64_t &hi) {
+  mmf((uint64_t)q.x | ((uint64_t)q.y << 32), lo, hi); mmf((uint64_t)q.z | ((uint64_t)q.w << 32), lo, hi);
+}
+// V: 0 = four requests a grid stride apart (round 2), 1 = four consecutive 4 KB pieces per workgroup trip, 2 = one request per trip,
+// 3 = eight consecutive pieces; NT: non-temporal loads
+template <int V, bool NT>
+__global__ void __launch_bounds__(256) k_mm(MmArgs A, uint64_t *out) {
+  const u32x4 *p = (const u32x4 *)A.values;
+  const int64_t nv = A.n_rows / 2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  uint64_t lo = ~0ull, hi = 0;
+  auto ld = [&](const u32x4 *q) { return NT ? __builtin_nontemporal_load(q) : *q; };
+  if (V == 0) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < nv; i += 4 * stride) {
+      const u32x4 a = ld(p + i), b = ld(p + i + stride), c = ld(p + i + 2 * stride), d = ld(p + i + 3 * stride);
+      mmv(a, lo, hi); mmv(b, lo, hi); mmv(c, lo, hi); mmv(d, lo, hi);
+    }
+    for (; i < nv; i += stride) mmv(p[i], lo, hi);
+  } else if (V == 1 || V == 3) {
+    constexpr int U = V == 1 ? 4 : 8;
+    const int64_t tile = (int64_t)blockDim.x * U, n_tiles = nv / tile;
+    for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+      const u32x4 *q = p + t * tile + threadIdx.x;
+      u32x4 x[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) x[u] = ld(q + u * blockDim.x);
+#pragma unroll
+      for (int u = 0; u < U; u++) mmv(x[u], lo, hi);
+    }
+    for (int64_t i = n_tiles * tile + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) mmv(p[i], lo, hi);
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) mmv(ld(p + i), lo, hi);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const uint64_t l2 = __shfl_xor(lo, off), h2 = __shfl_xor(hi, off);
+    lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi;
+  }
+  if ((threadIdx.x & 63) == 0) { out[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 2] = lo; out[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + 1] = hi; }
+}
+
+static void test_mm() {
+  hipStream_t s;
+  CHECK(hipStreamCreate(&s));
+  const size_t n = 100000000;
+  uint32_t *a; uint64_t *out;
+  CHECK(hipMalloc(&a, n * 8)); CHECK(hipMalloc(&out, 16384 * 4 * 16));
+  k_fill<<<4096, 256, 0, s>>>(a, 2 * n, 1, 0);
+  MmArgs A{}; A.values = (const uint8_t *)a; A.n_rows = (int64_t)n;
+  for (int grid : {1021, 1024, 2048, 4093, 8192, 16381}) {
+    float t[8];
+    t[0] = time_ms(s, 10, [&] { k_mm<0, true><<<grid, 256, 0, s>>>(A, out); });
+    t[1] = time_ms(s, 10, [&] { k_mm<0, false><<<grid, 256, 0, s>>>(A, out); });
+    t[2] = time_ms(s, 10, [&] { k_mm<1, true><<<grid, 256, 0, s>>>(A, out); });
+    t[3] = time_ms(s, 10, [&] { k_mm<1, false><<<grid, 256, 0, s>>>(A, out); });
+    t[4] = time_ms(s, 10, [&] { k_mm<2, true><<<grid, 256, 0, s>>>(A, out); });
+    t[5] = time_ms(s, 10, [&] { k_mm<2, false><<<grid, 256, 0, s>>>(A, out); });
+    t[6] = time_ms(s, 10, [&] { k_mm<3, true><<<grid, 256, 0, s>>>(A, out); });
+    t[7] = time_ms(s, 10, [&] { k_mm<3, false><<<grid, 256, 0, s>>>(A, out); });
+    printf("mm 800 MB grid=%5d us: strided4 nt %.0f plain %.0f | tile4 nt %.0f plain %.0f | single nt %.0f plain %.0f | tile8 nt %.0f plain %.0f\n", grid,
+           t[0] * 1e3, t[1] * 1e3, t[2] * 1e3, t[3] * 1e3, t[4] * 1e3, t[5] * 1e3, t[6] * 1e3, t[7] * 1e3);
+  }
+  CHECK(hipFree(a)); CHECK(hipFree(out));
 }
 
 // ---- ldsatom -------------------------------------------------------------------------------------------
@@ -171,6 +242,7 @@ int main(int argc, char **argv) {
   const char *t = argc > 1 ? argv[1] : "all";
   CHECK(hipSetDevice(0));
   if (!strcmp(t, "bw") || !strcmp(t, "all")) test_bw();
+  if (!strcmp(t, "mm") || !strcmp(t, "all")) test_mm();
   if (!strcmp(t, "ldsatom") || !strcmp(t, "all")) test_ldsatom();
   if (!strcmp(t, "gatom") || !strcmp(t, "all")) test_gatom();
   return 0;
