@@ -1033,7 +1033,10 @@ int estimate_groups_sampled(const Plan &P, uint64_t &g_est) {
     if (getenv("PLHIP_DEBUG_EST")) fprintf(stderr, "estimate: round %d n %lld ns %lld d %.0f f1 %.0f flags %u %u %u %u %u %u %u %u\n", round, (long long)n, (long long)ns, d, f1, f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
     const bool more = round == 0 && n >= 32 * ns; // a second sample is possible and worth its time
     const bool saturated = d >= 0.95 * (double)ns;
-    if (saturated && more) { ns = std::min<int64_t>((n / 16) & ~(int64_t)255, ns2_cap); continue; }
+    // (an all-distinct first sample means no heavy hitters: 2^20 keys then settle G up to ~5e8 -- 1 024 repeats -- to a few per
+    // cent, a quarter of the full second sample's time: 0.38 -> 0.1 ms on config 3.  The skew branch below keeps the full sample:
+    // config 5 at 2^20 read 4x too few groups and paid an overflow retry, 41 -> 152 ms)
+    if (saturated && more) { ns = std::min<int64_t>((n / 16) & ~(int64_t)255, std::min<int64_t>(ns2_cap, (int64_t)1 << 20)); continue; }
     // (almost) all distinct: the model still reads G ~ s^2 / (2 * repeats) while the sample holds enough repeated keys
     // for that count to mean something (4M samples of 1e9 rows over 1e8 ids: 8e4 repeats, +-0.4 %)
     if (saturated && (double)ns - d < 1024.0) {
