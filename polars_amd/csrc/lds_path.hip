@@ -450,6 +450,7 @@ DEVINL uint64_t part_row_key(const Plan &P, int64_t row) {
   return row_packed_key(P, row, isnull); // partitioned plans carry nulls inside the packed code
 }
 
+#define PH_ROWS 4
 __global__ void __launch_bounds__(PART_BLOCK) k_part_hist(Plan P, uint32_t pbits, int64_t tile_rows, uint32_t n_tiles,
                                                           uint32_t *__restrict__ counts) {
   __shared__ uint32_t h[PART_MAX];
@@ -458,8 +459,40 @@ __global__ void __launch_bounds__(PART_BLOCK) k_part_hist(Plan P, uint32_t pbits
   __syncthreads();
   const int64_t r0 = (int64_t)blockIdx.x * tile_rows;
   const int64_t r1 = r0 + tile_rows < P.n_rows ? r0 + tile_rows : P.n_rows;
-  for (int64_t row = r0 + threadIdx.x; row < r1; row += PART_BLOCK)
-    atomicAdd(&h[part_of(mix_a(part_row_key(P, row)), pbits)], 1u);
+  // Tuples of 2 .. 4 eight-byte key columns without nulls (config 3: three i64 ids): row_packed_key's loop over a run-time number
+  // of columns of run-time type makes every load wait for the one before (3.8 TB/s on config 3's 2.4 GB of keys).  Here the same
+  // arithmetic -- (norm - minv + nullable) << shift, OR-ed -- runs over loads that are all requested first, PH_ROWS rows at a time.
+  // Only whole multiples of PH_ROWS * PART_BLOCK rows take it (every row then lies below r1 by construction); anything else keeps the loop below.
+  bool wide = !P.prepacked && !P.single_key && P.n_keys >= 2 && P.n_keys <= 4 && ((r1 - r0) % (PH_ROWS * PART_BLOCK)) == 0;
+  uint64_t flip[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+    if (i < P.n_keys) {
+      const uint32_t dt = P.keys[i].dtype;
+      wide = wide && !P.keys[i].validity && (dt == PLHIP_I64 || dt == PLHIP_U64 || dt == PLHIP_F64);
+      flip[i] = dt == PLHIP_I64 ? SIGN64 : 0ull; // load_key_norm of an 8-byte column
+    }
+  if (wide) {
+    const int nk = P.n_keys;
+    for (int64_t row = r0 + threadIdx.x; row < r1; row += PH_ROWS * PART_BLOCK) {
+      uint64_t raw[PH_ROWS][4];
+#pragma unroll
+      for (int u = 0; u < PH_ROWS; u++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) raw[u][i] = i < nk ? ((const uint64_t *)P.keys[i].values)[row + (int64_t)u * PART_BLOCK] : 0ull;
+#pragma unroll
+      for (int u = 0; u < PH_ROWS; u++) {
+        uint64_t packed = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if (i < nk) packed |= ((raw[u][i] ^ flip[i]) - P.keys[i].minv + P.keys[i].nullable) << P.keys[i].shift;
+        atomicAdd(&h[part_of(mix_a(packed), pbits)], 1u);
+      }
+    }
+  } else {
+    for (int64_t row = r0 + threadIdx.x; row < r1; row += PART_BLOCK)
+      atomicAdd(&h[part_of(mix_a(part_row_key(P, row)), pbits)], 1u);
+  }
   __syncthreads();
   for (uint32_t p = threadIdx.x; p < np; p += PART_BLOCK) counts[(uint64_t)p * n_tiles + blockIdx.x] = h[p];
 }
