@@ -35,3 +35,16 @@ for how, code in (("inner", 0), ("left", 1)):
         if it:
             best = min(best, dt)
     print(f"{how} join: {n} x {m} rows -> {rows} pairs: {best * 1e3:.3f} ms = {(n + m) / best / 1e9:.2f} Grows/s", flush=True)
+
+# the CPU port beside it (oracle: the reference's single-threaded build + probe restated in C; checker, timed once here)
+from oracle import oracle as orc  # noqa: E402
+
+hl, hr = Column("k", lk.cpu().numpy()), Column("k", rk.cpu().numpy())
+orc.lib()
+t0 = time.perf_counter()
+li, ri = orc.hash_join(hl, hr, "inner")
+dt = time.perf_counter() - t0
+print(f"oracle (CPU port, 1 thread) inner join: {len(li)} pairs in {dt * 1e3:.0f} ms = {(n + m) / dt / 1e9:.3f} Grows/s", flush=True)
+# algorithmic bytes: both key columns read once, two u32 index arrays written once
+ab = (n + m) * 4 + 2 * 4 * rows
+print(f"algorithmic bytes {ab / 1e6:.0f} MB -> {ab / best / 1e9:.0f} GB/s = {ab / best / 8e12 * 100:.1f} % of 8 TB/s (left join timing)", flush=True)
