@@ -450,7 +450,6 @@ DEVINL uint64_t part_row_key(const Plan &P, int64_t row) {
   return row_packed_key(P, row, isnull); // partitioned plans carry nulls inside the packed code
 }
 
-#define PH_ROWS 4
 __global__ void __launch_bounds__(PART_BLOCK) k_part_hist(Plan P, uint32_t pbits, int64_t tile_rows, uint32_t n_tiles,
                                                           uint32_t *__restrict__ counts) {
   __shared__ uint32_t h[PART_MAX];
@@ -459,21 +458,33 @@ __global__ void __launch_bounds__(PART_BLOCK) k_part_hist(Plan P, uint32_t pbits
   __syncthreads();
   const int64_t r0 = (int64_t)blockIdx.x * tile_rows;
   const int64_t r1 = r0 + tile_rows < P.n_rows ? r0 + tile_rows : P.n_rows;
-  // Tuples of 2 .. 4 eight-byte key columns without nulls (config 3: three i64 ids): row_packed_key's loop over a run-time number
-  // of columns of run-time type makes every load wait for the one before (3.8 TB/s on config 3's 2.4 GB of keys).  Here the same
-  // arithmetic -- (norm - minv + nullable) << shift, OR-ed -- runs over loads that are all requested first, PH_ROWS rows at a time.
-  // Only whole multiples of PH_ROWS * PART_BLOCK rows take it (every row then lies below r1 by construction); anything else keeps the loop below.
-  bool wide = !P.prepacked && !P.single_key && P.n_keys >= 2 && P.n_keys <= 4 && ((r1 - r0) % (PH_ROWS * PART_BLOCK)) == 0;
-  uint64_t flip[4] = {0, 0, 0, 0};
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-    if (i < P.n_keys) {
-      const uint32_t dt = P.keys[i].dtype;
-      wide = wide && !P.keys[i].validity && (dt == PLHIP_I64 || dt == PLHIP_U64 || dt == PLHIP_F64);
-      flip[i] = dt == PLHIP_I64 ? SIGN64 : 0ull; // load_key_norm of an 8-byte column
-    }
-  if (wide) {
+  for (int64_t row = r0 + threadIdx.x; row < r1; row += PART_BLOCK)
+    atomicAdd(&h[part_of(mix_a(part_row_key(P, row)), pbits)], 1u);
+  __syncthreads();
+  for (uint32_t p = threadIdx.x; p < np; p += PART_BLOCK) counts[(uint64_t)p * n_tiles + blockIdx.x] = h[p];
+}
+
+// The same histogram for tuples of 2 .. 4 eight-byte key columns without nulls (config 3: three i64 ids; launch_part_hist checks the
+// plan): row_packed_key's loop over a run-time number of columns of run-time type makes every load wait for the one before (3.8 TB/s
+// on config 3's 2.4 GB of keys).  Here the same arithmetic -- (norm - minv + nullable) << shift, OR-ed -- runs over loads that are all
+// requested first, PH_ROWS rows at a time.  Only workgroups whose row count is a whole multiple of PH_ROWS * PART_BLOCK take that
+// loop (every row then lies below r1 by construction); the last, ragged tile keeps the row-at-a-time loop.  (A kernel of its own:
+// with both loops in k_part_hist the single-key histogram of config 5 went from 2.1 to 3.2 ms.)
+#define PH_ROWS 4
+__global__ void __launch_bounds__(PART_BLOCK) k_part_hist_wide(Plan P, uint32_t pbits, int64_t tile_rows, uint32_t n_tiles,
+                                                               uint32_t *__restrict__ counts) {
+  __shared__ uint32_t h[PART_MAX];
+  const uint32_t np = 1u << pbits;
+  for (uint32_t p = threadIdx.x; p < np; p += PART_BLOCK) h[p] = 0;
+  __syncthreads();
+  const int64_t r0 = (int64_t)blockIdx.x * tile_rows;
+  const int64_t r1 = r0 + tile_rows < P.n_rows ? r0 + tile_rows : P.n_rows;
+  if (((r1 - r0) % (PH_ROWS * PART_BLOCK)) == 0) {
     const int nk = P.n_keys;
+    uint64_t flip[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      if (i < nk) flip[i] = P.keys[i].dtype == PLHIP_I64 ? SIGN64 : 0ull; // load_key_norm of an 8-byte column
     for (int64_t row = r0 + threadIdx.x; row < r1; row += PH_ROWS * PART_BLOCK) {
       uint64_t raw[PH_ROWS][4];
 #pragma unroll
@@ -721,7 +732,11 @@ __global__ void __launch_bounds__(PART_BLOCK) k_part_scatter(Plan P, PartOut O, 
 }
 
 void launch_part_hist(const Plan &p, uint32_t pbits, int64_t tile_rows, uint32_t n_tiles, uint32_t *counts, hipStream_t s) {
-  hipLaunchKernelGGL(k_part_hist, dim3(n_tiles), dim3(PART_BLOCK), 0, s, p, pbits, tile_rows, n_tiles, counts);
+  bool wide = !p.prepacked && !p.single_key && p.n_keys >= 2 && p.n_keys <= 4; // tuples of 8-byte columns without nulls
+  for (int i = 0; wide && i < p.n_keys; i++)
+    wide = !p.keys[i].validity && (p.keys[i].dtype == PLHIP_I64 || p.keys[i].dtype == PLHIP_U64 || p.keys[i].dtype == PLHIP_F64);
+  if (wide) hipLaunchKernelGGL(k_part_hist_wide, dim3(n_tiles), dim3(PART_BLOCK), 0, s, p, pbits, tile_rows, n_tiles, counts);
+  else hipLaunchKernelGGL(k_part_hist, dim3(n_tiles), dim3(PART_BLOCK), 0, s, p, pbits, tile_rows, n_tiles, counts);
 }
 void launch_part_scan(uint32_t *counts, uint32_t np, uint32_t n_tiles, uint32_t *totals, hipStream_t s) {
   hipLaunchKernelGGL(k_part_scan, dim3(np), dim3(256), 0, s, counts, n_tiles, totals);
